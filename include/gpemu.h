@@ -1,0 +1,142 @@
+/*
+ * gpemu.h -- C-ABI of the MI355X (gfx950) device library for the
+ * MADAIEmulator GP hot path (libgpemu_hip.so).
+ *
+ * Plain C: opaque handle, plain pointers and sizes, int status returns.  No
+ * GSL and no torch types cross this boundary.  Every entry point names the
+ * reference interface it stands in for (paths relative to the reference's
+ * src/ directory).  All matrices are row-major, element (i,j) at a[i*ld+j]
+ * (the gsl_matrix layout); all arithmetic is IEEE fp64.
+ *
+ * Threading: a gpemu_ctx owns one HIP stream and its own HBM workspace; one
+ * ctx per host thread (this is what the reference's per-thread
+ * estimate_thetas_params deep copy becomes, libEmu/estimate_threaded.c:57-68).
+ * Different ctx objects may be used concurrently.
+ *
+ * There is no CPU fallback: every compute entry fails with
+ * GPEMU_ERR_NO_DEVICE / GPEMU_ERR_HIP when no gfx950 device is usable.
+ */
+#ifndef GPEMU_H
+#define GPEMU_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* covariance-function index, optstruct.h:12-14 */
+#define GPEMU_POWEREXP 1
+#define GPEMU_MATERN32 2
+#define GPEMU_MATERN52 3
+
+#define GPEMU_MAX_PARAMS 64   /* largest design dimension d accepted */
+
+/* status codes */
+#define GPEMU_OK              0
+#define GPEMU_ERR_ARG         1   /* bad argument / model not set */
+#define GPEMU_ERR_NO_DEVICE   2   /* no HIP device */
+#define GPEMU_ERR_HIP         3   /* a HIP runtime call failed; see gpemu_last_error */
+#define GPEMU_ERR_NOT_PD      4   /* Cholesky met a pivot <= 0 (GSL_EDOM in the reference) */
+#define GPEMU_ERR_REGRESSION  5   /* H^T C^-1 H not positive definite (regression.c:134-160) */
+#define GPEMU_ERR_STATE       6   /* call order (e.g. predict before predict_setup) */
+
+typedef struct gpemu_ctx gpemu_ctx;
+
+/* ---- context ------------------------------------------------------- */
+int  gpemu_ctx_create(gpemu_ctx **out, int device);
+void gpemu_ctx_destroy(gpemu_ctx *ctx);
+const char *gpemu_last_error(const gpemu_ctx *ctx);
+const char *gpemu_version(void);
+int  gpemu_device_count(void);
+
+/* ---- model data (modelstruct.h:28-98: xmodel, training_vector) ------
+ * Uploads the N x d design and the N training values to HBM and builds the
+ * regression basis H (regression.c:9-67,100-112: nreg = 1 + order*d) there.
+ * cov_fn_index is GPEMU_POWEREXP / MATERN32 / MATERN52. */
+int gpemu_set_model(gpemu_ctx *ctx, int cov_fn_index, int regression_order,
+                    int nmodel_points, int nparams,
+                    const double *xmodel /* N*d host */, const double *training_vector /* N host */);
+/* replace only the training vector (multi_modelstruct: same design, nr PCA columns) */
+int gpemu_set_training(gpemu_ctx *ctx, const double *training_vector);
+
+/* ---- a4: makeCovMatrix_fnptr (libEmu/emulator.c:636-653) -----------
+ * Full N x N covariance matrix (both triangles) for the model's design at
+ * the full theta vector, written to host memory c_out[N*N]. */
+int gpemu_cov_matrix(gpemu_ctx *ctx, const double *thetas, int nthetas, double *c_out);
+
+/* ---- a16: makeKVector_fnptr (libEmu/emulator.c:578-593) ------------
+ * k[q*N + i] = cov(x_i, xq_q), entries < 1e-10 clamped to 0; M query rows. */
+int gpemu_kvectors(gpemu_ctx *ctx, const double *thetas, int nthetas,
+                   int npoints, const double *xq /* M*d host */, double *k_out /* M*N host */);
+
+/* ---- a11: evalFnMulti / a9 estimateSigma / a10 getLogLikelyhood -----
+ * (libEmu/maxmultimin.c:288-394, 215-273; libEmu/estimator-fns.c:38-103)
+ * One likelihood evaluation at FULL thetas (the reference's evalFnMulti
+ * passes theta[0] = 0; the drop-in wrapper does that).  Outputs (any may be
+ * NULL):  neg_loglik = -logL with log det = 2*sum(log L_ii);  sigma2 =
+ * y.Cinv.(y - H beta)/N;  beta[nreg];  logdet;  quad = r.Cinv.r.
+ * *info = 0, or 1-based index of the first pivot <= 0 (then
+ * GPEMU_ERR_NOT_PD is returned and the outputs are NaN). */
+int gpemu_loglik(gpemu_ctx *ctx, const double *thetas, int nthetas,
+                 double *neg_loglik, double *sigma2, double *beta,
+                 double *logdet, double *quad, int *info);
+/* as above, but only enqueues the device work (no host sync, no outputs):
+ * used by the throughput bench to time back-to-back evaluations; follow the
+ * last call with gpemu_loglik_collect. */
+int gpemu_loglik_enqueue(gpemu_ctx *ctx, const double *thetas, int nthetas);
+int gpemu_loglik_collect(gpemu_ctx *ctx, double *neg_loglik, double *sigma2, double *beta,
+                         double *logdet, double *quad, int *info);
+
+/* ---- a12: gradFnMulti + getGradientCn (maxmultimin.c:416-550,571-608)
+ * grad[nthetas-1] as the reference defines it (literal formulas, SURVEY
+ * App. A.3): thetas are the FULL vector with theta[0] ignored (set to 0 for
+ * the matrix, replaced by log sigma^2 for the amplitude factor). */
+int gpemu_grad(gpemu_ctx *ctx, const double *thetas, int nthetas, double *grad, int *info);
+
+/* ---- a14/a15: chol_inverse_cov_matrix + alloc_emulator_struct -------
+ * (libEmu/emulate-fns.c:275-299, emulator_struct.c:13-37)
+ * Factorises C(thetas) once and keeps L^-1, C^-1 [y|H], beta and
+ * (H^T C^-1 H)^-1 resident in HBM.  beta_out[nreg] optional. */
+int gpemu_predict_setup(gpemu_ctx *ctx, const double *thetas, int nthetas, double *beta_out, int *info);
+/* optional: explicit C^-1 (N*N, both triangles) for emulator_struct.cinverse */
+int gpemu_get_cinverse(gpemu_ctx *ctx, double *cinv_out);
+
+/* ---- a19: emulate_point, batched (emulator_struct.c:124-143) --------
+ * mean[q], var[q] for M query rows xq[M*d].  Host buffers. */
+int gpemu_predict_batch(gpemu_ctx *ctx, int npoints, const double *xq, double *mean, double *var);
+/* same with query / result buffers already resident in HBM (device pointers) */
+int gpemu_predict_batch_dev(gpemu_ctx *ctx, int npoints, const double *xq_dev,
+                            double *mean_dev, double *var_dev);
+
+/* ---- device memory helpers for callers that keep data resident ------ */
+int gpemu_dev_alloc(gpemu_ctx *ctx, size_t bytes, void **dptr);
+int gpemu_dev_free(gpemu_ctx *ctx, void *dptr);
+int gpemu_dev_upload(gpemu_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int gpemu_dev_download(gpemu_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int gpemu_sync(gpemu_ctx *ctx);
+
+/* ---- measurement: HIP-event timing of the kernels on ctx's stream ---
+ * gpemu_prof_begin arms per-kernel-class event timing; every launch of that
+ * class between begin and end is bracketed by hipEvents on the ctx stream.
+ * gpemu_prof_end returns the number of launches and their summed duration. */
+#define GPEMU_PROF_NONE    0
+#define GPEMU_PROF_GEMM    1   /* f64 MFMA trailing-update / prediction GEMM */
+#define GPEMU_PROF_FILL    2   /* covariance fill */
+#define GPEMU_PROF_LEAF    3   /* diagonal-block factor + panel solve */
+#define GPEMU_PROF_POTRF   4   /* whole factorisation (graph launch) */
+int gpemu_prof_begin(gpemu_ctx *ctx, int kernel_class);
+int gpemu_prof_end(gpemu_ctx *ctx, int *nlaunches, double *total_ms, double *flops, double *bytes);
+
+/* ---- low-level building blocks exported for parity tests ------------ */
+/* C[m*n] = beta*C + alpha * A[m*K] * B[n*K]^T, host row-major buffers */
+int gpemu_test_gemm_nt(gpemu_ctx *ctx, int m, int n, int k, double alpha, int beta,
+                       const double *a, const double *b, double *c);
+/* in-place lower Cholesky of a host n*n matrix (both triangles read as lower);
+ * returns L in the lower triangle, zeros above. */
+int gpemu_test_potrf(gpemu_ctx *ctx, int n, double *a, int *info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPEMU_H */

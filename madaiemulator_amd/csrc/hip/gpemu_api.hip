@@ -1,0 +1,888 @@
+// gpemu_api.hip -- C-ABI entry points (include/gpemu.h) and host-side
+// orchestration of the gfx950 kernels: recursive tall-matrix Cholesky with the
+// right-hand sides (and optionally the identity) riding along as extra rows,
+// likelihood assembly, prediction set-up and the batched prediction sweep.
+#include "gpemu_internal.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <climits>
+#include <algorithm>
+
+using namespace gpemu;
+
+#define HIPCHK(ctx, call)                                                                       \
+	do {                                                                                        \
+		hipError_t e__ = (call);                                                                \
+		if (e__ != hipSuccess) {                                                                \
+			char buf__[512];                                                                    \
+			snprintf(buf__, sizeof buf__, "%s:%d: %s -> %s", __FILE__, __LINE__, #call,         \
+			         hipGetErrorString(e__));                                                   \
+			(ctx)->err = buf__;                                                                 \
+			return GPEMU_ERR_HIP;                                                               \
+		}                                                                                       \
+	} while (0)
+
+constexpr int INFO_NONE = 0x7f7f7f7f;   // "no failed pivot": what hipMemsetAsync(.., 0x7f, ..) leaves in *info
+
+static int fail(gpemu_ctx *ctx, int code, const char *msg)
+{
+	if (ctx) ctx->err = msg;
+	return code;
+}
+
+// ---------------------------------------------------------------------------
+// profiling helpers
+// ---------------------------------------------------------------------------
+static inline bool prof_on(gpemu_ctx *ctx, int cls) { return ctx->prof.cls == cls; }
+
+static void prof_mark(gpemu_ctx *ctx)
+{
+	hipEvent_t e;
+	hipEventCreate(&e);
+	hipEventRecord(e, ctx->stream);
+	ctx->prof.ev.push_back(e);
+}
+
+struct ProfScope {
+	gpemu_ctx *ctx;
+	bool on;
+	ProfScope(gpemu_ctx *c, int cls, double flops, double bytes) : ctx(c), on(prof_on(c, cls))
+	{
+		if (on) {
+			prof_mark(ctx);
+			ctx->prof.flops += flops;
+			ctx->prof.bytes += bytes;
+			ctx->prof.n++;
+		}
+	}
+	~ProfScope() { if (on) prof_mark(ctx); }
+};
+
+static hipError_t gemm(gpemu_ctx *ctx, const GemmArgs &a)
+{
+	// executed flops: 2*m*n*k over the tiles/k-range actually visited
+	double fl = 0.0;
+	if (prof_on(ctx, GPEMU_PROF_GEMM)) {
+		const int tm_n = (a.m + GEMM_BM - 1) / GEMM_BM, tn_n = (a.n + GEMM_BN - 1) / GEMM_BN;
+		for (int tm = 0; tm < tm_n; tm++)
+			for (int tn = 0; tn < tn_n; tn++) {
+				if (a.tri && tn * GEMM_BN > tm * GEMM_BM + GEMM_BM - 1 + a.diag_off) continue;
+				int kb = a.k0, ke = a.k1;
+				if (a.kstart_mode) { int ks = (tm * GEMM_BM - a.kstart_off) & ~(GEMM_BK - 1); if (ks > kb) kb = ks; }
+				if (a.kend_mode) { int kx = (tn * GEMM_BN + GEMM_BN - a.kend_off + GEMM_BK - 1) & ~(GEMM_BK - 1); if (kx < ke) ke = kx; }
+				if (ke <= kb) continue;
+				const int mm = std::min(GEMM_BM, a.m - tm * GEMM_BM), nn = std::min(GEMM_BN, a.n - tn * GEMM_BN);
+				fl += 2.0 * mm * nn * (double)(ke - kb);
+			}
+	}
+	ProfScope ps(ctx, GPEMU_PROF_GEMM, fl, 0.0);
+	return launch_gemm(ctx->stream, a);
+}
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+extern "C" const char *gpemu_version(void) { return "gpemu-mi355x 0.1 (gfx950, fp64 MFMA)"; }
+
+extern "C" int gpemu_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+extern "C" int gpemu_ctx_create(gpemu_ctx **out, int device)
+{
+	if (!out) return GPEMU_ERR_ARG;
+	*out = nullptr;
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return GPEMU_ERR_NO_DEVICE;
+	if (device < 0 || device >= n) return GPEMU_ERR_ARG;
+	gpemu_ctx *ctx = new gpemu_ctx();
+	ctx->device = device;
+	if (hipSetDevice(device) != hipSuccess) { delete ctx; return GPEMU_ERR_HIP; }
+	if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return GPEMU_ERR_HIP; }
+	ctx->res_len = 64 * 64 + 8;
+	if (hipMalloc(&ctx->dInfo, sizeof(int)) != hipSuccess ||
+	    hipMalloc(&ctx->dRes, ctx->res_len * sizeof(double)) != hipSuccess ||
+	    hipHostMalloc((void **)&ctx->hRes, ctx->res_len * sizeof(double)) != hipSuccess ||
+	    hipHostMalloc((void **)&ctx->hInfo, sizeof(int)) != hipSuccess) {
+		gpemu_ctx_destroy(ctx);
+		return GPEMU_ERR_HIP;
+	}
+	const char *ng = getenv("GPEMU_NO_GRAPH");
+	if (ng && ng[0] == '1') ctx->use_graph = false;
+	*out = ctx;
+	return GPEMU_OK;
+}
+
+static void free_graphs(gpemu_ctx *ctx)
+{
+	for (auto &kv : ctx->graphs) hipGraphExecDestroy(kv.second);
+	ctx->graphs.clear();
+}
+
+static void free_model(gpemu_ctx *ctx)
+{
+	free_graphs(ctx);
+	double **ptrs[] = {&ctx->dX, &ctx->dY, &ctx->dRrows, &ctx->dT, &ctx->dGramPart, &ctx->dLinvAug, &ctx->dBetaQ,
+	                   &ctx->dKq, &ctx->dV, &ctx->dXq, &ctx->dMean, &ctx->dVar, &ctx->dS, &ctx->dGradPart};
+	for (auto p : ptrs) { if (*p) hipFree(*p); *p = nullptr; }
+	ctx->T_rows = 0; ctx->pred_ready = false; ctx->cinv_ready = false; ctx->pred_batch = 0; ctx->stage_cap = 0;
+	ctx->S_dim = 0; ctx->gradpart_len = 0;
+}
+
+extern "C" void gpemu_ctx_destroy(gpemu_ctx *ctx)
+{
+	if (!ctx) return;
+	hipSetDevice(ctx->device);
+	if (ctx->stream) hipStreamSynchronize(ctx->stream);
+	free_model(ctx);
+	for (auto e : ctx->prof.ev) hipEventDestroy(e);
+	if (ctx->dInfo) hipFree(ctx->dInfo);
+	if (ctx->dRes) hipFree(ctx->dRes);
+	if (ctx->hRes) hipHostFree(ctx->hRes);
+	if (ctx->hInfo) hipHostFree(ctx->hInfo);
+	if (ctx->stream) hipStreamDestroy(ctx->stream);
+	delete ctx;
+}
+
+extern "C" const char *gpemu_last_error(const gpemu_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+extern "C" int gpemu_sync(gpemu_ctx *ctx)
+{
+	if (!ctx) return GPEMU_ERR_ARG;
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	return GPEMU_OK;
+}
+
+extern "C" int gpemu_dev_alloc(gpemu_ctx *ctx, size_t bytes, void **dptr)
+{
+	if (!ctx || !dptr) return GPEMU_ERR_ARG;
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	HIPCHK(ctx, hipMalloc(dptr, bytes));
+	return GPEMU_OK;
+}
+extern "C" int gpemu_dev_free(gpemu_ctx *ctx, void *dptr)
+{
+	if (!ctx) return GPEMU_ERR_ARG;
+	HIPCHK(ctx, hipFree(dptr));
+	return GPEMU_OK;
+}
+extern "C" int gpemu_dev_upload(gpemu_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+	if (!ctx) return GPEMU_ERR_ARG;
+	HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	return GPEMU_OK;
+}
+extern "C" int gpemu_dev_download(gpemu_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+	if (!ctx) return GPEMU_ERR_ARG;
+	HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	return GPEMU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// model
+// ---------------------------------------------------------------------------
+static int ensure_T(gpemu_ctx *ctx, size_t rows)
+{
+	if (ctx->T_rows >= rows) return GPEMU_OK;
+	free_graphs(ctx);
+	if (ctx->dT) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); hipFree(ctx->dT); ctx->dT = nullptr; }
+	HIPCHK(ctx, hipMalloc(&ctx->dT, rows * (size_t)ctx->Np * sizeof(double)));
+	ctx->T_rows = rows;
+	return GPEMU_OK;
+}
+
+extern "C" int gpemu_set_model(gpemu_ctx *ctx, int kind, int order, int N, int d, const double *X, const double *y)
+{
+	if (!ctx || !X || !y) return GPEMU_ERR_ARG;
+	if (kind < GPEMU_POWEREXP || kind > GPEMU_MATERN52) return fail(ctx, GPEMU_ERR_ARG, "bad cov_fn_index");
+	if (order < 0 || order > 3) return fail(ctx, GPEMU_ERR_ARG, "regression_order must be 0..3");
+	if (N < 1 || d < 1 || d > GPEMU_MAX_PARAMS) return fail(ctx, GPEMU_ERR_ARG, "bad N or nparams");
+	const int nreg = 1 + order * d;
+	if (nreg + 1 > 64) return fail(ctx, GPEMU_ERR_ARG, "1 + nregression_fns must be <= 64");
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	free_model(ctx);
+	ctx->kind = kind; ctx->order = order; ctx->N = N; ctx->d = d; ctx->nreg = nreg; ctx->nrhs = nreg + 1;
+	ctx->Np = round_up(N, LEAF);
+	ctx->Rp = 64;
+	ctx->hX.assign(X, X + (size_t)N * d);
+	ctx->hY.assign(y, y + N);
+	HIPCHK(ctx, hipMalloc(&ctx->dX, (size_t)N * d * sizeof(double)));
+	HIPCHK(ctx, hipMalloc(&ctx->dY, (size_t)N * sizeof(double)));
+	HIPCHK(ctx, hipMalloc(&ctx->dRrows, (size_t)ctx->Rp * ctx->Np * sizeof(double)));
+	HIPCHK(ctx, hipMalloc(&ctx->dGramPart, (size_t)(ctx->Np / 64) * ctx->Rp * ctx->Rp * sizeof(double)));
+	HIPCHK(ctx, hipMemcpyAsync(ctx->dX, ctx->hX.data(), (size_t)N * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+	HIPCHK(ctx, hipMemcpyAsync(ctx->dY, ctx->hY.data(), (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+	HIPCHK(ctx, launch_build_rrows(ctx->stream, ctx->dRrows, ctx->Np, ctx->Rp, ctx->dX, ctx->dY, N, d, order));
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	int rc = ensure_T(ctx, (size_t)ctx->Np + ctx->Rp);
+	return rc;
+}
+
+extern "C" int gpemu_set_training(gpemu_ctx *ctx, const double *y)
+{
+	if (!ctx || !y || !ctx->dX) return GPEMU_ERR_ARG;
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	ctx->hY.assign(y, y + ctx->N);
+	HIPCHK(ctx, hipMemcpyAsync(ctx->dY, ctx->hY.data(), (size_t)ctx->N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+	HIPCHK(ctx, launch_build_rrows(ctx->stream, ctx->dRrows, ctx->Np, ctx->Rp, ctx->dX, ctx->dY, ctx->N, ctx->d, ctx->order));
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	ctx->pred_ready = false; ctx->cinv_ready = false;
+	return GPEMU_OK;
+}
+
+static int nthetas_for(const gpemu_ctx *ctx) { return ctx->kind == GPEMU_POWEREXP ? ctx->d + 2 : 3; }
+
+// theta layout: modelstruct.c:300-308.  pow-exp exponentiates everything
+// (emulator.c:115-123); the Matern kernels take amp and nugget raw (:355-357).
+static int make_cov_params(gpemu_ctx *ctx, const double *thetas, int nthetas, CovParams *p)
+{
+	if (!thetas) return fail(ctx, GPEMU_ERR_ARG, "thetas is NULL");
+	if (nthetas < nthetas_for(ctx)) return fail(ctx, GPEMU_ERR_ARG, "nthetas too small for this covariance function");
+	memset(p, 0, sizeof *p);
+	p->kind = ctx->kind;
+	p->d = ctx->d;
+	if (ctx->kind == GPEMU_POWEREXP) {
+		p->amp = exp(thetas[0]);
+		p->nug = exp(thetas[1]);
+		p->eps = 0.0000000001;
+		for (int k = 0; k < ctx->d; k++) {
+			double r = exp(thetas[k + 2]);
+			p->w[k] = -0.5 / (r * r);
+		}
+	} else {
+		p->amp = thetas[0];
+		p->nug = thetas[1];
+		p->eps = 0.0000000000000001;
+		p->w[0] = 1.0 / exp(thetas[2]);
+	}
+	return GPEMU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// recursive tall Cholesky
+//   T rows [0,Np)            : C (lower), identity padded
+//   T rows [Np,Np+Rp)        : right-hand sides as rows (y, H columns) -> Z^T = (L^-1 [y|H])^T
+//   T rows [Np+Rp,Np+Rp+Np)  : identity -> U = L^-T (only with inv)
+// potrf_rec(c0,n) factors the column panel [c0,c0+n) for every row below it.
+// ---------------------------------------------------------------------------
+static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv)
+{
+	const long ld = ctx->Np;
+	const int base_end = ctx->Np + ctx->Rp;
+	if (n <= LEAF) {
+		const int row_end = base_end + (inv ? c0 + LEAF : 0);
+		ProfScope ps(ctx, GPEMU_PROF_LEAF, 0.0, 0.0);
+		return launch_leaf(ctx->stream, ctx->dT, ld, c0, row_end - (c0 + LEAF), ctx->dInfo);
+	}
+	const int n1 = ((n / LEAF + 1) / 2) * LEAF;
+	hipError_t e = potrf_rec(ctx, c0, n1, inv);
+	if (e != hipSuccess) return e;
+	GemmArgs g;
+	memset(&g, 0, sizeof g);
+	const int r0 = c0 + n1;
+	const int row_end = base_end + (inv ? c0 + n1 : 0);
+	g.C = ctx->dT + (long)r0 * ld + r0;
+	g.A = ctx->dT + (long)r0 * ld + c0;
+	g.B = g.A;
+	g.ldc = g.lda = g.ldb = ld;
+	g.m = row_end - r0;
+	g.n = n - n1;
+	g.k0 = 0; g.k1 = n1;
+	g.alpha = -1.0; g.beta = 1;
+	g.tri = 1; g.diag_off = 0;
+	e = gemm(ctx, g);
+	if (e != hipSuccess) return e;
+	return potrf_rec(ctx, r0, n - n1, inv);
+}
+
+static int run_potrf(gpemu_ctx *ctx, int inv)
+{
+	const bool profiling = ctx->prof.cls == GPEMU_PROF_GEMM || ctx->prof.cls == GPEMU_PROF_LEAF;
+	double fl = (double)ctx->Np * ctx->Np * ctx->Np / 3.0;
+	ProfScope ps(ctx, GPEMU_PROF_POTRF, fl, 0.0);
+	if (!ctx->use_graph || profiling) {
+		HIPCHK(ctx, potrf_rec(ctx, 0, ctx->Np, inv));
+		return GPEMU_OK;
+	}
+	gpemu_ctx::GraphKey key{ctx->Np, ctx->Rp, inv};
+	auto it = ctx->graphs.find(key);
+	if (it == ctx->graphs.end()) {
+		hipGraph_t graph = nullptr;
+		HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+		hipError_t e = potrf_rec(ctx, 0, ctx->Np, inv);
+		hipError_t e2 = hipStreamEndCapture(ctx->stream, &graph);
+		if (e != hipSuccess || e2 != hipSuccess) {
+			if (graph) hipGraphDestroy(graph);
+			ctx->err = "potrf graph capture failed";
+			return GPEMU_ERR_HIP;
+		}
+		hipGraphExec_t exec = nullptr;
+		HIPCHK(ctx, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+		hipGraphDestroy(graph);
+		it = ctx->graphs.emplace(key, exec).first;
+	}
+	HIPCHK(ctx, hipGraphLaunch(it->second, ctx->stream));
+	return GPEMU_OK;
+}
+
+// fill C(theta) into T (lower tiles only), load the RHS rows, reset info
+static int stage_matrix(gpemu_ctx *ctx, const CovParams &p, int inv)
+{
+	const int Np = ctx->Np, Rp = ctx->Rp;
+	int rc = ensure_T(ctx, (size_t)Np + Rp + (inv ? Np : 0));
+	if (rc) return rc;
+	{
+		const double nlow = 0.5 * (double)Np * Np;
+		ProfScope ps(ctx, GPEMU_PROF_FILL, 0.0, 8.0 * nlow);
+		HIPCHK(ctx, launch_cov_fill(ctx->stream, ctx->dT, Np, ctx->dX, ctx->N, Np, ctx->dX, ctx->N, Np, ctx->d, p,
+		                            FILL_LOWER | FILL_IDENT_PAD));
+	}
+	HIPCHK(ctx, hipMemcpyAsync(ctx->dT + (size_t)Np * Np, ctx->dRrows, (size_t)Rp * Np * sizeof(double),
+	                           hipMemcpyDeviceToDevice, ctx->stream));
+	if (inv)
+		HIPCHK(ctx, launch_set_identity_rows(ctx->stream, ctx->dT + (size_t)(Np + Rp) * Np, Np, Np));
+	HIPCHK(ctx, hipMemsetAsync(ctx->dInfo, 0x7f, sizeof(int), ctx->stream));
+	return GPEMU_OK;
+}
+
+static int enqueue_results(gpemu_ctx *ctx)
+{
+	const int Np = ctx->Np, Rp = ctx->Rp;
+	HIPCHK(ctx, launch_gram_partials(ctx->stream, ctx->dT + (size_t)Np * Np, Np, Np, ctx->nrhs, Rp, ctx->dGramPart));
+	HIPCHK(ctx, launch_finish(ctx->stream, ctx->dGramPart, Np / 64, Rp, ctx->nrhs, ctx->dT, Np, ctx->N, ctx->dRes));
+	HIPCHK(ctx, hipMemcpyAsync(ctx->hRes, ctx->dRes, ((size_t)Rp * Rp + 1) * sizeof(double), hipMemcpyDeviceToHost,
+	                           ctx->stream));
+	HIPCHK(ctx, hipMemcpyAsync(ctx->hInfo, ctx->dInfo, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+	return GPEMU_OK;
+}
+
+// small dense Cholesky solve on the host (nreg x nreg): beta and Q = (H^T C^-1 H)^-1
+// (regression.c:120-176 estimateBeta restated on the Gram matrix)
+static bool small_chol_inverse(std::vector<double> &A, int n)
+{
+	for (int j = 0; j < n; j++) {
+		double dsum = A[j * n + j];
+		for (int k = 0; k < j; k++) dsum -= A[j * n + k] * A[j * n + k];
+		if (!(dsum > 0.0)) return false;
+		const double l = sqrt(dsum);
+		A[j * n + j] = l;
+		for (int i = j + 1; i < n; i++) {
+			double s = A[i * n + j];
+			for (int k = 0; k < j; k++) s -= A[i * n + k] * A[j * n + k];
+			A[i * n + j] = s / l;
+		}
+	}
+	// invert L, then A^-1 = L^-T L^-1
+	std::vector<double> Li((size_t)n * n, 0.0);
+	for (int c = 0; c < n; c++)
+		for (int i = c; i < n; i++) {
+			double s = (i == c) ? 1.0 : 0.0;
+			for (int k = c; k < i; k++) s -= A[i * n + k] * Li[k * n + c];
+			Li[i * n + c] = s / A[i * n + i];
+		}
+	for (int i = 0; i < n; i++)
+		for (int j = 0; j < n; j++) {
+			double s = 0.0;
+			for (int k = std::max(i, j); k < n; k++) s += Li[k * n + i] * Li[k * n + j];
+			A[i * n + j] = s;
+		}
+	return true;
+}
+
+struct HostLik { double yy, quad, sigma2, logdet; std::vector<double> beta, Q, Hy; int status; };
+
+static HostLik host_likelihood(gpemu_ctx *ctx)
+{
+	HostLik r;
+	const int Rp = ctx->Rp, nreg = ctx->nreg;
+	const double *G = ctx->hRes;
+	r.logdet = G[Rp * Rp];
+	r.yy = G[0];
+	r.Hy.resize(nreg);
+	r.Q.assign((size_t)nreg * nreg, 0.0);
+	std::vector<double> HH((size_t)nreg * nreg);
+	for (int a = 0; a < nreg; a++) {
+		r.Hy[a] = G[(1 + a) * Rp];
+		for (int b = 0; b < nreg; b++) HH[a * nreg + b] = G[(1 + a) * Rp + 1 + b];
+	}
+	r.Q = HH;
+	r.beta.assign(nreg, NAN);
+	r.quad = r.sigma2 = NAN;
+	if (!small_chol_inverse(r.Q, nreg)) { r.status = GPEMU_ERR_REGRESSION; return r; }
+	for (int a = 0; a < nreg; a++) {
+		double s = 0.0;
+		for (int b = 0; b < nreg; b++) s += r.Q[a * nreg + b] * r.Hy[b];
+		r.beta[a] = s;
+	}
+	double bHy = 0.0, bHHb = 0.0;
+	for (int a = 0; a < nreg; a++) {
+		bHy += r.beta[a] * r.Hy[a];
+		double s = 0.0;
+		for (int b = 0; b < nreg; b++) s += HH[a * nreg + b] * r.beta[b];
+		bHHb += r.beta[a] * s;
+	}
+	r.sigma2 = (r.yy - bHy) / (double)ctx->N;           // y.Cinv.(y - H beta)/N   (maxmultimin.c:259-263)
+	r.quad = r.yy - 2.0 * bHy + bHHb;                   // r.Cinv.r               (estimator-fns.c:87-88)
+	r.status = GPEMU_OK;
+	return r;
+}
+
+extern "C" int gpemu_loglik_enqueue(gpemu_ctx *ctx, const double *thetas, int nthetas)
+{
+	if (!ctx || !ctx->dX) return ctx ? fail(ctx, GPEMU_ERR_STATE, "model not set") : GPEMU_ERR_ARG;
+	CovParams p;
+	int rc = make_cov_params(ctx, thetas, nthetas, &p);
+	if (rc) return rc;
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	rc = stage_matrix(ctx, p, 0);
+	if (rc) return rc;
+	rc = run_potrf(ctx, 0);
+	if (rc) return rc;
+	ctx->pred_ready = false; ctx->cinv_ready = false;
+	return enqueue_results(ctx);
+}
+
+extern "C" int gpemu_loglik_collect(gpemu_ctx *ctx, double *neg_loglik, double *sigma2, double *beta, double *logdet,
+                                    double *quad, int *info)
+{
+	if (!ctx) return GPEMU_ERR_ARG;
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	const int inf = (*ctx->hInfo >= INFO_NONE) ? 0 : *ctx->hInfo;
+	if (info) *info = inf;
+	if (inf != 0) {
+		if (neg_loglik) *neg_loglik = NAN;
+		if (sigma2) *sigma2 = NAN;
+		if (logdet) *logdet = NAN;
+		if (quad) *quad = NAN;
+		if (beta) for (int a = 0; a < ctx->nreg; a++) beta[a] = NAN;
+		return fail(ctx, GPEMU_ERR_NOT_PD, "covariance matrix is not positive definite");
+	}
+	HostLik r = host_likelihood(ctx);
+	if (beta) for (int a = 0; a < ctx->nreg; a++) beta[a] = r.beta[a];
+	if (sigma2) *sigma2 = r.sigma2;
+	if (logdet) *logdet = r.logdet;
+	if (quad) *quad = r.quad;
+	if (neg_loglik) {
+		const double log_2_pi = 1.83788;                                     // estimator-fns.c:48 (literal)
+		const double ll = -(1.0 / 2.0) * r.logdet - (ctx->N / 2.0) * log_2_pi + r.quad * (-1.0 / 2.0);
+		*neg_loglik = -1 * ll;
+	}
+	if (r.status) return fail(ctx, r.status, "H^T C^-1 H is not positive definite");
+	return GPEMU_OK;
+}
+
+extern "C" int gpemu_loglik(gpemu_ctx *ctx, const double *thetas, int nthetas, double *neg_loglik, double *sigma2,
+                            double *beta, double *logdet, double *quad, int *info)
+{
+	int rc = gpemu_loglik_enqueue(ctx, thetas, nthetas);
+	if (rc) return rc;
+	return gpemu_loglik_collect(ctx, neg_loglik, sigma2, beta, logdet, quad, info);
+}
+
+// ---------------------------------------------------------------------------
+// covariance matrix / k vectors to host
+// ---------------------------------------------------------------------------
+extern "C" int gpemu_cov_matrix(gpemu_ctx *ctx, const double *thetas, int nthetas, double *c_out)
+{
+	if (!ctx || !c_out) return GPEMU_ERR_ARG;
+	if (!ctx->dX) return fail(ctx, GPEMU_ERR_STATE, "model not set");
+	CovParams p;
+	int rc = make_cov_params(ctx, thetas, nthetas, &p);
+	if (rc) return rc;
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	const int Np = ctx->Np, N = ctx->N;
+	double *buf = nullptr;
+	HIPCHK(ctx, hipMalloc(&buf, (size_t)Np * Np * sizeof(double)));
+	hipError_t e = launch_cov_fill(ctx->stream, buf, Np, ctx->dX, N, Np, ctx->dX, N, Np, ctx->d, p, 0);
+	if (e == hipSuccess)
+		e = hipMemcpy2DAsync(c_out, (size_t)N * sizeof(double), buf, (size_t)Np * sizeof(double),
+		                     (size_t)N * sizeof(double), N, hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	hipFree(buf);
+	HIPCHK(ctx, e);
+	return GPEMU_OK;
+}
+
+extern "C" int gpemu_kvectors(gpemu_ctx *ctx, const double *thetas, int nthetas, int M, const double *xq, double *k_out)
+{
+	if (!ctx || !xq || !k_out || M < 1) return GPEMU_ERR_ARG;
+	if (!ctx->dX) return fail(ctx, GPEMU_ERR_STATE, "model not set");
+	CovParams p;
+	int rc = make_cov_params(ctx, thetas, nthetas, &p);
+	if (rc) return rc;
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	const int Np = ctx->Np, N = ctx->N, Mp = round_up(M, 64);
+	double *buf = nullptr, *dq = nullptr;
+	HIPCHK(ctx, hipMalloc(&buf, (size_t)Mp * Np * sizeof(double)));
+	hipError_t e = hipMalloc(&dq, (size_t)M * ctx->d * sizeof(double));
+	if (e == hipSuccess) e = hipMemcpyAsync(dq, xq, (size_t)M * ctx->d * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+	if (e == hipSuccess) e = launch_cov_fill(ctx->stream, buf, Np, dq, M, Mp, ctx->dX, N, Np, ctx->d, p, FILL_CLAMP);
+	if (e == hipSuccess)
+		e = hipMemcpy2DAsync(k_out, (size_t)N * sizeof(double), buf, (size_t)Np * sizeof(double),
+		                     (size_t)N * sizeof(double), M, hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	hipFree(buf);
+	if (dq) hipFree(dq);
+	HIPCHK(ctx, e);
+	return GPEMU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// prediction
+// ---------------------------------------------------------------------------
+static int factor_with_inverse(gpemu_ctx *ctx, const double *thetas, int nthetas, CovParams *p, int *info)
+{
+	int rc = make_cov_params(ctx, thetas, nthetas, p);
+	if (rc) return rc;
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	rc = stage_matrix(ctx, *p, 1);
+	if (rc) return rc;
+	rc = run_potrf(ctx, 1);
+	if (rc) return rc;
+	rc = enqueue_results(ctx);
+	if (rc) return rc;
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	const int inf = (*ctx->hInfo >= INFO_NONE) ? 0 : *ctx->hInfo;
+	if (info) *info = inf;
+	if (inf) return fail(ctx, GPEMU_ERR_NOT_PD, "covariance matrix is not positive definite");
+	return GPEMU_OK;
+}
+
+extern "C" int gpemu_predict_setup(gpemu_ctx *ctx, const double *thetas, int nthetas, double *beta_out, int *info)
+{
+	if (!ctx) return GPEMU_ERR_ARG;
+	if (!ctx->dX) return fail(ctx, GPEMU_ERR_STATE, "model not set");
+	ctx->pred_ready = false; ctx->cinv_ready = false;
+	CovParams p;
+	int rc = factor_with_inverse(ctx, thetas, nthetas, &p, info);
+	if (rc) return rc;
+	HostLik r = host_likelihood(ctx);
+	if (r.status) return fail(ctx, r.status, "H^T C^-1 H is not positive definite");
+
+	const int Np = ctx->Np, Rp = ctx->Rp, nreg = ctx->nreg, N = ctx->N;
+	const size_t la_rows = (size_t)Np + Rp;
+	if (!ctx->dLinvAug) HIPCHK(ctx, hipMalloc(&ctx->dLinvAug, la_rows * Np * sizeof(double)));
+	if (!ctx->dBetaQ) HIPCHK(ctx, hipMalloc(&ctx->dBetaQ, (size_t)(nreg + nreg * nreg) * sizeof(double)));
+	const double *Zt = ctx->dT + (size_t)Np * Np;
+	const double *U = ctx->dT + (size_t)(Np + Rp) * Np;
+	// rows [0,Np): L^-1 = U^T
+	HIPCHK(ctx, launch_transpose(ctx->stream, ctx->dLinvAug, Np, U, Np, Np));
+	// (C^-1 [y|H])^T = Z^T U^T : rows Np.. of LinvAug used as scratch first
+	GemmArgs g;
+	memset(&g, 0, sizeof g);
+	g.C = ctx->dLinvAug + (size_t)Np * Np; g.ldc = Np;
+	g.A = Zt; g.lda = Np;
+	g.B = U; g.ldb = Np;
+	g.m = Rp; g.n = Np; g.k0 = 0; g.k1 = Np; g.alpha = 1.0; g.beta = 0;
+	HIPCHK(ctx, gemm(ctx, g));
+	std::vector<double> cr((size_t)Rp * Np);
+	HIPCHK(ctx, hipMemcpyAsync(cr.data(), ctx->dLinvAug + (size_t)Np * Np, cr.size() * sizeof(double),
+	                           hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	// row 0 <- gamma = C^-1 y - (C^-1 H) beta = C^-1 (y - H beta); rows 1.. keep W^T = (C^-1 H)^T
+	for (int j = 0; j < Np; j++) {
+		double s = cr[j];
+		for (int a = 0; a < nreg; a++) s -= r.beta[a] * cr[(size_t)(1 + a) * Np + j];
+		cr[j] = (j < N) ? s : 0.0;
+	}
+	for (int a = ctx->nrhs; a < Rp; a++)
+		for (int j = 0; j < Np; j++) cr[(size_t)a * Np + j] = 0.0;
+	HIPCHK(ctx, hipMemcpyAsync(ctx->dLinvAug + (size_t)Np * Np, cr.data(), cr.size() * sizeof(double),
+	                           hipMemcpyHostToDevice, ctx->stream));
+	std::vector<double> bq(nreg + (size_t)nreg * nreg);
+	for (int a = 0; a < nreg; a++) bq[a] = r.beta[a];
+	for (int a = 0; a < nreg * nreg; a++) bq[nreg + a] = r.Q[a];
+	HIPCHK(ctx, hipMemcpyAsync(ctx->dBetaQ, bq.data(), bq.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	ctx->h_beta = r.beta; ctx->h_Q = r.Q;
+	ctx->pred_cov = p;
+	ctx->kappa = p.amp + p.nug;                       // cov(x*,x*): emulator_struct.c:135 (nugget included)
+	ctx->pred_ready = true;
+	ctx->last_thetas.assign(thetas, thetas + nthetas);
+	if (beta_out) for (int a = 0; a < nreg; a++) beta_out[a] = r.beta[a];
+	return GPEMU_OK;
+}
+
+static int ensure_pred_batch(gpemu_ctx *ctx, int mb)
+{
+	if (ctx->pred_batch >= mb) return GPEMU_OK;
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	if (ctx->dKq) hipFree(ctx->dKq);
+	if (ctx->dV) hipFree(ctx->dV);
+	ctx->dKq = ctx->dV = nullptr; ctx->pred_batch = 0;
+	HIPCHK(ctx, hipMalloc(&ctx->dKq, (size_t)mb * ctx->Np * sizeof(double)));
+	HIPCHK(ctx, hipMalloc(&ctx->dV, (size_t)mb * (ctx->Np + ctx->Rp) * sizeof(double)));
+	ctx->pred_batch = mb;
+	return GPEMU_OK;
+}
+
+constexpr int PRED_BATCH_MAX = 16384;
+
+extern "C" int gpemu_predict_batch_dev(gpemu_ctx *ctx, int M, const double *xq_dev, double *mean_dev, double *var_dev)
+{
+	if (!ctx || M < 1 || !xq_dev || !mean_dev || !var_dev) return GPEMU_ERR_ARG;
+	if (!ctx->pred_ready) return fail(ctx, GPEMU_ERR_STATE, "gpemu_predict_setup has not been called");
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	const int Np = ctx->Np, Rp = ctx->Rp, N = ctx->N, d = ctx->d;
+	const int cap = std::min(PRED_BATCH_MAX, round_up(M, 64));
+	int rc = ensure_pred_batch(ctx, cap);
+	if (rc) return rc;
+	for (int q0 = 0; q0 < M; q0 += cap) {
+		const int mb = std::min(cap, M - q0);
+		const int mbp = round_up(mb, 64);
+		{
+			ProfScope ps(ctx, GPEMU_PROF_FILL, 0.0, 8.0 * (double)mbp * Np);
+			HIPCHK(ctx, launch_cov_fill(ctx->stream, ctx->dKq, Np, xq_dev + (size_t)q0 * d, mb, mbp, ctx->dX, N, Np, d,
+			                            ctx->pred_cov, FILL_CLAMP));
+		}
+		GemmArgs g;
+		memset(&g, 0, sizeof g);
+		g.C = ctx->dV; g.ldc = Np + Rp;
+		g.A = ctx->dKq; g.lda = Np;
+		g.B = ctx->dLinvAug; g.ldb = Np;
+		g.m = mb; g.n = Np + Rp; g.k0 = 0; g.k1 = Np; g.alpha = 1.0; g.beta = 0;
+		g.kend_mode = 1; g.kend_off = 0;
+		HIPCHK(ctx, gemm(ctx, g));
+		HIPCHK(ctx, launch_predict_finish(ctx->stream, ctx->dV, Np + Rp, mb, Np, ctx->nreg, ctx->order, d,
+		                                  xq_dev + (size_t)q0 * d, ctx->dBetaQ, ctx->kappa, mean_dev + q0, var_dev + q0));
+	}
+	return GPEMU_OK;
+}
+
+extern "C" int gpemu_predict_batch(gpemu_ctx *ctx, int M, const double *xq, double *mean, double *var)
+{
+	if (!ctx || M < 1 || !xq || !mean || !var) return GPEMU_ERR_ARG;
+	if (!ctx->pred_ready) return fail(ctx, GPEMU_ERR_STATE, "gpemu_predict_setup has not been called");
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	if (ctx->stage_cap < M) {
+		HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+		if (ctx->dXq) hipFree(ctx->dXq);
+		if (ctx->dMean) hipFree(ctx->dMean);
+		if (ctx->dVar) hipFree(ctx->dVar);
+		ctx->dXq = ctx->dMean = ctx->dVar = nullptr; ctx->stage_cap = 0;
+		HIPCHK(ctx, hipMalloc(&ctx->dXq, (size_t)M * ctx->d * sizeof(double)));
+		HIPCHK(ctx, hipMalloc(&ctx->dMean, (size_t)M * sizeof(double)));
+		HIPCHK(ctx, hipMalloc(&ctx->dVar, (size_t)M * sizeof(double)));
+		ctx->stage_cap = M;
+	}
+	HIPCHK(ctx, hipMemcpyAsync(ctx->dXq, xq, (size_t)M * ctx->d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+	int rc = gpemu_predict_batch_dev(ctx, M, ctx->dXq, ctx->dMean, ctx->dVar);
+	if (rc) return rc;
+	HIPCHK(ctx, hipMemcpyAsync(mean, ctx->dMean, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(ctx, hipMemcpyAsync(var, ctx->dVar, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	return GPEMU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// explicit inverse: S = Aug Aug^T with Aug = [Z^T ; U]  ->  S[Rp+i][Rp+j] = (C^-1)_ij,
+// S[Rp+i][a] = (C^-1 [y|H])_ia   (lower triangle only)
+// ---------------------------------------------------------------------------
+static int build_corner(gpemu_ctx *ctx)
+{
+	const int Np = ctx->Np, Rp = ctx->Rp;
+	const size_t dim = (size_t)Np + Rp;
+	if (ctx->S_dim < dim) {
+		if (ctx->dS) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); hipFree(ctx->dS); ctx->dS = nullptr; }
+		HIPCHK(ctx, hipMalloc(&ctx->dS, dim * dim * sizeof(double)));
+		ctx->S_dim = dim;
+	}
+	GemmArgs g;
+	memset(&g, 0, sizeof g);
+	g.C = ctx->dS; g.ldc = (long)dim;
+	g.A = ctx->dT + (size_t)Np * Np; g.lda = Np;
+	g.B = g.A; g.ldb = Np;
+	g.m = (int)dim; g.n = (int)dim; g.k0 = 0; g.k1 = Np; g.alpha = 1.0; g.beta = 0;
+	g.tri = 1; g.diag_off = 0;
+	g.kstart_mode = 1; g.kstart_off = Rp;
+	HIPCHK(ctx, gemm(ctx, g));
+	return GPEMU_OK;
+}
+
+extern "C" int gpemu_get_cinverse(gpemu_ctx *ctx, double *cinv_out)
+{
+	if (!ctx || !cinv_out) return GPEMU_ERR_ARG;
+	if (!ctx->pred_ready) return fail(ctx, GPEMU_ERR_STATE, "gpemu_predict_setup has not been called");
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	if (!ctx->cinv_ready) {
+		int rc = build_corner(ctx);
+		if (rc) return rc;
+		ctx->cinv_ready = true;
+	}
+	const int N = ctx->N, Rp = ctx->Rp;
+	const size_t dim = ctx->S_dim;
+	HIPCHK(ctx, hipMemcpy2DAsync(cinv_out, (size_t)N * sizeof(double), ctx->dS + (size_t)Rp * dim + Rp,
+	                             dim * sizeof(double), (size_t)N * sizeof(double), N, hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	for (int i = 0; i < N; i++)
+		for (int j = i + 1; j < N; j++) cinv_out[(size_t)i * N + j] = cinv_out[(size_t)j * N + i];
+	return GPEMU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// gradient (gradFnMulti, maxmultimin.c:416-550)
+// ---------------------------------------------------------------------------
+extern "C" int gpemu_grad(gpemu_ctx *ctx, const double *thetas, int nthetas, double *grad, int *info)
+{
+	if (!ctx || !grad) return GPEMU_ERR_ARG;
+	if (!ctx->dX) return fail(ctx, GPEMU_ERR_STATE, "model not set");
+	if (ctx->kind != GPEMU_POWEREXP)
+		return fail(ctx, GPEMU_ERR_ARG,
+		            "gradient only for the power-exponential kernel: the reference's Matern derivative matrices "
+		            "carry an accumulator across elements (emulator.c:410-425) and cannot be reproduced in parallel");
+	if (nthetas < ctx->d + 2) return fail(ctx, GPEMU_ERR_ARG, "nthetas too small");
+	std::vector<double> th(thetas, thetas + nthetas);
+	th[0] = 0.0;                                      // maxmultimin.c:441
+	ctx->pred_ready = false; ctx->cinv_ready = false;
+	CovParams p;
+	int rc = factor_with_inverse(ctx, th.data(), nthetas, &p, info);
+	if (rc) return rc;
+	HostLik r = host_likelihood(ctx);
+	if (r.status) return fail(ctx, r.status, "H^T C^-1 H is not positive definite");
+	rc = build_corner(ctx);
+	if (rc) return rc;
+	const int N = ctx->N, d = ctx->d, Rp = ctx->Rp;
+	const size_t dim = ctx->S_dim;
+	// alpha = C^-1 y  = column 0 of the [I rows x R cols] block
+	double *dAlpha = nullptr, *dGp = nullptr;
+	HIPCHK(ctx, hipMalloc(&dAlpha, (size_t)N * sizeof(double)));
+	hipError_t e = hipMalloc(&dGp, (size_t)d * sizeof(double));
+	if (e == hipSuccess)
+		e = hipMemcpy2DAsync(dAlpha, sizeof(double), ctx->dS + (size_t)Rp * dim, dim * sizeof(double), sizeof(double), N,
+		                     hipMemcpyDeviceToDevice, ctx->stream);
+	if (e == hipSuccess)
+		e = hipMemcpyAsync(dGp, th.data() + 2, (size_t)d * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+	const int nt = (N + 63) / 64, ntiles = nt * (nt + 1) / 2;
+	const size_t need = (size_t)ntiles * (2 * d + 1);
+	if (e == hipSuccess && ctx->gradpart_len < need) {
+		if (ctx->dGradPart) hipFree(ctx->dGradPart);
+		ctx->dGradPart = nullptr; ctx->gradpart_len = 0;
+		e = hipMalloc(&ctx->dGradPart, need * sizeof(double));
+		if (e == hipSuccess) ctx->gradpart_len = need;
+	}
+	int nparts = 0;
+	if (e == hipSuccess)
+		e = launch_grad_partials(ctx->stream, ctx->dS, (long)dim, Rp, ctx->dX, N, d, dAlpha, ctx->kind, dGp,
+		                         ctx->dGradPart, &nparts);
+	std::vector<double> part(need), alpha(N);
+	if (e == hipSuccess)
+		e = hipMemcpyAsync(part.data(), ctx->dGradPart, need * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess)
+		e = hipMemcpyAsync(alpha.data(), dAlpha, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	hipFree(dAlpha);
+	if (dGp) hipFree(dGp);
+	HIPCHK(ctx, e);
+	std::vector<double> sums(2 * d + 1, 0.0);
+	for (int t = 0; t < nparts; t++)
+		for (int k = 0; k < 2 * d + 1; k++) sums[k] += part[(size_t)t * (2 * d + 1) + k];
+	double aa = 0.0;
+	for (int i = 0; i < N; i++) aa += alpha[i] * alpha[i];
+	const double amp = exp(log(r.sigma2));            // maxmultimin.c:503,514
+	const double nug = exp(th[1]);                    // :515
+	// G(dC) = -1/2 tr(A dC) + 1/2 alpha^T dC alpha ;  grad = -G   (:527,535; getGradientCn :571-608)
+	grad[0] = -1.0 * (-0.5 * nug * sums[2 * d] + 0.5 * nug * aa);
+	for (int k = 0; k < d; k++)
+		grad[k + 1] = -1.0 * (amp * (-0.5 * sums[2 * k] + 0.5 * sums[2 * k + 1]));
+	return GPEMU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// profiling
+// ---------------------------------------------------------------------------
+extern "C" int gpemu_prof_begin(gpemu_ctx *ctx, int cls)
+{
+	if (!ctx) return GPEMU_ERR_ARG;
+	for (auto e : ctx->prof.ev) hipEventDestroy(e);
+	ctx->prof.ev.clear();
+	ctx->prof.cls = cls; ctx->prof.flops = ctx->prof.bytes = 0; ctx->prof.n = 0;
+	return GPEMU_OK;
+}
+
+extern "C" int gpemu_prof_end(gpemu_ctx *ctx, int *nlaunches, double *total_ms, double *flops, double *bytes)
+{
+	if (!ctx) return GPEMU_ERR_ARG;
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	double ms = 0.0;
+	for (size_t i = 0; i + 1 < ctx->prof.ev.size(); i += 2) {
+		float t = 0.f;
+		hipEventElapsedTime(&t, ctx->prof.ev[i], ctx->prof.ev[i + 1]);
+		ms += t;
+	}
+	if (nlaunches) *nlaunches = ctx->prof.n;
+	if (total_ms) *total_ms = ms;
+	if (flops) *flops = ctx->prof.flops;
+	if (bytes) *bytes = ctx->prof.bytes;
+	for (auto e : ctx->prof.ev) hipEventDestroy(e);
+	ctx->prof.ev.clear();
+	ctx->prof.cls = GPEMU_PROF_NONE;
+	return GPEMU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// building blocks exported for the parity tests
+// ---------------------------------------------------------------------------
+extern "C" int gpemu_test_gemm_nt(gpemu_ctx *ctx, int m, int n, int k, double alpha, int beta, const double *a,
+                                  const double *b, double *c)
+{
+	if (!ctx || m < 1 || n < 1 || k < 1 || (k % GEMM_BK) != 0) return GPEMU_ERR_ARG;
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	double *da = nullptr, *db = nullptr, *dc = nullptr;
+	HIPCHK(ctx, hipMalloc(&da, (size_t)m * k * 8));
+	HIPCHK(ctx, hipMalloc(&db, (size_t)n * k * 8));
+	HIPCHK(ctx, hipMalloc(&dc, (size_t)m * n * 8));
+	HIPCHK(ctx, hipMemcpy(da, a, (size_t)m * k * 8, hipMemcpyHostToDevice));
+	HIPCHK(ctx, hipMemcpy(db, b, (size_t)n * k * 8, hipMemcpyHostToDevice));
+	HIPCHK(ctx, hipMemcpy(dc, c, (size_t)m * n * 8, hipMemcpyHostToDevice));
+	GemmArgs g;
+	memset(&g, 0, sizeof g);
+	g.C = dc; g.A = da; g.B = db; g.ldc = n; g.lda = k; g.ldb = k; g.m = m; g.n = n; g.k0 = 0; g.k1 = k;
+	g.alpha = alpha; g.beta = beta;
+	HIPCHK(ctx, gemm(ctx, g));
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	HIPCHK(ctx, hipMemcpy(c, dc, (size_t)m * n * 8, hipMemcpyDeviceToHost));
+	hipFree(da); hipFree(db); hipFree(dc);
+	return GPEMU_OK;
+}
+
+extern "C" int gpemu_test_potrf(gpemu_ctx *ctx, int n, double *a, int *info)
+{
+	if (!ctx || n < 1 || !a) return GPEMU_ERR_ARG;
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	// run through a scratch ctx-like state: temporarily adopt sizes
+	gpemu_ctx tmp;
+	tmp.device = ctx->device; tmp.stream = ctx->stream; tmp.use_graph = false;
+	tmp.Np = round_up(n, LEAF); tmp.Rp = 64; tmp.N = n; tmp.nrhs = 0;
+	const int Np = tmp.Np;
+	std::vector<double> h((size_t)(Np + 64) * Np, 0.0);
+	for (int i = 0; i < Np; i++)
+		for (int j = 0; j <= i; j++)
+			h[(size_t)i * Np + j] = (i < n) ? a[(size_t)i * n + j] : (i == j ? 1.0 : 0.0);
+	hipError_t e = hipMalloc(&tmp.dT, h.size() * 8);
+	if (e == hipSuccess) e = hipMalloc(&tmp.dInfo, sizeof(int));
+	int big = INFO_NONE;
+	if (e == hipSuccess) e = hipMemcpy(tmp.dT, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(tmp.dInfo, &big, sizeof(int), hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = potrf_rec(&tmp, 0, Np, 0);
+	if (e == hipSuccess) e = hipStreamSynchronize(tmp.stream);
+	if (e == hipSuccess) e = hipMemcpy(h.data(), tmp.dT, h.size() * 8, hipMemcpyDeviceToHost);
+	int inf = 0;
+	if (e == hipSuccess) e = hipMemcpy(&inf, tmp.dInfo, sizeof(int), hipMemcpyDeviceToHost);
+	if (tmp.dT) hipFree(tmp.dT);
+	if (tmp.dInfo) hipFree(tmp.dInfo);
+	tmp.dT = nullptr; tmp.dInfo = nullptr; tmp.stream = nullptr;
+	HIPCHK(ctx, e);
+	if (info) *info = (inf >= INFO_NONE) ? 0 : inf;
+	for (int i = 0; i < n; i++)
+		for (int j = 0; j < n; j++) a[(size_t)i * n + j] = (j <= i) ? h[(size_t)i * Np + j] : 0.0;
+	return GPEMU_OK;
+}

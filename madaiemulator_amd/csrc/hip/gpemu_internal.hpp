@@ -1,0 +1,134 @@
+// gpemu_internal.hpp -- shared declarations of the gfx950 device library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+#include <map>
+
+#include "gpemu.h"
+
+namespace gpemu {
+
+constexpr int LEAF = 64;          // diagonal block / padding granule
+constexpr int GEMM_BM = 128;
+constexpr int GEMM_BN = 128;
+constexpr int GEMM_BK = 16;
+
+inline int round_up(int x, int m) { return ((x + m - 1) / m) * m; }
+
+// Covariance parameters handed to kernels by value.
+// pow-exp (emulator.c:101-152): amp = exp(t0), nug = exp(t1), w[k] = -0.5/exp(t_{k+2})^2, eps = 1e-10
+// Matern  (emulator.c:344-386, 438-480): amp = t0, nug = t1, w[0] = 1/exp(t2), eps = 1e-16
+struct CovParams {
+	int kind;
+	int d;
+	double amp;
+	double nug;
+	double eps;
+	double w[GPEMU_MAX_PARAMS];
+};
+
+// C[m x n] = beta*C + alpha * A[m x K] * B[n x K]^T over k in [k0,k1)
+struct GemmArgs {
+	double *C;
+	const double *A;
+	const double *B;
+	long ldc, lda, ldb;
+	int m, n;
+	int k0, k1;          // multiples of GEMM_BK
+	double alpha;
+	int beta;            // 0 or 1
+	int tri;             // 1: skip tiles with tn*BN > tm*BM + BM-1 + diag_off
+	int diag_off;
+	int kstart_mode;     // 1: k starts at max(k0, floor_BK(tm*BM - kstart_off))   (upper-triangular A rows)
+	int kstart_off;
+	int kend_mode;       // 1: k ends at min(k1, ceil_BK(tn*BN + BN - kend_off))   (lower-triangular B rows)
+	int kend_off;
+};
+
+struct ProfState {
+	int cls = GPEMU_PROF_NONE;
+	std::vector<hipEvent_t> ev;   // pairs
+	double flops = 0, bytes = 0;
+	int n = 0;
+};
+
+} // namespace gpemu
+
+struct gpemu_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	std::string err;
+
+	// model
+	int kind = 0, order = 0, N = 0, d = 0, nreg = 0, nrhs = 0;
+	int Np = 0, Rp = 0;
+	double *dX = nullptr;        // N x d
+	double *dY = nullptr;        // N
+	double *dRrows = nullptr;    // Rp x Np : row 0 = y, rows 1..nreg = H columns, zero padded
+	std::vector<double> hX, hY;
+
+	// factorisation workspace: tall matrix T (rows x Np)
+	double *dT = nullptr;
+	size_t T_rows = 0;           // allocated rows
+	int *dInfo = nullptr;
+	double *dGramPart = nullptr; // [Np/128][Rp*Rp]
+	double *dRes = nullptr;      // Rp*Rp gram + logdet + spare
+	double *hRes = nullptr;      // pinned mirror
+	int *hInfo = nullptr;        // pinned
+	size_t res_len = 0;
+
+	// cached launch graphs for potrf, keyed by (Np, rows_total, with_inverse)
+	struct GraphKey { int Np; int aug_fixed; int inv; bool operator<(const GraphKey &o) const {
+		if (Np != o.Np) return Np < o.Np; if (aug_fixed != o.aug_fixed) return aug_fixed < o.aug_fixed; return inv < o.inv; } };
+	std::map<GraphKey, hipGraphExec_t> graphs;
+	bool use_graph = true;
+
+	// prediction state
+	bool pred_ready = false;
+	double *dLinvAug = nullptr;  // (Np + Rp) x Np : rows [0,Np) = L^-1, row Np = gamma, rows Np+1.. = W^T
+	double *dBetaQ = nullptr;    // beta (nreg) then Q (nreg*nreg)
+	double kappa = 0;
+	gpemu::CovParams pred_cov;
+	std::vector<double> h_beta, h_Q;
+	double *dKq = nullptr, *dV = nullptr; // batch buffers
+	int pred_batch = 0;
+	double *dXq = nullptr, *dMean = nullptr, *dVar = nullptr; // staging for host-buffer entry
+	int stage_cap = 0;
+	bool cinv_ready = false;
+	double *dS = nullptr;        // (Rp+Np)^2 corner for explicit inverse / gradient
+	size_t S_dim = 0;
+
+	// gradient scratch
+	double *dGradPart = nullptr;
+	size_t gradpart_len = 0;
+
+	gpemu::ProfState prof;
+	std::vector<double> last_thetas;
+};
+
+namespace gpemu {
+
+// ---- kernels_cov.hip
+hipError_t launch_cov_fill(hipStream_t s, double *out, long ld, const double *Xr, int nr, int nr_pad,
+                           const double *Xc, int nc, int nc_pad, int d, const CovParams &p, int mode);
+constexpr int FILL_LOWER = 1, FILL_CLAMP = 2, FILL_IDENT_PAD = 4;
+hipError_t launch_build_rrows(hipStream_t s, double *R, int Np, int Rp, const double *X, const double *y,
+                              int N, int d, int order);
+hipError_t launch_set_identity_rows(hipStream_t s, double *T, long ld, int n);
+hipError_t launch_transpose(hipStream_t s, double *dst, long ldd, const double *src, long lds, int n);
+hipError_t launch_predict_finish(hipStream_t s, const double *V, long ldv, int M, int Np, int nreg, int order, int d,
+                                 const double *Xq, const double *betaQ, double kappa, double *mean, double *var);
+hipError_t launch_grad_partials(hipStream_t s, const double *S, long lds, int soff, const double *X, int N, int d,
+                                const double *alpha, int kind, const double *gp /* d+2 scalars */, double *part, int *nparts);
+
+// ---- kernels_linalg.hip
+hipError_t launch_gemm(hipStream_t s, const GemmArgs &a);
+hipError_t launch_leaf(hipStream_t s, double *T, long ld, int c0, int m_below, int *info);
+hipError_t launch_gram_partials(hipStream_t s, const double *Z, long ld, int Np, int nrhs, int Rp, double *part);
+hipError_t launch_finish(hipStream_t s, const double *part, int nparts, int Rp, int nrhs, const double *T, long ld,
+                         int N, double *res);
+
+} // namespace gpemu

@@ -1,0 +1,333 @@
+// kernels_cov.hip -- covariance-function kernels for gfx950 (MI355X).
+//
+// cov_fill_kernel restates, per element, the three covariance functions of the
+// reference (libEmu/emulator.c:101-152 pow-exp, :344-386 Matern 3/2,
+// :438-480 Matern 5/2) and replaces the N^2 indirect calls of
+// makeCovMatrix_fnptr (:636-653) and the N calls + clamp of makeKVector_fnptr
+// (:578-593).  HBM-write-bound: 64x64 output tiles, every wave writes whole
+// 512-byte row segments; design rows are staged once per tile in LDS.
+#include "gpemu_internal.hpp"
+
+namespace gpemu {
+
+constexpr int FT = 64;            // fill tile edge
+constexpr int DCH = 8;            // dimensions handled per register chunk
+
+__device__ __forceinline__ double cov_finalize(const CovParams &p, double acc, bool same)
+{
+	double c;
+	if (p.kind == GPEMU_POWEREXP) {
+		c = exp(acc) * p.amp;                                   // emulator.c:141
+	} else {
+		const double dist = sqrt(acc);                          // emulator.c:373 / :467
+		const double s = dist * p.w[0];                          // distance / rho
+		if (p.kind == GPEMU_MATERN32) {
+			const double root3 = 1.732050808;                   // emulator.c:359 (literal)
+			c = (dist > 0.0) ? p.amp * (1 + root3 * s) * exp(-root3 * s) : p.amp;
+		} else {
+			const double root5 = 2.236067978;                   // emulator.c:452 (literal)
+			c = (dist > 0.0) ? p.amp * (1 + root5 * s + (5.0 / 3.0) * s * s) * exp(-root5 * s) : p.amp;
+		}
+	}
+	if (same) c += p.nug;                                       // emulator.c:147-150 / :382-384 / :476-478
+	return c;
+}
+
+// out[r][c] = cov(Xr[r], Xc[c]);  rows/cols beyond nr/nc (padding up to the
+// launch grid) get identity (square factorisation matrix) or zero.
+__global__ __launch_bounds__(256) void cov_fill_kernel(double *out, long ld, const double *Xr, int nr,
+                                                       const double *Xc, int nc, int d, CovParams p, int mode)
+{
+	const int tr = blockIdx.y, tc = blockIdx.x;
+	if ((mode & FILL_LOWER) && tc > tr) return;
+
+	__shared__ double xr_s[FT * (GPEMU_MAX_PARAMS + 1)];
+	const int tid = threadIdx.x;
+	const int sd = d + 1;
+	for (int e = tid; e < FT * d; e += 256) {
+		int r = e / d, k = e % d;
+		int gr = tr * FT + r;
+		xr_s[r * sd + k] = (gr < nr) ? Xr[(long)gr * d + k] : 0.0;
+	}
+	__syncthreads();
+
+	const int col = tc * FT + (tid & 63);
+	const int rsub = tid >> 6;                 // rows rsub, rsub+4, ...
+	const bool colv = col < nc;
+
+	double acc[16];
+	int cnt[16];
+#pragma unroll
+	for (int t = 0; t < 16; t++) { acc[t] = 0.0; cnt[t] = 0; }
+
+	for (int k0 = 0; k0 < d; k0 += DCH) {
+		double xc[DCH], wk[DCH];
+#pragma unroll
+		for (int k = 0; k < DCH; k++) {
+			const bool kv = (k0 + k) < d;
+			xc[k] = (kv && colv) ? Xc[(long)col * d + k0 + k] : 0.0;
+			wk[k] = kv ? ((p.kind == GPEMU_POWEREXP) ? p.w[k0 + k] : 1.0) : 0.0;
+		}
+#pragma unroll
+		for (int t = 0; t < 16; t++) {
+			const double *xr = &xr_s[(rsub + 4 * t) * sd + k0];
+#pragma unroll
+			for (int k = 0; k < DCH; k++) {
+				if (k0 + k < d) {
+					const double diff = fabs(xr[k] - xc[k]);
+					acc[t] += wk[k] * diff * diff;
+					cnt[t] += (diff < p.eps) ? 1 : 0;
+				}
+			}
+		}
+	}
+
+#pragma unroll
+	for (int t = 0; t < 16; t++) {
+		const int row = tr * FT + rsub + 4 * t;
+		double v;
+		if (row < nr && colv) {
+			v = cov_finalize(p, acc[t], cnt[t] == d);
+			if ((mode & FILL_CLAMP) && v < 1E-10) v = 0.0;          // emulator.c:588-590
+		} else {
+			v = ((mode & FILL_IDENT_PAD) && row == col) ? 1.0 : 0.0;
+		}
+		out[(long)row * ld + col] = v;
+	}
+}
+
+hipError_t launch_cov_fill(hipStream_t s, double *out, long ld, const double *Xr, int nr, int nr_pad,
+                           const double *Xc, int nc, int nc_pad, int d, const CovParams &p, int mode)
+{
+	dim3 grid(nc_pad / FT, nr_pad / FT);
+	hipLaunchKernelGGL(cov_fill_kernel, grid, dim3(256), 0, s, out, ld, Xr, nr, Xc, nc, d, p, mode);
+	return hipGetLastError();
+}
+
+// regression basis h(x) (libEmu/regression.c:9-67): h = [1, x, x^2, x^3] per coordinate
+__device__ __forceinline__ double hfun(int a, const double *x, int d)
+{
+	if (a == 0) return 1.0;
+	const int q = (a - 1) / d, k = (a - 1) % d;
+	const double v = x[k];
+	return q == 0 ? v : (q == 1 ? v * v : v * v * v);
+}
+
+// R rows (Rp x Np): row 0 = y, row 1+a = column a of the H matrix
+// (makeHMatrix_fnptr, regression.c:100-112), zero padded.
+__global__ void build_rrows_kernel(double *R, int Np, int Rp, const double *X, const double *y, int N, int d, int nreg)
+{
+	const int j = blockIdx.x * blockDim.x + threadIdx.x;
+	const int a = blockIdx.y;
+	if (j >= Np) return;
+	double v = 0.0;
+	if (j < N) {
+		if (a == 0) v = y[j];
+		else if (a <= nreg) v = hfun(a - 1, X + (long)j * d, d);
+	}
+	R[(long)a * Np + j] = v;
+}
+
+hipError_t launch_build_rrows(hipStream_t s, double *R, int Np, int Rp, const double *X, const double *y,
+                              int N, int d, int order)
+{
+	const int nreg = 1 + order * d;
+	dim3 grid((Np + 255) / 256, Rp);
+	hipLaunchKernelGGL(build_rrows_kernel, grid, dim3(256), 0, s, R, Np, Rp, X, y, N, d, nreg);
+	return hipGetLastError();
+}
+
+__global__ void set_identity_rows_kernel(double *T, long ld, int n)
+{
+	const long i = blockIdx.y;
+	const int j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < n) T[i * ld + j] = (i == j) ? 1.0 : 0.0;
+}
+
+hipError_t launch_set_identity_rows(hipStream_t s, double *T, long ld, int n)
+{
+	dim3 grid((n + 255) / 256, n);
+	hipLaunchKernelGGL(set_identity_rows_kernel, grid, dim3(256), 0, s, T, ld, n);
+	return hipGetLastError();
+}
+
+// dst[j][i] = src[i][j] for an n x n block (n multiple of 64)
+__global__ __launch_bounds__(256) void transpose_kernel(double *dst, long ldd, const double *src, long lds_, int n)
+{
+	__shared__ double t[64 * 65];
+	const int bi = blockIdx.y * 64, bj = blockIdx.x * 64;
+	const int tid = threadIdx.x;
+	for (int e = tid; e < 4096; e += 256) {
+		int r = e >> 6, c = e & 63;
+		t[r * 65 + c] = src[(long)(bi + r) * lds_ + bj + c];
+	}
+	__syncthreads();
+	for (int e = tid; e < 4096; e += 256) {
+		int r = e >> 6, c = e & 63;
+		dst[(long)(bj + r) * ldd + bi + c] = t[c * 65 + r];
+	}
+	(void)n;
+}
+
+hipError_t launch_transpose(hipStream_t s, double *dst, long ldd, const double *src, long lds_, int n)
+{
+	dim3 grid(n / 64, n / 64);
+	hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, dst, ldd, src, lds_, n);
+	return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Prediction epilogue (makeEmulatedMean / makeEmulatedVariance,
+// libEmu/emulator.c:672-704, 720-785), one wave per query row q of
+//   V[q] = [ L^-1 k*  (Np entries) | k*.gamma | k*.W (nreg entries) ]
+// mean = h.beta + k*.gamma ;  var = kappa - |L^-1 k*|^2 + q^T Q q,  q = h - W^T k*
+// betaQ = beta (nreg) followed by Q = (H^T C^-1 H)^-1 (nreg x nreg).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void predict_finish_kernel(const double *V, long ldv, int M, int Np, int nreg, int d,
+                                                             const double *Xq, const double *betaQ, double kappa,
+                                                             double *mean, double *var)
+{
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int q = blockIdx.x * 4 + wave;
+	if (q >= M) return;
+	const double *v = V + (long)q * ldv;
+	double ss = 0.0;
+	for (int i = lane * 2; i < Np; i += 128) {
+		const double2 t = *reinterpret_cast<const double2 *>(v + i);
+		ss += t.x * t.x;
+		ss += t.y * t.y;
+	}
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+	if (lane == 0) {
+		const double *x = Xq + (long)q * d;
+		const double *beta = betaQ;
+		const double *Q = betaQ + nreg;
+		double m = v[Np];
+		double reg = 0.0;
+		for (int a = 0; a < nreg; a++) m += hfun(a, x, d) * beta[a];
+		for (int a = 0; a < nreg; a++) {
+			const double qa = hfun(a, x, d) - v[Np + 1 + a];
+			double t = 0.0;
+			for (int b = 0; b < nreg; b++) t += Q[a * nreg + b] * (hfun(b, x, d) - v[Np + 1 + b]);
+			reg += qa * t;
+		}
+		mean[q] = m;
+		var[q] = kappa - ss + reg;
+	}
+}
+
+hipError_t launch_predict_finish(hipStream_t s, const double *V, long ldv, int M, int Np, int nreg, int order, int d,
+                                 const double *Xq, const double *betaQ, double kappa, double *mean, double *var)
+{
+	(void)order;
+	hipLaunchKernelGGL(predict_finish_kernel, dim3((M + 3) / 4), dim3(256), 0, s, V, ldv, M, Np, nreg, d, Xq, betaQ,
+	                   kappa, mean, var);
+	return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Gradient partial sums (getGradientCn, libEmu/maxmultimin.c:571-608, with the
+// dC/dtheta matrices of derivative_l_gauss, emulator.c:173-209, generated on
+// the fly instead of being stored and multiplied by an N^3 dgemm).
+// For each length direction k (pow-exp: ONE coordinate only, as the reference):
+//   dC_ab = exp(-0.5*e^{-2 t_k} D^2 - 2 t_k) * D^2,  D = x_ak - x_bk
+//   tr_k  = sum_ab A_ab dC_ab          (A = C^-1, symmetric)
+//   q_k   = sum_ab alpha_a alpha_b dC_ab   (alpha = A y)
+// plus tr_A = sum_a A_aa for the nugget direction.  A is read from the lower
+// triangle of the corner matrix S (rows/cols offset soff); off-diagonal
+// elements are counted twice.  One 64x64 tile per workgroup (lower tiles only);
+// part[tile][2*d+1].
+// gp[k] = t_k (length thetas, k < d).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grad_part_kernel(const double *S, long lds_, int soff, const double *X, int N,
+                                                        int d, const double *alpha, const double *gp, double *part)
+{
+	// lower-triangular tile index -> (tr, tc)
+	const int t = blockIdx.x;
+	int tr = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+	while ((long)(tr + 1) * (tr + 2) / 2 <= t) tr++;
+	while ((long)tr * (tr + 1) / 2 > t) tr--;
+	const int tc = t - tr * (tr + 1) / 2;
+
+	__shared__ double xr_s[64 * (GPEMU_MAX_PARAMS + 1)];
+	__shared__ double xc_s[64 * (GPEMU_MAX_PARAMS + 1)];
+	__shared__ double ar_s[64], ac_s[64];
+	__shared__ double red[256];
+	const int tid = threadIdx.x;
+	const int sd = d + 1;
+	for (int e = tid; e < 64 * d; e += 256) {
+		int r = e / d, k = e % d;
+		int gr = tr * 64 + r, gc = tc * 64 + r;
+		xr_s[r * sd + k] = (gr < N) ? X[(long)gr * d + k] : 0.0;
+		xc_s[r * sd + k] = (gc < N) ? X[(long)gc * d + k] : 0.0;
+	}
+	if (tid < 64) {
+		int gr = tr * 64 + tid, gc = tc * 64 + tid;
+		ar_s[tid] = (gr < N) ? alpha[gr] : 0.0;
+		ac_s[tid] = (gc < N) ? alpha[gc] : 0.0;
+	}
+	__syncthreads();
+
+	const int c = tid & 63, rsub = tid >> 6;
+	const int gc = tc * 64 + c;
+	double a_el[16], w_el[16];
+#pragma unroll
+	for (int u = 0; u < 16; u++) {
+		const int r = rsub + 4 * u;
+		const int gr = tr * 64 + r;
+		const bool valid = gr < N && gc < N && gc <= gr;
+		a_el[u] = valid ? S[(long)(soff + gr) * lds_ + soff + gc] : 0.0;
+		w_el[u] = valid ? ((gc == gr) ? 1.0 : 2.0) : 0.0;
+	}
+	// trace of A
+	{
+		double tsum = 0.0;
+#pragma unroll
+		for (int u = 0; u < 16; u++) {
+			const int gr = tr * 64 + rsub + 4 * u;
+			if (gr == gc && gr < N) tsum += a_el[u];
+		}
+		red[tid] = tsum;
+		__syncthreads();
+		for (int st = 128; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
+		if (tid == 0) part[(long)t * (2 * d + 1) + 2 * d] = red[0];
+		__syncthreads();
+	}
+	for (int k = 0; k < d; k++) {
+		const double th = gp[k];
+		const double e2 = exp(-2.0 * th);
+		double s_tr = 0.0, s_q = 0.0;
+#pragma unroll
+		for (int u = 0; u < 16; u++) {
+			const int r = rsub + 4 * u;
+			const double D = xr_s[r * sd + k] - xc_s[c * sd + k];
+			const double dc = exp(-0.5 * e2 * D * D - 2 * th) * D * D;   // emulator.c:203
+			s_tr += w_el[u] * a_el[u] * dc;
+			s_q += w_el[u] * ar_s[r] * ac_s[c] * dc;
+		}
+		red[tid] = s_tr;
+		__syncthreads();
+		for (int st = 128; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
+		if (tid == 0) part[(long)t * (2 * d + 1) + 2 * k] = red[0];
+		__syncthreads();
+		red[tid] = s_q;
+		__syncthreads();
+		for (int st = 128; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
+		if (tid == 0) part[(long)t * (2 * d + 1) + 2 * k + 1] = red[0];
+		__syncthreads();
+	}
+}
+
+hipError_t launch_grad_partials(hipStream_t s, const double *S, long lds_, int soff, const double *X, int N, int d,
+                                const double *alpha, int kind, const double *gp, double *part, int *nparts)
+{
+	(void)kind;
+	const int nt = (N + 63) / 64;
+	const int ntiles = nt * (nt + 1) / 2;
+	*nparts = ntiles;
+	hipLaunchKernelGGL(grad_part_kernel, dim3(ntiles), dim3(256), 0, s, S, lds_, soff, X, N, d, alpha, gp, part);
+	return hipGetLastError();
+}
+
+} // namespace gpemu
