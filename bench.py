@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric on MI355X: estimate_thetas likelihood-evals/sec (+ predictions/sec)
+at N=8192, d=8, fp64.
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank/GPU)
+
+A step = one evalFnMulti-equivalent likelihood evaluation (covariance fill + Cholesky + solves + logL, sigma^2,
+beta) at a FRESH theta (nothing cacheable), design resident in HBM.  After the K timed evaluation steps a second
+timed region pushes 1e6 query points (resident in HBM, K batches) through the posterior mean+variance sweep.
+Workload = BASELINE.json configs[2]: N=8192, d=8, Matern 5/2, regression order 1, 1e6 batched predictions.
+The evaluation is at given (supplied) thetas: the reference cannot train a Matern model.
+
+Multi-GPU: the evaluations / query blocks are independent units sharded one share per rank with no data-path
+collective; a single all-gather of the per-rank results ends each region ("weak" scaling: per-rank work fixed).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with "roofline" and "cpu_baseline" objects.
+"""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP64_MFMA_TFLOPS = 78.6     # MI355X dense fp64 matrix peak (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+
+WORKLOADS = {
+    # name: (kind, N, d, regression_order, n_queries)
+    "c3": (3, 8192, 8, 1, 1_000_000),   # BASELINE.json configs[2] -- the configuration the metric is quoted on
+    "c2": (1, 4096, 8, 0, 1_000_000),   # configs[1]
+    "c5": (1, 16384, 8, 0, 1_000_000),  # configs[4] (one rank's share)
+    "tiny": (3, 512, 8, 1, 8192),       # plumbing check
+}
+
+
+def _cpu_eval_worker(args):
+    """one oracle likelihood evaluation (reference operation sequence) -- cpu_baseline leg only"""
+    kind, order, N, d, seed, i = args
+    from oracle import oracle as O
+    from madaiemulator_amd import synth
+    X, y = synth.design(N, d, seed)
+    th = synth.perturbed_thetas(kind, d, seed, i)
+    t = time.perf_counter()
+    if kind == 1:
+        O.eval_fn_multi(kind, order, X, y, th[1:])
+    else:
+        e = O.Emulator(kind, order, X, y, th)       # fill + chol + explicit inverse + estimateBeta: same N^3 sequence
+        r = y - e.H @ e.beta
+        _ = r @ e.cinverse @ r
+    return time.perf_counter() - t
+
+
+def cpu_baseline(kind, order, N, d, seed):
+    """Reference-faithful CPU restatement (oracle/, kind "port") on the host cores: one independent evaluation
+    per core, the reference's own parallelisation (estimate_threaded.c:97,172).  Bounded sample at N_s < N,
+    extrapolated by (N/N_s)^3 (the path is N^3: unblocked Cholesky + explicit inverse)."""
+    from oracle import oracle as O
+    O.build()
+    cores = min(os.cpu_count() or 1, 16)
+    Ns = 1280
+    t0 = time.perf_counter()
+    with mp.get_context("spawn").Pool(cores) as pool:
+        times = pool.map(_cpu_eval_worker, [(kind, order, Ns, d, seed, i) for i in range(cores)])
+    wall = time.perf_counter() - t0
+    per_eval = float(np.mean(times))
+    scale = (N / Ns) ** 3
+    evals_per_s = cores / (per_eval * scale)
+    # predictions: emulate_point on the oracle at Ns, scaled by N^2 (three N^2 dgemv + N^2*nreg dgemm per query)
+    from madaiemulator_amd import synth
+    X, y = synth.design(Ns, d, seed)
+    e = O.Emulator(kind, order, X, y, synth.default_thetas(kind, d))
+    tq = time.perf_counter()
+    e.emulate(synth.queries(4, d, 3))
+    per_q = (time.perf_counter() - tq) / 4
+    preds_per_s = cores / (per_q * (N / Ns) ** 2)
+    return {
+        "value": evals_per_s, "unit": "likelihood-evals/s", "cores": cores, "kind": "port",
+        "sample": (f"{cores} concurrent oracle evaluations (one per core) at N={Ns}, d={d}: {per_eval:.2f} s each "
+                   f"({wall:.1f} s wall); extrapolated to N={N} by (N/{Ns})^3; predictions: 4 oracle emulate_point "
+                   f"calls at N={Ns} ({per_q*1e3:.1f} ms each) scaled by (N/{Ns})^2"),
+        "predictions_per_s": preds_per_s,
+        "seconds_per_eval_at_sample": per_eval,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--queries", type=int, default=None, help="total prediction points per rank (default 1e6)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-predict", action="store_true")
+    args = ap.parse_args()
+
+    import torch        # torch first: its bundled HIP runtime must be the one in the process (the reverse order
+    torch.cuda.is_available()   # leaves torch without a device); the device library binds to the same soname
+    from madaiemulator_amd import abi, shard, synth
+
+    rank, world_size, local_rank = shard.world()
+    distributed = world_size > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    ngpus = world_size
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    kind, N, d, order, nq = WORKLOADS[args.workload]
+    if args.queries:
+        nq = args.queries
+    seed = 20261003 + 2
+    K, W = args.steps, args.warmup
+
+    ctx = abi.Context(local_rank if distributed else 0)
+    X, y = synth.design(N, d, seed)
+    ctx.set_model(kind, order, X, y)
+    # independent evaluations: global eval index g -> rank g mod world (each rank draws its own fresh thetas)
+    def theta(i):
+        return synth.perturbed_thetas(kind, d, seed, rank + world_size * i)
+
+    # ---- correctness gate before timing (small N, same seeds): HIP vs oracle, 1e-8 relative
+    gate = None
+    if rank == 0:
+        from oracle import oracle as O
+        Xg, yg = synth.design(512, d, seed)
+        g = abi.Context(local_rank if distributed else 0)
+        g.set_model(kind, order, Xg, yg)
+        thg = synth.default_thetas(kind, d)
+        got = g.loglik(thg)
+        e = O.Emulator(kind, order, Xg, yg, thg)
+        r = yg - e.H @ e.beta
+        ref = -(-0.5 * e.logdet - 512 / 2.0 * 1.83788 - 0.5 * (r @ e.cinverse @ r))
+        g.predict_setup(thg)
+        qg = synth.queries(64, d, 5)
+        m, v = g.predict(qg)
+        mo, vo, _ = e.emulate(qg)
+        gate = {"loglik_rel": abs(got["value"] - ref) / abs(ref), "mean_abs": float(np.max(np.abs(m - mo))),
+                "var_abs": float(np.max(np.abs(v - vo)))}
+        assert gate["loglik_rel"] < 1e-8 and gate["mean_abs"] < 1e-8 and gate["var_abs"] < 1e-8, gate
+        g.close()
+
+    # ---- region A: likelihood evaluations
+    for i in range(W):
+        ctx.loglik_enqueue(theta(1000 + i))
+    last = ctx.loglik_collect()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(K):
+        ctx.loglik_enqueue(theta(i))
+    last = ctx.loglik_collect()
+    barrier()
+    tA = time.perf_counter() - t0
+    assert last["status"] == 0 and np.isfinite(last["value"]), last
+    if distributed:
+        tt = torch.tensor([tA], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        tA = float(tt.item())
+        # the single collective of the path: gather (value, thetas...) per rank, arg-max on every rank
+        rows = shard.all_gather_rows(np.concatenate([[last["value"]], theta(K - 1)])[None, :], 1 + len(theta(0)))
+        assert len(rows) == world_size
+    evals_per_s = ngpus * K / tA
+
+    # ---- region B: batched predictions, queries resident in HBM
+    pred = None
+    if not args.no_predict:
+        th0 = synth.default_thetas(kind, d)
+        ctx.predict_setup(th0)
+        nb = max(1, K)
+        per = -(-nq // nb)
+        Xq = synth.queries(per, d, seed + 11 + rank)
+        dq, dm, dv = ctx.dev_alloc(Xq.nbytes), ctx.dev_alloc(per * 8), ctx.dev_alloc(per * 8)
+        ctx.upload(dq, Xq)
+        for _ in range(min(W, 2)):
+            ctx.predict_dev(per, dq, dm, dv)
+        ctx.sync()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(nb):
+            ctx.predict_dev(per, dq, dm, dv)
+        ctx.sync()
+        barrier()
+        tB = time.perf_counter() - t0
+        if distributed:
+            tt = torch.tensor([tB], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tB = float(tt.item())
+        mean = ctx.download(dm, (per,))
+        assert np.all(np.isfinite(mean))
+        pred = {"value": ngpus * nb * per / tB, "unit": "predictions/s", "points_per_rank": nb * per,
+                "batches": nb, "ms_per_batch": tB / nb * 1e3}
+
+    # ---- roofline of the dominant kernel (fp64 MFMA GEMM of the Cholesky trailing updates), HIP events on the
+    #      ctx stream around every launch; rank 0 only
+    roof, roof_other = None, {}
+    if rank == 0:
+        ctx.prof_begin(abi.PROF_GEMM)
+        for i in range(3):
+            ctx.loglik_enqueue(theta(2000 + i))
+        p = ctx.prof_end()
+        ach = p["flops"] / (p["ms"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "gemm_nt_kernel (potrf trailing update, v_mfma_f64_16x16x4_f64)",
+                "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS,
+                "traffic": None, "launches": p["n"], "avg_launch_us": p["ms"] * 1e3 / max(p["n"], 1),
+                "flops_per_eval": p["flops"] / 3}
+        ctx.prof_begin(abi.PROF_POTRF)
+        for i in range(3):
+            ctx.loglik_enqueue(theta(3000 + i))
+        p = ctx.prof_end()
+        roof_other["potrf_whole"] = {"bound": "mfma", "achieved": (N ** 3 / 3.0) * p["n"] / (p["ms"] * 1e-3) / 1e12,
+                                     "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "ms": p["ms"] / max(p["n"], 1)}
+        roof_other["potrf_whole"]["frac"] = roof_other["potrf_whole"]["achieved"] / PEAK_FP64_MFMA_TFLOPS
+        ctx.prof_begin(abi.PROF_FILL)
+        for i in range(3):
+            ctx.loglik_enqueue(theta(4000 + i))
+        p = ctx.prof_end()
+        gbs = p["bytes"] / (p["ms"] * 1e-3) / 1e9
+        roof_other["cov_fill"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                  "frac": gbs / PEAK_HBM_GBS, "avg_launch_us": p["ms"] * 1e3 / max(p["n"], 1)}
+        if pred is not None:
+            ctx.predict_setup(synth.default_thetas(kind, d))
+            ctx.prof_begin(abi.PROF_GEMM)
+            ctx.predict_dev(per, dq, dm, dv)
+            p = ctx.prof_end()
+            ach = p["flops"] / (p["ms"] * 1e-3) / 1e12
+            roof_other["predict_gemm"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS,
+                                          "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS,
+                                          "flops_per_prediction": p["flops"] / per}
+
+    cpu = None
+    if rank == 0 and ngpus == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(kind, order, N, d, seed)
+
+    if rank == 0:
+        out = {
+            "metric": "estimate_thetas likelihood-evals/sec + predictions/sec at N=8192 d=8 fp64",
+            "value": evals_per_s, "unit": "likelihood-evals/s",
+            "n_gpus": ngpus, "steps": K, "warmup": W, "ms_per_step": tA / K * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: N={N}, d={d}, cov_fn={kind} "
+                                   f"({'pow-exp' if kind == 1 else 'Matern32' if kind == 2 else 'Matern52'}), "
+                                   f"regression_order={order}, {nq} prediction points per rank",
+                       "parallelism": f"independent evaluations / query blocks x{ngpus}, one all-gather"},
+            "predictions": pred,
+            "roofline": roof, "roofline_other": roof_other,
+            "cpu_baseline": cpu,
+            "speedup_vs_cpu_all_cores": (evals_per_s / cpu["value"]) if cpu else None,
+            "parity_gate": gate,
+        }
+        print(json.dumps(out))
+    ctx.close()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,78 @@
+"""Seeded synthetic designs for tests and bench.py.
+
+Self-contained splitmix64 generator (no libc rand, no numpy Generator state), so the
+same seed gives the same bytes everywhere.
+"""
+import numpy as np
+
+_MASK = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(seed, n):
+    """n uint64 values of the splitmix64 sequence started at `seed`."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(1, n + 1, dtype=np.uint64)
+        z = (np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)) & _MASK
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _MASK
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _MASK
+        return z ^ (z >> np.uint64(31))
+
+
+def uniform(seed, shape):
+    """iid U[0,1) doubles: top 53 bits of splitmix64."""
+    n = int(np.prod(shape))
+    u = (splitmix64(seed, n) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    return u.reshape(shape)
+
+
+def normal(seed, n):
+    """iid N(0,1) by Box-Muller on two uniform streams."""
+    u1 = uniform(seed, (n,))
+    u2 = uniform(seed ^ 0x5DEECE66D, (n,))
+    return np.sqrt(-2.0 * np.log(1.0 - u1)) * np.cos(2.0 * np.pi * u2)
+
+
+def design(N, d, seed):
+    """X: N x d iid U[0,1); y = sum_k sin(2 pi x_k (k+1)/d) + 0.01 N(0,1), standardised."""
+    X = uniform(seed, (N, d))
+    k = np.arange(1, d + 1, dtype=np.float64)
+    y = np.sin(2.0 * np.pi * X * k / d).sum(axis=1) + 0.01 * normal(seed + 7919, N)
+    y = (y - y.mean()) / y.std()
+    return X, y
+
+
+def multi_outputs(X, y, nt):
+    """t outputs y^(j) = y cos(j) + sin(j pi x_{j mod d}) (config 4: PCA keeps nt-1 components)."""
+    N, d = X.shape
+    Y = np.empty((N, nt))
+    for j in range(nt):
+        Y[:, j] = y * np.cos(j) + np.sin(j * np.pi * X[:, j % d])
+    return Y
+
+
+def queries(M, d, seed):
+    return uniform(seed, (M, d))
+
+
+def default_thetas(kind, d):
+    """supplied hyper-parameters of SURVEY 8(d): pow-exp [0,-4,log .6 x d]; Matern [1, .01, log .6]."""
+    if kind == 1:
+        return np.array([0.0, -4.0] + [np.log(0.6)] * d)
+    return np.array([1.0, 0.01, np.log(0.6)])
+
+
+def perturbed_thetas(kind, d, seed, i):
+    """a fresh theta per evaluation: length scales += 0.01 U(-1,1), so nothing can be cached."""
+    th = default_thetas(kind, d).copy()
+    u = uniform(seed + 104729 * (i + 1), (th.size - 2,))
+    th[2:] += 0.01 * (2.0 * u - 1.0)
+    return th
+
+
+def read_input_model_file(path):
+    """INPUT_MODEL_FILE (interactive_emulator.c:222-238): nt d N, N*d design values, N*nt outputs."""
+    vals = np.array(open(path).read().split(), dtype=np.float64)
+    nt, d, N = int(vals[0]), int(vals[1]), int(vals[2])
+    X = vals[3:3 + N * d].reshape(N, d)
+    Y = vals[3 + N * d:3 + N * d + N * nt].reshape(N, nt)
+    return X, Y

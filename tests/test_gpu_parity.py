@@ -1,0 +1,376 @@
+"""Parity of the HIP path (through the C-ABI, include/gpemu.h) against the CPU oracle, the committed golden
+vectors and size-independent properties.  Bar (BASELINE.json north_star): log-likelihood, sigma^2, beta and
+posterior mean within 1e-8 relative, posterior variance within 1e-8*kappa absolute; covariance elements are
+compared at 1e-13 relative (device exp/fma vs glibc differ in the last ulp)."""
+import numpy as np
+import pytest
+import scipy.linalg as sl
+
+from madaiemulator_amd import abi, synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-8          # the north_star parity bar
+ELEM_RTOL = 1e-13    # covariance elements
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def thetas_for(kind, d, golden=None):
+    return synth.default_thetas(kind, d)
+
+
+# ------------------------------------------------------------------ building blocks
+@pytest.mark.parametrize("m,n,k", [(16, 16, 16), (128, 128, 16), (200, 72, 64), (129, 257, 48), (384, 256, 256)])
+def test_gemm_nt_asymmetric(gpu_ctx, m, n, k):
+    rng = np.random.default_rng(m * 7 + n)
+    A, B, C0 = rng.standard_normal((m, k)), rng.standard_normal((n, k)), rng.standard_normal((m, n))
+    got = gpu_ctx.test_gemm_nt(A, B, C0, alpha=-1.0, beta=1)
+    assert relerr(got, C0 - A @ B.T) < 1e-13
+    got = gpu_ctx.test_gemm_nt(A, B, C0, alpha=1.0, beta=0)
+    assert relerr(got, A @ B.T) < 1e-13
+
+
+def test_gemm_identity_asymmetric_exact(gpu_ctx):
+    # A = I against an asymmetric integer B: any row/col or k-slot mix-up of the MFMA maps shows up exactly
+    n = 128
+    A = np.eye(n)
+    B = np.arange(n * n, dtype=np.float64).reshape(n, n)
+    got = gpu_ctx.test_gemm_nt(A, B, np.zeros((n, n)))
+    assert np.array_equal(got, B.T)
+
+
+@pytest.mark.parametrize("n", [1, 5, 64, 65, 100, 128, 200, 512, 1000])
+def test_potrf_matches_lapack(gpu_ctx, n):
+    rng = np.random.default_rng(n)
+    M = rng.standard_normal((n, n))
+    S = M @ M.T + n * np.eye(n)
+    L, info = gpu_ctx.test_potrf(S)
+    assert info == 0
+    assert relerr(L, np.linalg.cholesky(S)) < 1e-13
+    assert relerr(L @ L.T, S) < 1e-14
+
+
+def test_potrf_reports_first_bad_pivot(gpu_ctx):
+    S = np.eye(200)
+    S[57, 57] = -1.0
+    S[150, 150] = -2.0
+    _, info = gpu_ctx.test_potrf(S)
+    assert info == 58                       # 1-based index of the FIRST non-positive pivot
+
+
+# ------------------------------------------------------------------ a1-a4, a16: covariance fill
+@pytest.mark.parametrize("kind", [1, 2, 3])
+@pytest.mark.parametrize("N,d", [(1, 1), (34, 1), (63, 2), (64, 3), (65, 8), (200, 16), (130, 20)])
+def test_cov_matrix_vs_oracle(gpu_ctx, kind, N, d):
+    X, y = synth.design(N, d, 100 + N + d) if N > 1 else (np.array([[0.25] * d]), np.array([1.0]))
+    th = thetas_for(kind, d)
+    gpu_ctx.set_model(kind, 0, X, y)
+    got = gpu_ctx.cov_matrix(th)
+    ref = O.cov_matrix(kind, X, th)
+    assert got.shape == (N, N)
+    assert relerr(got, ref) < ELEM_RTOL
+    assert np.array_equal(got, got.T)
+
+
+def test_cov_golden_special_pairs(gpu_ctx, golden):
+    # identical points, |delta| = 5e-11 / 2e-10 (pow-exp nugget threshold), 5e-17 (Matern), far points
+    for x, y, kind, d, val, th in zip(golden["g1_x"], golden["g1_y"], golden["g1_kind"], golden["g1_d"],
+                                      golden["g1_val"], golden["g1_th"]):
+        kind, d = int(kind), int(d)
+        X = np.vstack([x[:d], y[:d]])
+        gpu_ctx.set_model(kind, 0, X, np.zeros(2))
+        got = gpu_ctx.cov_matrix(th[:O.nthetas_for(kind, d)])
+        assert got[0, 1] == pytest.approx(val, rel=ELEM_RTOL, abs=1e-300)
+        assert got[1, 0] == got[0, 1]
+
+
+def test_duplicate_design_points_get_offdiagonal_nugget(gpu_ctx):
+    # the nugget is added wherever two rows coincide, not only on i == j
+    X = np.array([[0.1, 0.2], [0.5, 0.5], [0.1, 0.2]])
+    th = np.array([0.0, -1.0, 0.0, 0.0])
+    gpu_ctx.set_model(1, 0, X, np.zeros(3))
+    got = gpu_ctx.cov_matrix(th)
+    assert relerr(got, O.cov_matrix(1, X, th)) < ELEM_RTOL
+    assert got[0, 2] == pytest.approx(1.0 + np.exp(-1.0), rel=1e-14)
+
+
+@pytest.mark.parametrize("kind", [1, 2, 3])
+def test_kvectors_with_clamp(gpu_ctx, kind):
+    X, y = synth.design(150, 3, 9)
+    th = thetas_for(kind, 3)
+    th = th.copy()
+    th[2:] = np.log(0.05)                   # short length scale: many covariances fall below 1e-10
+    Xq = np.vstack([synth.queries(70, 3, 5), X[:2]])
+    gpu_ctx.set_model(kind, 0, X, y)
+    got = gpu_ctx.kvectors(th, Xq)
+    ref = np.vstack([O.kvector(kind, X, q, th) for q in Xq])
+    assert (ref == 0.0).sum() > 100         # the clamp is exercised
+    assert np.array_equal(got == 0.0, ref == 0.0)
+    assert relerr(got, ref) < ELEM_RTOL
+
+
+# ------------------------------------------------------------------ a7-a11: likelihood
+def check_loglik(gpu_ctx, kind, order, X, y, th_full):
+    gpu_ctx.set_model(kind, order, X, y)
+    got = gpu_ctx.loglik(th_full)
+    if kind == 1 and th_full[0] == 0.0:
+        ref = O.eval_fn_multi(kind, order, X, y, th_full[1:])
+    else:
+        # likelihood at a given FULL theta (Matern: amp is not exponentiated): same pieces, stored thetas
+        e = O.Emulator(kind, order, X, y, th_full)
+        H = e.H
+        r = y - H @ e.beta
+        quad = r @ e.cinverse @ r
+        ref = dict(value=-(-0.5 * e.logdet - len(y) / 2.0 * 1.83788 - 0.5 * quad), sigma2=y @ e.cinverse @ r / len(y),
+                   beta=e.beta, logdet=e.logdet, quad=quad, info=0)
+    assert got["status"] == 0 and got["info"] == 0
+    assert got["value"] == pytest.approx(ref["value"], rel=RTOL)
+    assert got["sigma2"] == pytest.approx(ref["sigma2"], rel=RTOL)
+    assert got["logdet"] == pytest.approx(ref["logdet"], rel=RTOL)
+    assert got["quad"] == pytest.approx(ref["quad"], rel=RTOL)
+    assert relerr(got["beta"], ref["beta"]) < RTOL
+    return got, ref
+
+
+@pytest.mark.parametrize("order", [0, 1, 2, 3])
+def test_loglik_uni_simple(gpu_ctx, ref_inputs, golden, order):
+    X, y = ref_inputs["uni"]
+    th = np.concatenate([[0.0], golden["th_pe1"][1:]])
+    got, _ = check_loglik(gpu_ctx, 1, order, X, y, th)
+    row = golden["g3_uni"][order]
+    assert got["value"] == pytest.approx(row[0], rel=RTOL)
+    assert got["sigma2"] == pytest.approx(row[1], rel=RTOL)
+
+
+@pytest.mark.parametrize("order", [0, 1])
+def test_loglik_2d_param(gpu_ctx, ref_inputs, golden, order):
+    X, y = ref_inputs["twod"]
+    th = np.concatenate([[0.0], golden["th_pe2"][1:]])
+    got, _ = check_loglik(gpu_ctx, 1, order, X, y, th)
+    assert got["value"] == pytest.approx(golden["g3_2d"][order][0], rel=RTOL)
+
+
+@pytest.mark.parametrize("kind,N,d,order", [(1, 512, 8, 0), (1, 512, 8, 1), (1, 1024, 8, 1), (3, 512, 8, 1),
+                                            (2, 300, 4, 2), (1, 257, 16, 1)])
+def test_loglik_seeded_designs(gpu_ctx, kind, N, d, order):
+    X, y = synth.design(N, d, 20261003 + N)
+    check_loglik(gpu_ctx, kind, order, X, y, thetas_for(kind, d))
+
+
+def test_loglik_not_positive_definite_returns_nan(gpu_ctx, ref_inputs):
+    # the Matern "training" failure mode (SURVEY C2 / golden G8): amp = 0 -> C = theta_1 * I, theta_1 < 0
+    X, y = ref_inputs["uni"]
+    gpu_ctx.set_model(2, 0, X, y)
+    got = gpu_ctx.loglik(np.array([0.0, -3.0, 0.0]))
+    assert got["status"] == abi.ERR_NOT_PD and got["info"] == 1 and np.isnan(got["value"])
+    ref = O.eval_fn_multi(2, 0, X, y, np.array([-3.0, 0.0]))
+    assert np.isnan(ref["value"]) and ref["info"] == 1
+
+
+def test_loglik_is_deterministic_and_theta_sensitive(gpu_ctx):
+    X, y = synth.design(700, 8, 4)
+    gpu_ctx.set_model(1, 1, X, y)
+    a = gpu_ctx.loglik(synth.perturbed_thetas(1, 8, 1, 0))
+    b = gpu_ctx.loglik(synth.perturbed_thetas(1, 8, 1, 0))
+    c = gpu_ctx.loglik(synth.perturbed_thetas(1, 8, 1, 1))
+    assert a["value"] == b["value"] and np.array_equal(a["beta"], b["beta"])   # bit-identical re-run
+    assert a["value"] != c["value"]
+
+
+def test_loglik_enqueue_collect_pipeline(gpu_ctx):
+    X, y = synth.design(400, 8, 5)
+    gpu_ctx.set_model(1, 0, X, y)
+    ths = [synth.perturbed_thetas(1, 8, 2, i) for i in range(4)]
+    single = [gpu_ctx.loglik(t)["value"] for t in ths]
+    for t in ths:
+        gpu_ctx.loglik_enqueue(t)
+    last = gpu_ctx.loglik_collect()
+    assert last["value"] == single[-1]
+
+
+def test_set_training_swaps_outputs(gpu_ctx):
+    # multi_modelstruct: one design, nr training vectors
+    X, y = synth.design(300, 3, 6)
+    Y = synth.multi_outputs(X, y, 3)
+    th = thetas_for(1, 3)
+    gpu_ctx.set_model(1, 1, X, Y[:, 0])
+    for j in range(3):
+        gpu_ctx.set_training(Y[:, j])
+        got = gpu_ctx.loglik(th)
+        ref = O.eval_fn_multi(1, 1, X, Y[:, j], th[1:])
+        assert got["value"] == pytest.approx(ref["value"], rel=RTOL)
+
+
+# ------------------------------------------------------------------ a5, a12: gradient
+@pytest.mark.parametrize("N,d,order", [(34, 1, 1), (100, 3, 0), (300, 8, 1), (130, 2, 2)])
+def test_grad_vs_oracle(gpu_ctx, N, d, order):
+    X, y = synth.design(N, d, 77 + N)
+    th = thetas_for(1, d)
+    gpu_ctx.set_model(1, order, X, y)
+    g, rc = gpu_ctx.grad(th)
+    ref, st = O.grad_fn_multi(1, order, X, y, th[1:])
+    assert rc == 0 and st == 0
+    assert np.allclose(g, ref, rtol=1e-7, atol=1e-7 * np.abs(ref).max())
+
+
+def test_grad_golden(gpu_ctx, ref_inputs, golden):
+    X, y = ref_inputs["uni"]
+    gpu_ctx.set_model(1, 1, X, y)
+    g, _ = gpu_ctx.grad(np.concatenate([[0.0], golden["th_pe1"][1:]]))
+    assert np.allclose(g, golden["g4_uni"], rtol=1e-7, atol=1e-7 * np.abs(golden["g4_uni"]).max())
+    X3, _ = ref_inputs["multi"]
+    gpu_ctx.set_model(1, 0, X3, golden["g4_y3"])
+    g, _ = gpu_ctx.grad(np.concatenate([[0.0], golden["th_pe3"][1:]]))
+    assert np.allclose(g, golden["g4_multi"], rtol=1e-7, atol=1e-7 * np.abs(golden["g4_multi"]).max())
+
+
+def test_grad_matern_is_refused(gpu_ctx, ref_inputs):
+    X, y = ref_inputs["uni"]
+    gpu_ctx.set_model(3, 0, X, y)
+    with pytest.raises(abi.GpemuError) as e:
+        gpu_ctx.grad(np.array([1.0, 0.01, 0.0]))
+    assert e.value.code == abi.ERR_ARG
+
+
+# ------------------------------------------------------------------ a14-a19: prediction
+def check_predict(gpu_ctx, kind, order, X, y, th, Xq):
+    gpu_ctx.set_model(kind, order, X, y)
+    beta, rc = gpu_ctx.predict_setup(th)
+    assert rc == 0
+    e = O.Emulator(kind, order, X, y, th)
+    m, v = gpu_ctx.predict(Xq)
+    mo, vo, st = e.emulate(Xq)
+    assert st == 0
+    kappa = O.cov(kind, Xq[0], Xq[0], th)
+    assert relerr(beta, e.beta) < RTOL
+    assert np.max(np.abs(m - mo)) <= RTOL * max(1.0, np.max(np.abs(mo)))
+    assert np.max(np.abs(v - vo)) <= RTOL * kappa
+    return m, v, e
+
+
+@pytest.mark.parametrize("kind", [1, 2, 3])
+@pytest.mark.parametrize("order", [0, 1])
+def test_predict_golden_inputs(gpu_ctx, ref_inputs, golden, kind, order):
+    for tag, key, th in (("uni", "uni", golden["th_pe1"]), ("2d", "twod", golden["th_pe2"])):
+        X, y = ref_inputs[key]
+        thk = th if kind == 1 else golden["th_mat"]
+        Q = golden["g5_q_" + tag]
+        m, v, _ = check_predict(gpu_ctx, kind, order, X, y, thk, Q)
+        ref = golden[f"g5_{tag}_k{kind}_o{order}"]
+        kappa = O.cov(kind, Q[0], Q[0], thk)
+        assert np.max(np.abs(m - ref[0])) <= RTOL * max(1.0, np.max(np.abs(ref[0])))
+        assert np.max(np.abs(v - ref[1])) <= RTOL * kappa
+
+
+@pytest.mark.parametrize("kind,N,d,order,M", [(1, 512, 8, 1, 300), (3, 512, 8, 1, 300), (2, 200, 5, 3, 65),
+                                               (1, 100, 16, 0, 1), (3, 1000, 8, 1, 129)])
+def test_predict_seeded(gpu_ctx, kind, N, d, order, M):
+    X, y = synth.design(N, d, 31 + N)
+    Xq = np.vstack([synth.queries(M, d, 17), X[:1]])
+    check_predict(gpu_ctx, kind, order, X, y, thetas_for(kind, d), Xq)
+
+
+def test_predict_at_training_points_interpolates(gpu_ctx):
+    # k* at a training point carries the nugget -> C^-1 k* = e_i: mean = y_i, variance = 0
+    X, y = synth.design(2048, 8, 8)
+    th = thetas_for(3, 8)
+    gpu_ctx.set_model(3, 1, X, y)
+    gpu_ctx.predict_setup(th)
+    m, v = gpu_ctx.predict(X[:500])
+    assert np.max(np.abs(m - y[:500])) < 1e-8
+    assert np.max(np.abs(v)) < 1e-8 * (th[0] + th[1])
+
+
+def test_cinverse_matches_oracle_and_identity(gpu_ctx):
+    X, y = synth.design(300, 4, 12)
+    th = thetas_for(1, 4)
+    gpu_ctx.set_model(1, 1, X, y)
+    gpu_ctx.predict_setup(th)
+    Ai = gpu_ctx.cinverse()
+    e = O.Emulator(1, 1, X, y, th)
+    assert relerr(Ai, e.cinverse) < RTOL
+    assert np.array_equal(Ai, Ai.T)
+    assert relerr(Ai @ O.cov_matrix(1, X, th), np.eye(300)) < 1e-9
+
+
+def test_predict_batching_is_consistent(gpu_ctx):
+    # results do not depend on how the queries are split into calls
+    X, y = synth.design(640, 8, 13)
+    gpu_ctx.set_model(1, 1, X, y)
+    gpu_ctx.predict_setup(thetas_for(1, 8))
+    Xq = synth.queries(1000, 8, 3)
+    m_all, v_all = gpu_ctx.predict(Xq)
+    m_a, v_a = gpu_ctx.predict(Xq[:333])
+    m_b, v_b = gpu_ctx.predict(Xq[333:])
+    assert np.array_equal(m_all, np.concatenate([m_a, m_b])) and np.array_equal(v_all, np.concatenate([v_a, v_b]))
+
+
+# ------------------------------------------------------------------ BASELINE sizes: size-independent properties
+@pytest.mark.parametrize("kind,N", [(1, 4096), (3, 8192)])
+def test_full_size_properties(gpu_ctx, kind, N):
+    d, order = 8, (0 if kind == 1 else 1)
+    X, y = synth.design(N, d, 20261003 + kind)
+    th = thetas_for(kind, d)
+    gpu_ctx.set_model(kind, order, X, y)
+    a = gpu_ctx.loglik(th)
+    assert a["status"] == 0 and np.isfinite(a["value"])
+    # (1) independent LAPACK evaluation of the same theta (not the oracle: scipy on the host cores)
+    Cm = gpu_ctx.cov_matrix(th)
+    cf = sl.cho_factor(Cm, lower=True, overwrite_a=True, check_finite=False)
+    logdet = 2.0 * np.log(np.diag(cf[0])).sum()
+    H = O.hmatrix(order, X)
+    AyH = sl.cho_solve(cf, np.column_stack([y, H]), check_finite=False)
+    beta = np.linalg.solve(H.T @ AyH[:, 1:], H.T @ AyH[:, 0])
+    r = y - H @ beta
+    quad = r @ sl.cho_solve(cf, r, check_finite=False)
+    assert a["logdet"] == pytest.approx(logdet, rel=RTOL)
+    assert relerr(a["beta"], beta) < RTOL
+    assert a["quad"] == pytest.approx(quad, rel=RTOL)
+    assert a["value"] == pytest.approx(-(-0.5 * logdet - N / 2.0 * 1.83788 - 0.5 * quad), rel=RTOL)
+    del Cm, cf
+    # (2) scaling y by 2 scales sigma^2 and the quadratic form by 4, beta by 2, leaves log det alone
+    gpu_ctx.set_training(2.0 * y)
+    b = gpu_ctx.loglik(th)
+    assert b["sigma2"] == pytest.approx(4.0 * a["sigma2"], rel=1e-12)
+    assert b["quad"] == pytest.approx(4.0 * a["quad"], rel=1e-12)
+    assert relerr(b["beta"], 2.0 * a["beta"]) < 1e-10
+    assert b["logdet"] == a["logdet"]
+    gpu_ctx.set_training(y)
+    # (3) fit -> predict at the training points returns the training values with zero variance
+    gpu_ctx.predict_setup(th)
+    idx = np.arange(0, N, 7)
+    m, v = gpu_ctx.predict(X[idx])
+    kappa = O.cov(kind, X[0], X[0], th)
+    assert np.max(np.abs(m - y[idx])) < 1e-8 * max(1.0, np.abs(y).max())
+    assert np.max(np.abs(v)) < 1e-8 * kappa
+    # (4) away from the design the variance lies in (0, kappa + regression term] and the mean is finite
+    m, v = gpu_ctx.predict(synth.queries(4096, d, 99))
+    assert np.all(np.isfinite(m)) and np.all(v > 0) and np.all(v < 2.0 * kappa)
+
+
+# ------------------------------------------------------------------ error behaviour at the boundary
+def test_error_codes(gpu_ctx):
+    X, y = synth.design(50, 2, 1)
+    ctx = abi.Context(0)
+    with pytest.raises(abi.GpemuError) as e:
+        ctx.loglik(np.zeros(4))
+    assert e.value.code == abi.ERR_STATE                                   # model not set
+    ctx.set_model(1, 0, X, y)
+    with pytest.raises(abi.GpemuError) as e:
+        ctx.predict(X[:2])
+    assert e.value.code == abi.ERR_STATE                                   # predict before predict_setup
+    with pytest.raises(abi.GpemuError) as e:
+        ctx.loglik(np.zeros(2))
+    assert e.value.code == abi.ERR_ARG                                     # nthetas too small for d+2
+    with pytest.raises(abi.GpemuError) as e:
+        ctx.set_model(1, 0, np.zeros((4, 65)), np.zeros(4))
+    assert e.value.code == abi.ERR_ARG                                     # d > GPEMU_MAX_PARAMS
+    with pytest.raises(abi.GpemuError) as e:
+        ctx.set_model(1, 3, np.zeros((40, 30)), np.zeros(40))
+    assert e.value.code == abi.ERR_ARG                                     # 1 + nregression_fns > 64
+    ctx.close()

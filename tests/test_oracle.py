@@ -1,0 +1,150 @@
+"""CPU tests of the oracle (oracle/gp_oracle.c): against the committed golden vectors and against
+independent numpy/scipy re-derivations.  The oracle is test infrastructure ("parity unpinned", see its header)."""
+import numpy as np
+import pytest
+import scipy.linalg as sl
+
+from oracle import oracle as O
+from madaiemulator_amd import synth
+
+
+def test_kernel_values_golden(golden):
+    g = golden
+    for x, y, kind, d, val, th in zip(g["g1_x"], g["g1_y"], g["g1_kind"], g["g1_d"], g["g1_val"], g["g1_th"]):
+        nth = O.nthetas_for(int(kind), int(d))
+        v = O.cov(int(kind), x[:d], y[:d], th[:nth])
+        assert v == val
+
+
+def test_nugget_rule_and_clamp():
+    # emulator.c:136 per-coordinate 1e-10 threshold (pow-exp), :368/:462 1e-16 (Matern), :588 clamp
+    th = np.array([0.0, -2.0, 0.0])
+    x = np.array([0.3])
+    nug = np.exp(-2.0)
+    assert O.cov(1, x, x, th) == pytest.approx(1.0 + nug, rel=1e-15)
+    assert O.cov(1, x, x + 5e-11, th) == pytest.approx(1.0 + nug, rel=1e-12)      # still "the same point"
+    assert O.cov(1, x, x + 2e-10, th) == pytest.approx(1.0, rel=1e-12)            # not any more
+    tm = np.array([1.5, 0.25, 0.0])
+    assert O.cov(2, x, x, tm) == 1.75 and O.cov(3, x, x, tm) == 1.75              # amp + nugget, raw
+    assert O.cov(2, x, x + 1e-3, tm) < 1.5
+    k = O.kvector(1, np.array([[0.0], [50.0]]), np.array([0.0]), th)
+    assert k[1] == 0.0 and k[0] > 1.0                                             # far point clamped to exactly 0
+
+
+def test_cov_matrices_golden(golden, ref_inputs):
+    X1, _ = ref_inputs["uni"]
+    for name, kind, X, th in (("uni_pe", 1, X1, golden["th_pe1"]), ("uni_m32", 2, X1, golden["th_mat"]),
+                              ("uni_m52", 3, X1, golden["th_mat"]), ("r8_pe", 1, golden["g2_Xr"], golden["th_pe3"]),
+                              ("r8_m52", 3, golden["g2_Xr"], golden["th_mat"])):
+        Cm = O.cov_matrix(kind, X, th)
+        assert np.array_equal(Cm, golden["g2_" + name])
+        assert np.array_equal(Cm, Cm.T)
+
+
+def test_cholesky_against_lapack():
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 7, 64, 130):
+        M = rng.standard_normal((n, n))
+        S = M @ M.T + n * np.eye(n)
+        LLT, st = O.cholesky_decomp(S)
+        assert st == 0
+        L = np.tril(LLT)
+        assert np.allclose(L, np.linalg.cholesky(S), rtol=1e-12, atol=1e-12)
+        assert np.allclose(np.triu(LLT), L.T)                 # GSL mirrors L^T into the upper triangle
+        Ai = O.cholesky_invert(LLT)
+        assert np.allclose(Ai, np.linalg.inv(S), rtol=1e-10, atol=1e-12)
+        assert np.array_equal(Ai, Ai.T)
+    bad = np.eye(5)
+    bad[3, 3] = -1.0
+    _, st = O.cholesky_decomp(bad)
+    assert st == 1                                            # GSL_EDOM
+
+
+def test_eval_fn_multi_golden(golden, ref_inputs):
+    X1, y1 = ref_inputs["uni"]
+    X2, y2 = ref_inputs["twod"]
+    for order in range(4):
+        o = O.eval_fn_multi(1, order, X1, y1, golden["th_pe1"][1:])
+        row = golden["g3_uni"][order]
+        assert [o["value"], o["sigma2"], o["logdet"], o["quad"]] == row[:4].tolist()
+        assert np.array_equal(o["beta"], row[4:4 + o["beta"].size])
+    for order in range(2):
+        o = O.eval_fn_multi(1, order, X2, y2, golden["th_pe2"][1:])
+        row = golden["g3_2d"][order]
+        assert [o["value"], o["sigma2"], o["logdet"], o["quad"]] == row[:4].tolist()
+
+
+def test_eval_fn_multi_independent():
+    # Appendix A.2 re-derived with LAPACK on a seeded design
+    X, y = synth.design(150, 4, 20261003)
+    th = synth.default_thetas(1, 4)
+    o = O.eval_fn_multi(1, 1, X, y, th[1:])
+    D = ((X[:, None, :] - X[None, :, :]) ** 2 / np.exp(th[2:]) ** 2).sum(-1)
+    Cm = np.exp(-0.5 * D) + np.exp(th[1]) * np.eye(150)
+    cf = sl.cho_factor(Cm, lower=True)
+    A = sl.cho_solve(cf, np.eye(150))
+    H = np.hstack([np.ones((150, 1)), X])
+    beta = np.linalg.solve(H.T @ A @ H, H.T @ A @ y)
+    r = y - H @ beta
+    ll = -np.log(np.diag(cf[0])).sum() - 75 * 1.83788 - 0.5 * r @ A @ r
+    assert o["value"] == pytest.approx(-ll, rel=1e-11)
+    assert o["sigma2"] == pytest.approx(y @ A @ r / 150, rel=1e-9)
+    assert np.allclose(o["beta"], beta, rtol=1e-8)
+
+
+def test_determinant_product_underflows():
+    # the reference's det = (prod L_ii)^2 is 0 (logL = inf) at realistic sizes; 2*sum(log) is finite
+    X, y = synth.design(600, 8, 1)
+    th = synth.default_thetas(1, 8)
+    o0 = O.eval_fn_multi(1, 0, X, y, th[1:], det_mode=0)
+    o1 = O.eval_fn_multi(1, 0, X, y, th[1:], det_mode=1)
+    assert np.isinf(o0["value"]) or np.isinf(o0["logdet"])
+    assert np.isfinite(o1["value"])
+
+
+def test_grad_golden(golden, ref_inputs):
+    X1, y1 = ref_inputs["uni"]
+    X3, _ = ref_inputs["multi"]
+    g, st = O.grad_fn_multi(1, 1, X1, y1, golden["th_pe1"][1:])
+    assert st == 0 and np.array_equal(g, golden["g4_uni"])
+    g, st = O.grad_fn_multi(1, 0, X3, golden["g4_y3"], golden["th_pe3"][1:])
+    assert st == 0 and np.array_equal(g, golden["g4_multi"])
+
+
+def test_emulate_golden(golden, ref_inputs):
+    for kind in (1, 2, 3):
+        for order in (0, 1):
+            for tag, key, th in (("uni", "uni", golden["th_pe1"]), ("2d", "twod", golden["th_pe2"])):
+                X, y = ref_inputs[key]
+                thk = th if kind == 1 else golden["th_mat"]
+                e = O.Emulator(kind, order, X, y, thk)
+                m, v, st = e.emulate(golden["g5_q_" + tag])
+                ref = golden[f"g5_{tag}_k{kind}_o{order}"]
+                assert st == 0 and np.array_equal(m, ref[0]) and np.array_equal(v, ref[1])
+
+
+def test_matern_training_failure_mode(ref_inputs, golden):
+    # evalFnMulti zeroes theta_0; the Matern kernels read it raw -> C = theta_1 * I, theta_1 < 0 -> NaN
+    X1, y1 = ref_inputs["uni"]
+    o = O.eval_fn_multi(2, 0, X1, y1, np.array([-3.0, 0.0]))
+    assert np.isnan(o["value"]) and o["info"] == int(golden["g8_info"][0]) == 1
+
+
+def test_matern_derivative_carries_accumulator():
+    # rtemp is never reset (emulator.c:410-425), so element (0,1) depends on element (0,0)
+    X = np.array([[0.0], [1.0], [3.0]])
+    dC = O.derivative_l(2, X, 0.7, 2)
+    r01 = np.sqrt(0.0 + 1.0)                   # carried 0 from (0,0), plus 1
+    r02 = np.sqrt(r01 + 9.0)                   # carries sqrt'ed value forward
+    assert dC[0, 1] == pytest.approx(3.0 * np.exp(-1.732050808 * r01 / 0.7) * r01 ** 2 / 0.7 ** 3, rel=1e-14)
+    assert dC[0, 2] == pytest.approx(3.0 * np.exp(-1.732050808 * r02 / 0.7) * r02 ** 2 / 0.7 ** 3, rel=1e-14)
+
+
+def test_pca_backprojection():
+    ybar = np.array([1.0, -2.0, 0.5])
+    evals = np.array([4.0, 0.25])
+    evecs = np.array([[0.6, 0.8], [0.8, -0.6], [0.0, 1.0]])
+    m, v = np.array([0.3, -1.2]), np.array([0.5, 2.0])
+    mo, vo = O.pca_backproject(ybar, evals, evecs, m, v)
+    assert np.allclose(mo, ybar + evecs @ (np.sqrt(evals) * m))
+    assert np.allclose(vo, (evecs ** 2) @ (evals * v))

@@ -1,0 +1,96 @@
+"""World-size-2 gloo tests of the multi-GPU sharding logic (madaiemulator_amd/shard.py).  The per-unit work is a
+tiny oracle evaluation standing in for the device call -- what is tested is partition + the single all-gather."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+from madaiemulator_amd import shard
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ["REPO_ROOT"])
+import torch.distributed as dist
+from madaiemulator_amd import shard, synth
+from oracle import oracle as O
+dist.init_process_group("gloo")
+rank, ws, _ = shard.world()
+X, y = synth.design(40, 2, 5)
+thetas = np.array([synth.perturbed_thetas(1, 2, 9, i) for i in range(7)])
+calls = []
+def ev(th):
+    calls.append(1)
+    return O.eval_fn_multi(1, 0, X, y, th[1:])["value"]
+vals = shard.farm_evaluations(ev, thetas)
+Y = synth.multi_outputs(X, y, 5)
+comp = shard.farm_components(lambda c: [O.eval_fn_multi(1, 0, X, Y[:, c], thetas[0][1:])["value"], float(c)], 5, 2)
+e = O.Emulator(1, 0, X, y, thetas[0])
+Xq = synth.queries(11, 2, 3)
+m, v = shard.farm_queries(lambda q: e.emulate(q)[:2], Xq)
+dist.barrier()
+if rank == 0:
+    print("RESULT " + json.dumps(dict(vals=vals.tolist(), comp=comp.tolist(), m=m.tolist(), v=v.tolist(), ncalls=len(calls))))
+else:
+    print("NCALLS %d" % len(calls))
+dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_partitions():
+    assert shard.cyclic_share(10, 1, 4) == [1, 5, 9]
+    assert sorted(sum((shard.cyclic_share(13, r, 8) for r in range(8)), [])) == list(range(13))
+    spans = [shard.block_share(11, r, 4) for r in range(4)]
+    assert spans[0][0] == 0 and spans[-1][1] == 11 and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert shard.block_share(2, 3, 4) == (2, 2)                      # more ranks than units: empty share
+    i, th = shard.best_of([np.nan, 3.0, -1.0, np.inf], np.arange(8).reshape(4, 2))
+    assert i == 2 and th.tolist() == [4, 5]
+    assert shard.best_of([np.nan], [[0]]) == (None, None)
+
+
+def test_single_process_paths_match_direct_evaluation():
+    from oracle import oracle as O
+    from madaiemulator_amd import synth
+    X, y = synth.design(30, 2, 5)
+    thetas = np.array([synth.perturbed_thetas(1, 2, 9, i) for i in range(3)])
+    vals = shard.farm_evaluations(lambda th: O.eval_fn_multi(1, 0, X, y, th[1:])["value"], thetas, 0, 1)
+    assert vals.tolist() == [O.eval_fn_multi(1, 0, X, y, th[1:])["value"] for th in thetas]
+
+
+def test_world_size_2_gloo(tmp_path):
+    import json
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, REPO_ROOT=ROOT, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")][0]
+    res = json.loads(line[len("RESULT "):])
+    other = int([l for l in out.stdout.splitlines() if l.startswith("NCALLS ")][0].split()[1])
+    # 7 evaluations split 4 + 3, nothing evaluated twice
+    assert res["ncalls"] == 4 and other == 3
+    from oracle import oracle as O
+    from madaiemulator_amd import synth
+    X, y = synth.design(40, 2, 5)
+    thetas = np.array([synth.perturbed_thetas(1, 2, 9, i) for i in range(7)])
+    assert res["vals"] == [O.eval_fn_multi(1, 0, X, y, th[1:])["value"] for th in thetas]
+    Y = synth.multi_outputs(X, y, 5)
+    for c in range(5):
+        assert res["comp"][c] == [O.eval_fn_multi(1, 0, X, Y[:, c], thetas[0][1:])["value"], float(c)]
+    e = O.Emulator(1, 0, X, y, thetas[0])
+    m, v, _ = e.emulate(synth.queries(11, 2, 3))
+    assert res["m"] == m.tolist() and res["v"] == v.tolist()
