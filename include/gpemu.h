@@ -132,6 +132,10 @@ int gpemu_prof_end(gpemu_ctx *ctx, int *nlaunches, double *total_ms, double *flo
 /* C[m*n] = beta*C + alpha * A[m*K] * B[n*K]^T, host row-major buffers */
 int gpemu_test_gemm_nt(gpemu_ctx *ctx, int m, int n, int k, double alpha, int beta,
                        const double *a, const double *b, double *c);
+/* micro-benchmark of one GEMM shape on device-resident random operands: cfg -1 = heuristic, 0 = 128x128,
+ * 1 = 128x64, 2 = 64x64 tiles; tri = lower-trapezoid update as in the factorisation; HIP-event timed. */
+int gpemu_test_gemm_bench(gpemu_ctx *ctx, int m, int n, int k, int ld, int cfg, int tri, int beta, int reps,
+                          double *ms_avg, double *flops);
 /* in-place lower Cholesky of a host n*n matrix (both triangles read as lower);
  * returns L in the lower triangle, zeros above. */
 int gpemu_test_potrf(gpemu_ctx *ctx, int n, double *a, int *info);

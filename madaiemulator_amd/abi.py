@@ -46,6 +46,8 @@ SYMBOLS = {
     "gpemu_prof_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "gpemu_prof_end": (C.c_int, [C.c_void_p, _ip, _dp, _dp, _dp]),
     "gpemu_test_gemm_nt": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, _dp, _dp, _dp]),
+    "gpemu_test_gemm_bench": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, _dp, _dp]),
     "gpemu_test_potrf": (C.c_int, [C.c_void_p, C.c_int, _dp, _ip]),
 }
 
@@ -239,6 +241,11 @@ class Context:
         n = B.shape[0]
         self._chk(self.L.gpemu_test_gemm_nt(self.h, m, n, k, alpha, beta, _p(A), _p(B), _p(Cm)))
         return Cm
+
+    def gemm_bench(self, m, n, k, ld=0, cfg=-1, tri=0, beta=1, reps=5):
+        ms, fl = C.c_double(0), C.c_double(0)
+        self._chk(self.L.gpemu_test_gemm_bench(self.h, m, n, k, ld, cfg, tri, beta, reps, C.byref(ms), C.byref(fl)))
+        return ms.value, fl.value
 
     def test_potrf(self, A):
         A = _a(A).copy()

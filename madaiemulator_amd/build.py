@@ -47,7 +47,7 @@ def build_hip(force=False, verbose=False):
     for s in srcs:
         o = os.path.join(LIBDIR, os.path.basename(s) + ".o")
         if force or _newer(o, [s] + deps[len(srcs):]):
-            cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", HIP_SRC,
+            cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value", "-I", INCLUDE, "-I", HIP_SRC,
                    "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))

@@ -24,6 +24,7 @@ using namespace gpemu;
 		}                                                                                       \
 	} while (0)
 
+static int g_nb_top = 512;              // width of the right-looking outer panels (env GPEMU_NB_TOP)
 constexpr int INFO_NONE = 0x7f7f7f7f;   // "no failed pivot": what hipMemsetAsync(.., 0x7f, ..) leaves in *info
 
 static int fail(gpemu_ctx *ctx, int code, const char *msg)
@@ -60,23 +61,31 @@ struct ProfScope {
 	~ProfScope() { if (on) prof_mark(ctx); }
 };
 
+// algorithmic flops of one GEMM call: 2 * (k-range) summed over the output elements the call owns
+// (lower trapezoid for tri; rows of an upper-triangular A start at k = row - kstart_off; rows of a
+// lower-triangular B end at k = col - kend_off)
+static double gemm_flops(const GemmArgs &a)
+{
+	double fl = 0.0;
+	if (a.kend_mode) {
+		for (int j = 0; j < a.n; j++) {
+			int ke = std::min(a.k1, j + 1 - a.kend_off);
+			if (ke > a.k0) fl += 2.0 * a.m * (double)(ke - a.k0);
+		}
+		return fl;
+	}
+	for (int i = 0; i < a.m; i++) {
+		const int ncols = a.tri ? std::max(0, std::min(a.n, i + a.diag_off + 1)) : a.n;
+		int kb = a.k0;
+		if (a.kstart_mode) kb = std::max(kb, i - a.kstart_off);
+		if (a.k1 > kb) fl += 2.0 * ncols * (double)(a.k1 - kb);
+	}
+	return fl;
+}
+
 static hipError_t gemm(gpemu_ctx *ctx, const GemmArgs &a)
 {
-	// executed flops: 2*m*n*k over the tiles/k-range actually visited
-	double fl = 0.0;
-	if (prof_on(ctx, GPEMU_PROF_GEMM)) {
-		const int tm_n = (a.m + GEMM_BM - 1) / GEMM_BM, tn_n = (a.n + GEMM_BN - 1) / GEMM_BN;
-		for (int tm = 0; tm < tm_n; tm++)
-			for (int tn = 0; tn < tn_n; tn++) {
-				if (a.tri && tn * GEMM_BN > tm * GEMM_BM + GEMM_BM - 1 + a.diag_off) continue;
-				int kb = a.k0, ke = a.k1;
-				if (a.kstart_mode) { int ks = (tm * GEMM_BM - a.kstart_off) & ~(GEMM_BK - 1); if (ks > kb) kb = ks; }
-				if (a.kend_mode) { int kx = (tn * GEMM_BN + GEMM_BN - a.kend_off + GEMM_BK - 1) & ~(GEMM_BK - 1); if (kx < ke) ke = kx; }
-				if (ke <= kb) continue;
-				const int mm = std::min(GEMM_BM, a.m - tm * GEMM_BM), nn = std::min(GEMM_BN, a.n - tn * GEMM_BN);
-				fl += 2.0 * mm * nn * (double)(ke - kb);
-			}
-	}
+	const double fl = prof_on(ctx, GPEMU_PROF_GEMM) ? gemm_flops(a) : 0.0;
 	ProfScope ps(ctx, GPEMU_PROF_GEMM, fl, 0.0);
 	return launch_gemm(ctx->stream, a);
 }
@@ -114,6 +123,8 @@ extern "C" int gpemu_ctx_create(gpemu_ctx **out, int device)
 	}
 	const char *ng = getenv("GPEMU_NO_GRAPH");
 	if (ng && ng[0] == '1') ctx->use_graph = false;
+	const char *nbt = getenv("GPEMU_NB_TOP");
+	if (nbt && atoi(nbt) >= LEAF) g_nb_top = (atoi(nbt) / LEAF) * LEAF;
 	*out = ctx;
 	return GPEMU_OK;
 }
@@ -274,6 +285,27 @@ static int make_cov_params(gpemu_ctx *ctx, const double *thetas, int nthetas, Co
 //   T rows [Np+Rp,Np+Rp+Np)  : identity -> U = L^-T (only with inv)
 // potrf_rec(c0,n) factors the column panel [c0,c0+n) for every row below it.
 // ---------------------------------------------------------------------------
+static hipError_t trailing_update(gpemu_ctx *ctx, int c0, int k, int ncols, int inv)
+{
+	// C[rows >= c0+k, cols c0+k .. c0+k+ncols) -= P P^T with P = the factored panel columns [c0, c0+k)
+	const long ld = ctx->Np;
+	const int r0 = c0 + k;
+	const int row_end = ctx->Np + ctx->Rp + (inv ? r0 : 0);   // identity rows < r0 have fill-in in the panel
+	GemmArgs g;
+	memset(&g, 0, sizeof g);
+	g.C = ctx->dT + (long)r0 * ld + r0;
+	g.A = ctx->dT + (long)r0 * ld + c0;
+	g.B = g.A;
+	g.ldc = g.lda = g.ldb = ld;
+	g.m = row_end - r0;
+	g.n = ncols;
+	g.k0 = 0; g.k1 = k;
+	g.alpha = -1.0; g.beta = 1;
+	g.tri = 1; g.diag_off = 0;
+	return gemm(ctx, g);
+}
+
+
 static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv)
 {
 	const long ld = ctx->Np;
@@ -283,25 +315,28 @@ static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv)
 		ProfScope ps(ctx, GPEMU_PROF_LEAF, 0.0, 0.0);
 		return launch_leaf(ctx->stream, ctx->dT, ld, c0, row_end - (c0 + LEAF), ctx->dInfo);
 	}
+	if (n > g_nb_top) {
+		// right-looking over panels of g_nb_top columns: the trailing update touches the whole remaining
+		// matrix (thousands of tiles, K = panel width), which fills the chip far better than the few huge-K
+		// tiles a pure recursion would produce at the top levels
+		for (int c = c0; c < c0 + n; c += g_nb_top) {
+			const int nb = std::min(g_nb_top, c0 + n - c);
+			hipError_t e = potrf_rec(ctx, c, nb, inv);
+			if (e != hipSuccess) return e;
+			const int rest = c0 + n - (c + nb);
+			if (rest > 0) {
+				e = trailing_update(ctx, c, nb, rest, inv);
+				if (e != hipSuccess) return e;
+			}
+		}
+		return hipSuccess;
+	}
 	const int n1 = ((n / LEAF + 1) / 2) * LEAF;
 	hipError_t e = potrf_rec(ctx, c0, n1, inv);
 	if (e != hipSuccess) return e;
-	GemmArgs g;
-	memset(&g, 0, sizeof g);
-	const int r0 = c0 + n1;
-	const int row_end = base_end + (inv ? c0 + n1 : 0);
-	g.C = ctx->dT + (long)r0 * ld + r0;
-	g.A = ctx->dT + (long)r0 * ld + c0;
-	g.B = g.A;
-	g.ldc = g.lda = g.ldb = ld;
-	g.m = row_end - r0;
-	g.n = n - n1;
-	g.k0 = 0; g.k1 = n1;
-	g.alpha = -1.0; g.beta = 1;
-	g.tri = 1; g.diag_off = 0;
-	e = gemm(ctx, g);
+	e = trailing_update(ctx, c0, n1, n - n1, inv);
 	if (e != hipSuccess) return e;
-	return potrf_rec(ctx, r0, n - n1, inv);
+	return potrf_rec(ctx, c0 + n1, n - n1, inv);
 }
 
 static int run_potrf(gpemu_ctx *ctx, int inv)
@@ -851,6 +886,46 @@ extern "C" int gpemu_test_gemm_nt(gpemu_ctx *ctx, int m, int n, int k, double al
 	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 	HIPCHK(ctx, hipMemcpy(c, dc, (size_t)m * n * 8, hipMemcpyDeviceToHost));
 	hipFree(da); hipFree(db); hipFree(dc);
+	return GPEMU_OK;
+}
+
+namespace gpemu { extern int g_gemm_force_cfg; hipError_t launch_fill_random(hipStream_t s, double *p, size_t n, unsigned seed); }
+
+// times `reps` launches of one GEMM shape with HIP events on the ctx stream (device-resident random operands)
+extern "C" int gpemu_test_gemm_bench(gpemu_ctx *ctx, int m, int n, int k, int ld_in, int cfg, int tri, int beta,
+                                     int reps, double *ms_avg, double *flops)
+{
+	if (!ctx || m < 1 || n < 1 || k < 16 || (k % GEMM_BK) != 0 || reps < 1) return GPEMU_ERR_ARG;
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	const long ld = std::max(std::max(k, n), ld_in);
+	double *da = nullptr, *dc = nullptr;
+	const size_t rows = (size_t)std::max(m, n);
+	HIPCHK(ctx, hipMalloc(&da, rows * ld * 8));
+	HIPCHK(ctx, hipMalloc(&dc, (size_t)m * ld * 8));
+	HIPCHK(ctx, launch_fill_random(ctx->stream, da, rows * ld, 1u));
+	HIPCHK(ctx, launch_fill_random(ctx->stream, dc, (size_t)m * ld, 2u));
+	GemmArgs g;
+	memset(&g, 0, sizeof g);
+	g.C = dc; g.A = da; g.B = da; g.ldc = ld; g.lda = ld; g.ldb = ld; g.m = m; g.n = n; g.k0 = 0; g.k1 = k;
+	g.alpha = -1.0; g.beta = beta; g.tri = tri;
+	const int saved = g_gemm_force_cfg;
+	g_gemm_force_cfg = cfg;
+	hipEvent_t e0, e1;
+	hipEventCreate(&e0); hipEventCreate(&e1);
+	hipError_t e = launch_gemm(ctx->stream, g);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	hipEventRecord(e0, ctx->stream);
+	for (int r = 0; r < reps && e == hipSuccess; r++) e = launch_gemm(ctx->stream, g);
+	hipEventRecord(e1, ctx->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	g_gemm_force_cfg = saved;
+	float ms = 0.f;
+	hipEventElapsedTime(&ms, e0, e1);
+	hipEventDestroy(e0); hipEventDestroy(e1);
+	hipFree(da); hipFree(dc);
+	HIPCHK(ctx, e);
+	if (ms_avg) *ms_avg = ms / reps;
+	if (flops) *flops = gemm_flops(g);
 	return GPEMU_OK;
 }
 

@@ -104,6 +104,26 @@ hipError_t launch_cov_fill(hipStream_t s, double *out, long ld, const double *Xr
 	return hipGetLastError();
 }
 
+// pseudo-random fill in [-1,1) for the GEMM micro-benchmark (operands must not be zeros: DVFS, rule 25)
+__global__ void fill_random_kernel(double *p, size_t n, unsigned seed)
+{
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (; i < n; i += stride) {
+		unsigned long long z = (i + 1) * 0x9E3779B97F4A7C15ull + seed * 0xBF58476D1CE4E5B9ull;
+		z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+		z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+		z ^= z >> 31;
+		p[i] = (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+	}
+}
+
+hipError_t launch_fill_random(hipStream_t s, double *p, size_t n, unsigned seed)
+{
+	hipLaunchKernelGGL(fill_random_kernel, dim3(4096), dim3(256), 0, s, p, n, seed);
+	return hipGetLastError();
+}
+
 // regression basis h(x) (libEmu/regression.c:9-67): h = [1, x, x^2, x^3] per coordinate
 __device__ __forceinline__ double hfun(int a, const double *x, int d)
 {

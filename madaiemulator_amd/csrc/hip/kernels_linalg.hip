@@ -19,28 +19,40 @@ constexpr int LDS_S = GEMM_BK + 2;   // row stride (doubles): conflict-free ds_r
 // ---------------------------------------------------------------------------
 // GEMM  C[m x n] = beta*C + alpha * A[m x K] * B[n x K]^T   (row-major, k contiguous in A and B)
 //
-// 256 threads = 4 waves as 2x2; each wave owns a 64x64 sub-tile = 4x4 MFMA
-// 16x16 tiles (128 accumulator VGPRs).  MFMA f64 16x16x4 operand maps
-// (cdna_hip_programming.md section 3): A lane l -> A[row l&15][k l>>4],
-// B lane l -> B[k l>>4][col l&15], D reg r -> D[row (l>>4)+4r][col l&15].
+// 256 threads = 4 waves as 2x2; each wave owns a (BM/2)x(BN/2) sub-tile of
+// 16x16 MFMA tiles.  MFMA f64 16x16x4 operand maps (cdna_hip_programming.md
+// section 3): A lane l -> A[row l&15][k l>>4], B lane l -> B[k l>>4][col l&15],
+// D reg r -> D[row (l>>4)+4r][col l&15].
+// Three tile shapes (128x128, 128x64, 64x64): the fp64 MFMA rate per CU is low
+// (one 16x16x4 per 64 cycles per SIMD), so short or narrow updates need many
+// small tiles to cover 256 CUs while the big trailing updates want 128x128
+// for L2 traffic; launch_gemm picks per call.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g)
+template <int BM, int BN, int MINW>
+__global__ __launch_bounds__(256, MINW) void gemm_nt_kernel(GemmArgs g)
 {
-	__shared__ double As[2][GEMM_BM * LDS_S];
-	__shared__ double Bs[2][GEMM_BN * LDS_S];
+	constexpr int WM = BM / 2, WN = BN / 2;
+	constexpr int TM = WM / 16, TN = WN / 16;
+	constexpr int AIT = BM * 8 / 256, BIT = BN * 8 / 256;
+	__shared__ double As[2][BM * LDS_S];
+	__shared__ double Bs[2][BN * LDS_S];
 
-	const int tiles_m = (g.m + GEMM_BM - 1) / GEMM_BM;
+	const int tiles_m = (g.m + BM - 1) / BM;
+	const int tiles_n = (g.n + BN - 1) / BN;
+	// natural order: consecutive blocks (which the dispatcher deals round-robin over the 8 XCDs) walk down a
+	// tile column, so one XCD keeps re-using 1/8 of the A panels and every B panel; measured equal to grouped /
+	// XCD-chunked orders at these sizes (the operands sit in the 256 MB Infinity Cache).
 	const int tm = blockIdx.x % tiles_m;
 	const int tn = blockIdx.x / tiles_m;
-	if (g.tri && tn * GEMM_BN > tm * GEMM_BM + GEMM_BM - 1 + g.diag_off) return;
+	if (g.tri && tn * BN > tm * BM + BM - 1 + g.diag_off) return;
 
 	int kb = g.k0, ke = g.k1;
 	if (g.kstart_mode) {
-		int ks = (tm * GEMM_BM - g.kstart_off) & ~(GEMM_BK - 1);
+		int ks = (tm * BM - g.kstart_off) & ~(GEMM_BK - 1);
 		if (ks > kb) kb = ks;
 	}
 	if (g.kend_mode) {
-		int kx = (tn * GEMM_BN + GEMM_BN - g.kend_off + GEMM_BK - 1) & ~(GEMM_BK - 1);
+		int kx = (tn * BN + BN - g.kend_off + GEMM_BK - 1) & ~(GEMM_BK - 1);
 		if (kx < ke) ke = kx;
 	}
 
@@ -49,42 +61,46 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g)
 	const int wave = tid >> 6;
 	const int wm = wave >> 1, wn = wave & 1;
 
-	// staging map: 4 x (row, 16-byte segment) per operand per thread
-	const double *ag[4];
-	const double *bg[4];
-	int lofs[4];
+	// staging map: (row, 16-byte segment) pairs per operand per thread
+	const double *ag[AIT];
+	const double *bg[BIT];
+	int lofs_a[AIT], lofs_b[BIT];
 #pragma unroll
-	for (int it = 0; it < 4; it++) {
+	for (int it = 0; it < AIT; it++) {
 		int idx = tid + 256 * it;
 		int row = idx >> 3, seg = idx & 7;
-		int ar = tm * GEMM_BM + row; if (ar > g.m - 1) ar = g.m - 1;
-		int br = tn * GEMM_BN + row; if (br > g.n - 1) br = g.n - 1;
+		int ar = tm * BM + row; if (ar > g.m - 1) ar = g.m - 1;
 		ag[it] = g.A + (long)ar * g.lda + 2 * seg;
+		lofs_a[it] = row * LDS_S + 2 * seg;
+	}
+#pragma unroll
+	for (int it = 0; it < BIT; it++) {
+		int idx = tid + 256 * it;
+		int row = idx >> 3, seg = idx & 7;
+		int br = tn * BN + row; if (br > g.n - 1) br = g.n - 1;
 		bg[it] = g.B + (long)br * g.ldb + 2 * seg;
-		lofs[it] = row * LDS_S + 2 * seg;
+		lofs_b[it] = row * LDS_S + 2 * seg;
 	}
 
-	d4_t acc[4][4];
+	d4_t acc[TM][TN];
 #pragma unroll
-	for (int i = 0; i < 4; i++)
+	for (int i = 0; i < TM; i++)
 #pragma unroll
-		for (int j = 0; j < 4; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+		for (int j = 0; j < TN; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
 
-	const int a_base = (wm * 64 + (lane & 15)) * LDS_S + (lane >> 4);
-	const int b_base = (wn * 64 + (lane & 15)) * LDS_S + (lane >> 4);
+	const int a_base = (wm * WM + (lane & 15)) * LDS_S + (lane >> 4);
+	const int b_base = (wn * WN + (lane & 15)) * LDS_S + (lane >> 4);
 
 	if (kb < ke) {
-		d2_t ra[4], rb[4];
+		d2_t ra[AIT], rb[BIT];
 #pragma unroll
-		for (int it = 0; it < 4; it++) {
-			ra[it] = *reinterpret_cast<const d2_t *>(ag[it] + kb);
-			rb[it] = *reinterpret_cast<const d2_t *>(bg[it] + kb);
-		}
+		for (int it = 0; it < AIT; it++) ra[it] = *reinterpret_cast<const d2_t *>(ag[it] + kb);
 #pragma unroll
-		for (int it = 0; it < 4; it++) {
-			*reinterpret_cast<d2_t *>(&As[0][lofs[it]]) = ra[it];
-			*reinterpret_cast<d2_t *>(&Bs[0][lofs[it]]) = rb[it];
-		}
+		for (int it = 0; it < BIT; it++) rb[it] = *reinterpret_cast<const d2_t *>(bg[it] + kb);
+#pragma unroll
+		for (int it = 0; it < AIT; it++) *reinterpret_cast<d2_t *>(&As[0][lofs_a[it]]) = ra[it];
+#pragma unroll
+		for (int it = 0; it < BIT; it++) *reinterpret_cast<d2_t *>(&Bs[0][lofs_b[it]]) = rb[it];
 		__syncthreads();
 
 		int cur = 0;
@@ -92,32 +108,30 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g)
 			const bool more = (k + GEMM_BK) < ke;
 			if (more) {
 #pragma unroll
-				for (int it = 0; it < 4; it++) {
-					ra[it] = *reinterpret_cast<const d2_t *>(ag[it] + k + GEMM_BK);
-					rb[it] = *reinterpret_cast<const d2_t *>(bg[it] + k + GEMM_BK);
-				}
+				for (int it = 0; it < AIT; it++) ra[it] = *reinterpret_cast<const d2_t *>(ag[it] + k + GEMM_BK);
+#pragma unroll
+				for (int it = 0; it < BIT; it++) rb[it] = *reinterpret_cast<const d2_t *>(bg[it] + k + GEMM_BK);
 			}
 			const double *as = As[cur];
 			const double *bs = Bs[cur];
 #pragma unroll
 			for (int s = 0; s < GEMM_BK / 4; s++) {
-				double a[4], b[4];
+				double a[TM], b[TN];
 #pragma unroll
-				for (int i = 0; i < 4; i++) a[i] = as[a_base + i * 16 * LDS_S + 4 * s];
+				for (int i = 0; i < TM; i++) a[i] = as[a_base + i * 16 * LDS_S + 4 * s];
 #pragma unroll
-				for (int j = 0; j < 4; j++) b[j] = bs[b_base + j * 16 * LDS_S + 4 * s];
+				for (int j = 0; j < TN; j++) b[j] = bs[b_base + j * 16 * LDS_S + 4 * s];
 #pragma unroll
-				for (int i = 0; i < 4; i++)
+				for (int i = 0; i < TM; i++)
 #pragma unroll
-					for (int j = 0; j < 4; j++)
+					for (int j = 0; j < TN; j++)
 						acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
 			}
 			if (more) {
 #pragma unroll
-				for (int it = 0; it < 4; it++) {
-					*reinterpret_cast<d2_t *>(&As[cur ^ 1][lofs[it]]) = ra[it];
-					*reinterpret_cast<d2_t *>(&Bs[cur ^ 1][lofs[it]]) = rb[it];
-				}
+				for (int it = 0; it < AIT; it++) *reinterpret_cast<d2_t *>(&As[cur ^ 1][lofs_a[it]]) = ra[it];
+#pragma unroll
+				for (int it = 0; it < BIT; it++) *reinterpret_cast<d2_t *>(&Bs[cur ^ 1][lofs_b[it]]) = rb[it];
 			}
 			__syncthreads();
 			cur ^= 1;
@@ -125,17 +139,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g)
 	}
 
 	// epilogue
-	const int row0 = tm * GEMM_BM + wm * 64 + (lane >> 4);
-	const int col0 = tn * GEMM_BN + wn * 64 + (lane & 15);
+	const int row0 = tm * BM + wm * WM + (lane >> 4);
+	const int col0 = tn * BN + wn * WN + (lane & 15);
 #pragma unroll
-	for (int i = 0; i < 4; i++)
+	for (int i = 0; i < TM; i++)
 #pragma unroll
 		for (int r = 0; r < 4; r++) {
 			const int row = row0 + i * 16 + 4 * r;
 			if (row >= g.m) continue;
 			double *crow = g.C + (long)row * g.ldc;
 #pragma unroll
-			for (int j = 0; j < 4; j++) {
+			for (int j = 0; j < TN; j++) {
 				const int col = col0 + j * 16;
 				if (col >= g.n) continue;
 				double v = g.alpha * acc[i][j][r];
@@ -145,106 +159,221 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g)
 		}
 }
 
+// active-tile count for a tile shape (tri skips the tiles strictly above the diagonal)
+static long count_tiles(const GemmArgs &a, int BM, int BN)
+{
+	const int tiles_m = (a.m + BM - 1) / BM, tiles_n = (a.n + BN - 1) / BN;
+	if (!a.tri) return (long)tiles_m * tiles_n;
+	long c = 0;
+	for (int tn = 0; tn < tiles_n; tn++) {
+		// smallest tm with tn*BN <= tm*BM + BM-1 + diag_off
+		long lo = ((long)tn * BN - a.diag_off - (BM - 1) + BM - 1) / BM;
+		if ((long)tn * BN - a.diag_off - (BM - 1) <= 0) lo = 0;
+		if (lo < tiles_m) c += tiles_m - lo;
+	}
+	return c;
+}
+
+int g_gemm_force_cfg = -1;   // test/bench hook: 0 = 128x128, 1 = 128x64, 2 = 64x64
+
+// Tile shape per call (measured on MI355X, profiles/r01_gemm_tile_sweep.txt): with thousands of 128x128 tiles
+// the big shape wins (less LDS/L2 traffic per flop: 60-62 vs 52 TF/s on the prediction GEMM); below that the
+// 64x64 shape is never slower (more workgroups for 256 CUs, 4 resident per CU) and up to 3x faster on the
+// narrow K<=256 updates of the factorisation.
+int choose_gemm_cfg(const GemmArgs &a)
+{
+	if (g_gemm_force_cfg >= 0) return g_gemm_force_cfg;
+	return count_tiles(a, 128, 128) >= 2048 ? 0 : 2;
+}
+
 hipError_t launch_gemm(hipStream_t s, const GemmArgs &a)
 {
 	if (a.m <= 0 || a.n <= 0) return hipSuccess;
-	const int tiles_m = (a.m + GEMM_BM - 1) / GEMM_BM;
-	const int tiles_n = (a.n + GEMM_BN - 1) / GEMM_BN;
-	hipLaunchKernelGGL(gemm_nt_kernel, dim3(tiles_m * tiles_n), dim3(256), 0, s, a);
+	const int cfg = choose_gemm_cfg(a);
+	if (cfg == 0) {
+		const int T = ((a.m + 127) / 128) * ((a.n + 127) / 128);
+		hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 2>), dim3(T), dim3(256), 0, s, a);
+	} else if (cfg == 1) {
+		const int T = ((a.m + 127) / 128) * ((a.n + 63) / 64);
+		hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 2>), dim3(T), dim3(256), 0, s, a);
+	} else {
+		const int T = ((a.m + 63) / 64) * ((a.n + 63) / 64);
+		hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4>), dim3(T), dim3(256), 0, s, a);
+	}
 	return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
-// Leaf: factor the 64x64 diagonal block at (c0,c0) of the tall matrix T and
-// solve X * L^T = B for the m_below rows under it (in place).  Every
-// workgroup factors the block redundantly in LDS (no separate launch, no
-// inter-workgroup hand-off); workgroup 0 writes L back.  Each wave then owns
-// 64 panel rows, one row per lane, held in registers.
-// A pivot <= 0 (or NaN) records its 1-based global index in *info (atomicMin)
-// -- GSL_EDOM of gsl_linalg_cholesky_decomp (maxmultimin.c:325-350).
+// Leaf = two kernels on the 64x64 diagonal block at (c0,c0) of T:
+//
+//  leaf_factor_kernel (1 workgroup, 1 wave): right-looking Cholesky, one matrix
+//    row per lane held in 64 VGPR pairs, no barriers; column k of L goes to LDS
+//    (transposed image, so the rank-1 update reads two l_ck per ds_read_b128 as
+//    wave-uniform broadcasts).  The 64 sequential pivots are the critical path
+//    of the whole factorisation: the next pivot is updated through an SGPR
+//    broadcast ahead of the LDS round trip, and 1/sqrt is the hardware estimate
+//    plus two Newton steps.  A pivot <= 0 (or NaN) records its 1-based global
+//    index in *info (atomicMin) -- GSL_EDOM of gsl_linalg_cholesky_decomp
+//    (maxmultimin.c:325-350).
+//  leaf_solve_kernel (4 waves, 16 panel rows each): X L^T = B in place on the
+//    fp64 MFMA.  L is staged in LDS, each wave first inverts one 16x16 diagonal
+//    block, then per row tile  X_j^T = Linv_jj (B_j^T - sum_{i<j} L_ji X_i^T):
+//    the D registers of one MFMA are exactly the B operand of the next (k slot
+//    of lane group g in step r is g+4r in both maps), so the chain never leaves
+//    registers.
+// (One fused kernel with the old row-per-lane solve made hipcc spill ~2000 VGPRs.)
 // ---------------------------------------------------------------------------
-constexpr int LP = LEAF + 1;
+constexpr int LP = LEAF + 2;
 
-__global__ __launch_bounds__(256) void leaf_kernel(double *T, long ld, int c0, int m_below, int *info)
+__device__ __forceinline__ double bcast_lane(double v, int srclane)
 {
-	__shared__ double Ls[LEAF * LP];
-	__shared__ double dg[LEAF];
-	__shared__ double invd[LEAF];
+	// wave-wide broadcast of lane `srclane` (compile-time constant after unrolling) through SGPRs
+	int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+	int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+	return __hiloint2double(hi, lo);
+}
 
-	const int tid = threadIdx.x;
-	double *D = T + (long)c0 * ld + c0;
-	for (int e = tid; e < LEAF * LEAF; e += 256) {
-		int r = e >> 6, c = e & 63;
-		Ls[r * LP + c] = D[(long)r * ld + c];
+__global__ __launch_bounds__(64) void leaf_factor_kernel(double *T, long ld, int c0, int *info)
+{
+	__shared__ double Lt[LEAF * LP];       // Lt[k*LP + c] = L[c][k]
+	const int lane = threadIdx.x;
+	double a[LEAF];
+	{
+		const double *rp = T + (long)(c0 + lane) * ld + c0;
+#pragma unroll
+		for (int k = 0; k < LEAF; k += 2) {
+			d2_t v = *reinterpret_cast<const d2_t *>(rp + k);
+			a[k] = v[0];
+			a[k + 1] = v[1];
+		}
+	}
+	int bad = 0;
+#pragma unroll
+	for (int k = 0; k < LEAF; k++) {
+		const double p = bcast_lane(a[k], k);          // current pivot a_kk (lane k, register k)
+		if (!(p > 0.0) && bad == 0) bad = k + 1;
+		// rs = 1/sqrt(p): hardware estimate + two Newton steps (full double precision)
+		double rs = __builtin_amdgcn_rsq(p);
+		{
+			double t = p * rs;
+			double e = fma(-t, rs, 1.0);
+			rs = fma(rs * 0.5, e, rs);
+			t = p * rs;
+			e = fma(-t, rs, 1.0);
+			rs = fma(rs * 0.5, e, rs);
+		}
+		const double lik = (lane == k) ? p * rs : a[k] * rs;   // l_kk = sqrt(p), l_ik = a_ik / l_kk
+		a[k] = lik;
+		Lt[k * LP + lane] = lik;
+		if (k + 1 < LEAF) {
+			// next pivot column first, through SGPRs: keeps the LDS round trip off the pivot chain
+			a[k + 1] = fma(-lik, bcast_lane(lik, k + 1), a[k + 1]);
+			// a_ic -= l_ik * l_ck for c >= k+2; l_ck pairs are wave-uniform 16-byte LDS reads
+			constexpr int dummy = 0; (void)dummy;
+			const int cs = k + 2;
+			if (cs < LEAF) {
+				int c = cs;
+				if (c & 1) { a[c] = fma(-lik, Lt[k * LP + c], a[c]); c++; }
+#pragma unroll
+				for (; c + 1 < LEAF; c += 2) {
+					const d2_t v = *reinterpret_cast<const d2_t *>(&Lt[k * LP + c]);
+					a[c] = fma(-lik, v[0], a[c]);
+					a[c + 1] = fma(-lik, v[1], a[c + 1]);
+				}
+			}
+		}
+	}
+	if (bad && lane == 0) atomicMin(info, c0 + bad);
+	double *wp = T + (long)(c0 + lane) * ld + c0;
+#pragma unroll
+	for (int k = 0; k < LEAF; k++)
+		if (k <= lane) wp[k] = a[k];
+}
+
+__global__ __launch_bounds__(256) void leaf_solve_kernel(double *T, long ld, int c0, int m_below)
+{
+	__shared__ double M[LEAF * LP];        // L; diagonal 16x16 blocks replaced by their inverses
+	__shared__ double Xs[4][16 * 17];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	{
+		// 16 rows per wave, all loads issued before the first LDS store (an un-unrolled loop serialises 16 L2 latencies)
+		const double *D = T + (long)c0 * ld + c0;
+		double v[16];
+#pragma unroll
+		for (int u = 0; u < 16; u++) v[u] = D[(long)(wave + 4 * u) * ld + lane];
+#pragma unroll
+		for (int u = 0; u < 16; u++) M[(wave + 4 * u) * LP + lane] = v[u];
+	}
+	__syncthreads();
+	{
+		// wave w inverts diagonal block w: row i = lane&15 (the four 16-lane groups do identical work)
+		const int i = lane & 15, o = 16 * wave;
+		double l[16], x[16];
+#pragma unroll
+		for (int m = 0; m < 16; m++) {
+			l[m] = M[(o + i) * LP + o + m];
+			x[m] = (m == i) ? 1.0 : 0.0;
+		}
+		const double inv_ii = 1.0 / M[(o + i) * LP + o + i];
+		double *xs = Xs[wave];
+#pragma unroll
+		for (int m = 0; m < 16; m++) {
+			if (i == m) {
+#pragma unroll
+				for (int c = 0; c < 16; c++) xs[m * 17 + c] = (c <= m) ? x[c] * inv_ii : 0.0;
+			}
+#pragma unroll
+			for (int c = 0; c <= m; c++) {
+				const double xm = xs[m * 17 + c];
+				if (i > m) x[c] = fma(-l[m], xm, x[c]);
+			}
+		}
+		__syncthreads();      // every wave has finished reading its diagonal block of M
+#pragma unroll
+		for (int m = 0; m < 16; m++)
+			if (lane < 16) M[(o + m) * LP + o + lane] = xs[m * 17 + lane];
 	}
 	__syncthreads();
 
-	for (int j = 0; j < LEAF; j++) {
-		const double p = Ls[j * LP + j];
-		const double s = sqrt(p);
-		const double inv = 1.0 / s;
-		if (tid < LEAF) {
-			if (tid == j) {
-				dg[j] = s;
-				invd[j] = inv;
-				if (!(p > 0.0) && blockIdx.x == 0) atomicMin(info, c0 + j + 1);
-			} else if (tid > j) {
-				Ls[tid * LP + j] *= inv;
+	const int g = lane >> 4, q = lane & 15;
+	const int prow0 = (blockIdx.x * 4 + wave) * 16;
+	if (prow0 >= m_below) return;
+	int prow = prow0 + q;
+	const bool valid = prow < m_below;
+	if (!valid) prow = m_below - 1;
+	double *bp = T + (long)(c0 + LEAF + prow) * ld + c0;
+	d4_t X[4];
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		d4_t acc;
+#pragma unroll
+		for (int r = 0; r < 4; r++) acc[r] = bp[16 * j + g + 4 * r];
+#pragma unroll
+		for (int i = 0; i < j; i++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) {
+				const double a = -M[(16 * j + q) * LP + 16 * i + g + 4 * r];
+				acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[i][r], acc, 0, 0, 0);
 			}
-		}
-		__syncthreads();
-		{
-			const int i = tid >> 2;
-			if (i > j) {
-				const double lij = Ls[i * LP + j];
-				for (int c = j + 1 + (tid & 3); c <= i; c += 4)
-					Ls[i * LP + c] -= lij * Ls[c * LP + j];
-			}
-		}
-		__syncthreads();
-	}
-
-	if (blockIdx.x == 0) {
-		for (int e = tid; e < LEAF * LEAF; e += 256) {
-			int r = e >> 6, c = e & 63;
-			if (c < r) D[(long)r * ld + c] = Ls[r * LP + c];
-			else if (c == r) D[(long)r * ld + c] = dg[r];
-		}
-	}
-
-	// panel rows: X L^T = B  ->  column-oriented forward substitution, row per lane
-	const int wave = tid >> 6, lane = tid & 63;
-	const int prow = (blockIdx.x * 4 + wave) * 64 + lane;
-	if (prow < m_below) {
-		double *bp = T + (long)(c0 + LEAF + prow) * ld + c0;
-		double b[LEAF];
+		d4_t xj = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-		for (int k = 0; k < LEAF; k += 2) {
-			d2_t v = *reinterpret_cast<const d2_t *>(bp + k);
-			b[k] = v[0];
-			b[k + 1] = v[1];
+		for (int r = 0; r < 4; r++) {
+			const double a = M[(16 * j + q) * LP + 16 * j + g + 4 * r];
+			xj = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[r], xj, 0, 0, 0);
 		}
+		X[j] = xj;
+		if (valid) {
 #pragma unroll
-		for (int k = 0; k < LEAF; k++) {
-			const double xk = b[k] * invd[k];
-			b[k] = xk;
-#pragma unroll
-			for (int j = k + 1; j < LEAF; j++)
-				b[j] -= xk * Ls[j * LP + k];
-		}
-#pragma unroll
-		for (int k = 0; k < LEAF; k += 2) {
-			d2_t v = {b[k], b[k + 1]};
-			*reinterpret_cast<d2_t *>(bp + k) = v;
+			for (int r = 0; r < 4; r++) bp[16 * j + g + 4 * r] = xj[r];
 		}
 	}
 }
 
 hipError_t launch_leaf(hipStream_t s, double *T, long ld, int c0, int m_below, int *info)
 {
-	int nblk = (m_below + 255) / 256;
-	if (nblk < 1) nblk = 1;
-	hipLaunchKernelGGL(leaf_kernel, dim3(nblk), dim3(256), 0, s, T, ld, c0, m_below, info);
+	hipLaunchKernelGGL(leaf_factor_kernel, dim3(1), dim3(64), 0, s, T, ld, c0, info);
+	if (m_below > 0)
+		hipLaunchKernelGGL(leaf_solve_kernel, dim3((m_below + 63) / 64), dim3(256), 0, s, T, ld, c0, m_below);
 	return hipGetLastError();
 }
 
