@@ -93,6 +93,10 @@ int gpemu_loglik_collect(gpemu_ctx *ctx, double *neg_loglik, double *sigma2, dou
  * App. A.3): thetas are the FULL vector with theta[0] ignored (set to 0 for
  * the matrix, replaced by log sigma^2 for the amplitude factor). */
 int gpemu_grad(gpemu_ctx *ctx, const double *thetas, int nthetas, double *grad, int *info);
+/* a13: evalFnGradMulti (maxmultimin.c:615-618): value and gradient from ONE factorisation (the reference
+ * fills and factors twice).  neg_loglik is the evalFnMulti value (theta[0] taken as 0). */
+int gpemu_loglik_grad(gpemu_ctx *ctx, const double *thetas, int nthetas, double *neg_loglik, double *sigma2,
+                      double *beta, double *grad, int *info);
 
 /* ---- a14/a15: chol_inverse_cov_matrix + alloc_emulator_struct -------
  * (libEmu/emulate-fns.c:275-299, emulator_struct.c:13-37)

@@ -34,6 +34,7 @@ SYMBOLS = {
     "gpemu_loglik_enqueue": (C.c_int, [C.c_void_p, _dp, C.c_int]),
     "gpemu_loglik_collect": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _ip]),
     "gpemu_grad": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _ip]),
+    "gpemu_loglik_grad": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _dp, _dp, _dp, _ip]),
     "gpemu_predict_setup": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _ip]),
     "gpemu_get_cinverse": (C.c_int, [C.c_void_p, _dp]),
     "gpemu_predict_batch": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
@@ -179,6 +180,16 @@ class Context:
         info = C.c_int(0)
         rc = self._chk(self.L.gpemu_grad(self.h, _p(th), th.size, _p(g), C.byref(info)), allow=(ERR_NOT_PD,))
         return g, rc
+
+    def loglik_grad(self, thetas):
+        th = _a(thetas)
+        g = np.full(th.size - 1, np.nan)
+        beta = np.full(self.nreg, np.nan)
+        v, s2 = C.c_double(np.nan), C.c_double(np.nan)
+        info = C.c_int(0)
+        rc = self._chk(self.L.gpemu_loglik_grad(self.h, _p(th), th.size, C.byref(v), C.byref(s2), _p(beta), _p(g),
+                                                C.byref(info)), allow=(ERR_NOT_PD,))
+        return dict(value=v.value, sigma2=s2.value, beta=beta, grad=g, info=info.value, status=rc)
 
     # -- a15 / a19 ---------------------------------------------------------
     def predict_setup(self, thetas):

@@ -766,7 +766,36 @@ extern "C" int gpemu_get_cinverse(gpemu_ctx *ctx, double *cinv_out)
 // ---------------------------------------------------------------------------
 // gradient (gradFnMulti, maxmultimin.c:416-550)
 // ---------------------------------------------------------------------------
+static int grad_impl(gpemu_ctx *ctx, const double *thetas, int nthetas, double *grad, int *info, HostLik *lik_out);
+
 extern "C" int gpemu_grad(gpemu_ctx *ctx, const double *thetas, int nthetas, double *grad, int *info)
+{
+	return grad_impl(ctx, thetas, nthetas, grad, info, nullptr);
+}
+
+// evalFnGradMulti (maxmultimin.c:615-618) with ONE factorisation shared by value and gradient
+extern "C" int gpemu_loglik_grad(gpemu_ctx *ctx, const double *thetas, int nthetas, double *neg_loglik, double *sigma2,
+                                 double *beta, double *grad, int *info)
+{
+	HostLik r;
+	int rc = grad_impl(ctx, thetas, nthetas, grad, info, &r);
+	if (rc == GPEMU_ERR_NOT_PD) {
+		if (neg_loglik) *neg_loglik = NAN;
+		if (sigma2) *sigma2 = NAN;
+		return rc;
+	}
+	if (rc) return rc;
+	if (beta) for (int a = 0; a < ctx->nreg; a++) beta[a] = r.beta[a];
+	if (sigma2) *sigma2 = r.sigma2;
+	if (neg_loglik) {
+		const double log_2_pi = 1.83788;
+		const double ll = -(1.0 / 2.0) * r.logdet - (ctx->N / 2.0) * log_2_pi + r.quad * (-1.0 / 2.0);
+		*neg_loglik = -1 * ll;
+	}
+	return GPEMU_OK;
+}
+
+static int grad_impl(gpemu_ctx *ctx, const double *thetas, int nthetas, double *grad, int *info, HostLik *lik_out)
 {
 	if (!ctx || !grad) return GPEMU_ERR_ARG;
 	if (!ctx->dX) return fail(ctx, GPEMU_ERR_STATE, "model not set");
@@ -783,6 +812,7 @@ extern "C" int gpemu_grad(gpemu_ctx *ctx, const double *thetas, int nthetas, dou
 	if (rc) return rc;
 	HostLik r = host_likelihood(ctx);
 	if (r.status) return fail(ctx, r.status, "H^T C^-1 H is not positive definite");
+	if (lik_out) *lik_out = r;
 	rc = build_corner(ctx);
 	if (rc) return rc;
 	const int N = ctx->N, d = ctx->d, Rp = ctx->Rp;

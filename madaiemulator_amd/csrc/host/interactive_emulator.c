@@ -1,0 +1,277 @@
+/*
+ * interactive_emulator -- command-line front end, drop-in for the reference's
+ * src/interactive_emulator.c (same three modes, options, file formats and stdout protocol):
+ *
+ *   interactive_emulator estimate_thetas INPUT_MODEL_FILE MODEL_SNAPSHOT_FILE [OPTIONS]
+ *   interactive_emulator interactive_mode MODEL_SNAPSHOT_FILE [OPTIONS]
+ *   interactive_emulator print_thetas MODEL_SNAPSHOT_FILE
+ *
+ * Kept quirks: --covariance_fn is atoi'd and compared with POWEREXPCOVFN=1 /
+ * MATERN32=2 / MATERN52=3 (0 and 1 both mean power-exponential); --pca_variance falls through
+ * into --pca_output and --quiet.
+ *
+ * interactive_mode is a request/response pipe (flush after every answer, :440 of the reference).
+ * Points that are ALREADY waiting on stdin are answered as one GPU batch; a lone point is
+ * answered immediately, so MCMC drivers that wait for each answer never dead-lock.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <getopt.h>
+#include <unistd.h>
+#include <poll.h>
+#include <assert.h>
+#include <math.h>
+#include "libemu.h"
+
+struct cmdLineOpts {
+	int regOrder, covFn, quietFlag, pcaOutputFlag;
+	double pca_variance;
+	char *run_mode, *inputfile, *statefile;
+};
+
+static const char useage[] =
+	"useage:\n"
+	"  interactive_emulator estimate_thetas INPUT_MODEL_FILE MODEL_SNAPSHOT_FILE [OPTIONS]\n"
+	"or\n"
+	"  interactive_emulator interactive_mode MODEL_SNAPSHOT_FILE [OPTIONS]\n"
+	"or\n"
+	"  interactive_emulator print_thetas MODEL_SNAPSHOT_FILE\n"
+	"\n"
+	"INPUT_MODEL_FILE can be \"-\" to read from standard input.\n"
+	"\n"
+	"Options which only influence estimate_thetas:\n"
+	"  --regression_order=0..3   (const, linear, quadratic, cubic)\n"
+	"  --covariance_fn=0|1 (POWER_EXPONENTIAL)  2 (MATERN32)  3 (MATERN52)\n"
+	"  (-v FRAC) --pca_variance=FRAC : keep PCA components up to variance fraction FRAC\n"
+	"options which influence interactive_mode:\n"
+	"  (-q) --quiet: run without any extraneous output\n"
+	"  (-z) --pca_output: emulator output is left in the pca space\n"
+	"general options:\n"
+	"  -h -? print this dialogue\n"
+	"environment: GPEMU_DEVICE (HIP device), GPEMU_SEED, GPEMU_NTHREADS, GPEMU_JOBS, GPEMU_RESTARTS\n";
+
+static int perr(const char *s) { fprintf(stderr, "%s\n", s); return EXIT_FAILURE; }
+
+/* interactive_emulator.c:212-251 of the reference: "nt d N", N*d design values, N*nt outputs */
+static int open_model_file(const char *name, gsl_matrix **xmodel_ptr, gsl_matrix **training_ptr)
+{
+	FILE *in = (!strcmp(name, "-") || !strcmp(name, "stdin")) ? stdin : fopen(name, "r");
+	if (!in) return 0;
+	int nt = 0, d = 0, n = 0;
+	if (fscanf(in, "%d%*c", &nt) != 1 || fscanf(in, "%d%*c", &d) != 1 || fscanf(in, "%d%*c", &n) != 1) return 0;
+	assert(nt > 0 && d > 0 && n > 0);
+	gsl_matrix *x = gsl_matrix_alloc(n, d), *y = gsl_matrix_alloc(n, nt);
+	for (int i = 0; i < n; i++) for (int j = 0; j < d; j++) if (fscanf(in, "%lf%*c", gsl_matrix_ptr(x, i, j)) != 1) return 0;
+	for (int i = 0; i < n; i++) for (int j = 0; j < nt; j++) if (fscanf(in, "%lf%*c", gsl_matrix_ptr(y, i, j)) != 1) return 0;
+	if (in != stdin) fclose(in);
+	*xmodel_ptr = x; *training_ptr = y;
+	return 1;
+}
+
+static int estimate_thetas(struct cmdLineOpts *o)
+{
+	gsl_matrix *xmodel = NULL, *training = NULL;
+	double varfrac = 0.95;
+	if (!open_model_file(o->inputfile, &xmodel, &training)) return perr("Input File read failed.");
+	FILE *out = fopen(o->statefile, "w");
+	if (!out) return perr("Opening statefile failed.");
+	if (o->pca_variance <= 1.0 && o->pca_variance > 0) varfrac = o->pca_variance;
+	if (o->covFn < 0 || o->covFn > 3) { fprintf(stderr, "#ERROR cov_fn_index %d not supported\n", o->covFn); exit(EXIT_FAILURE); }
+	if (o->regOrder < 0 || o->regOrder > 3) { fprintf(stderr, "#ERROR regression_order %d not supported\n", o->regOrder); exit(EXIT_FAILURE); }
+	multi_modelstruct *model = alloc_multimodelstruct(xmodel, training, o->covFn, o->regOrder, varfrac);
+	if (!model) return perr("Failed to allocated multi_modelstruct.\n");
+	estimate_multi(model, out);
+	fclose(out);
+	free_multimodelstruct(model);
+	return EXIT_SUCCESS;
+}
+
+/* ---- stdin reader that knows whether more input is already waiting ---- */
+struct reader { int fd; char buf[1 << 16]; size_t len, pos; int eof; };
+
+static int reader_fill(struct reader *r, int block)
+{
+	if (r->eof) return 0;
+	if (r->pos > 0) { memmove(r->buf, r->buf + r->pos, r->len - r->pos); r->len -= r->pos; r->pos = 0; }
+	if (r->len >= sizeof r->buf - 1) return 0;
+	if (!block) {
+		struct pollfd p = {r->fd, POLLIN, 0};
+		if (poll(&p, 1, 0) <= 0) return 0;
+	}
+	ssize_t n = read(r->fd, r->buf + r->len, sizeof r->buf - 1 - r->len);
+	if (n <= 0) { r->eof = 1; return 0; }
+	r->len += (size_t)n;
+	return 1;
+}
+
+/* next number; block=0 never waits for more input. returns 1 ok, 0 nothing available (yet / eof) */
+static int reader_next(struct reader *r, int block, double *out)
+{
+	for (;;) {
+		while (r->pos < r->len && strchr(" \t\r\n,;", r->buf[r->pos])) r->pos++;
+		size_t e = r->pos;
+		while (e < r->len && !strchr(" \t\r\n,;", r->buf[e])) e++;
+		if (e > r->pos && (e < r->len || r->eof)) {     /* a complete token */
+			char tmp[128];
+			size_t n = e - r->pos < sizeof tmp - 1 ? e - r->pos : sizeof tmp - 1;
+			memcpy(tmp, r->buf + r->pos, n); tmp[n] = 0;
+			r->pos = e;
+			char *endp;
+			*out = strtod(tmp, &endp);
+			if (endp == tmp) return 0;                  /* not a number: stop like fscanf would */
+			return 1;
+		}
+		if (!reader_fill(r, block)) {
+			if (r->eof && e > r->pos) continue;         /* flush the last token */
+			return 0;
+		}
+	}
+}
+
+#define BATCH_MAX 16384
+
+static int interactive_mode(struct cmdLineOpts *o)
+{
+	FILE *fp = fopen(o->statefile, "r");
+	if (!fp) return perr("Error opening file");
+	multi_modelstruct *model = load_multi_modelstruct(fp);
+	fclose(fp);
+	multi_emulator *emu = alloc_multi_emulator(model);
+	const int d = model->nparams, nt = model->nt;
+	const int nout = o->pcaOutputFlag ? model->nr : nt;
+	FILE *out = stdout;
+	if (!o->quietFlag) {
+		fprintf(out, "%d\n", d);
+		for (int i = 0; i < d; i++) fprintf(out, "%s%d\n", "param_", i);
+		fprintf(out, "%d\n", 2 * nt);
+		for (int i = 0; i < nt; i++) fprintf(out, "%s_%d\n%s_%d\n", "mean", i, "variance", i);
+		fflush(out);
+	}
+	struct reader *rd = (struct reader *)calloc(1, sizeof *rd);
+	rd->fd = STDIN_FILENO;
+	double *pts = (double *)malloc(sizeof(double) * (size_t)BATCH_MAX * d);
+	double *mean = (double *)malloc(sizeof(double) * (size_t)BATCH_MAX * nt), *var = (double *)malloc(sizeof(double) * (size_t)BATCH_MAX * nt);
+	for (;;) {
+		int np = 0, partial = 0;
+		/* first point: wait for it; further points: only what is already there */
+		while (np < BATCH_MAX) {
+			int k;
+			for (k = 0; k < d; k++)
+				if (!reader_next(rd, np == 0 || k > 0, &pts[(size_t)np * d + k])) break;
+			if (k < d) { partial = (k > 0); break; }
+			np++;
+		}
+		(void)partial;
+		if (np == 0) break;
+		gsl_matrix view;
+		view.size1 = (size_t)np; view.size2 = (size_t)d; view.tda = (size_t)d; view.data = pts; view.block = NULL; view.owner = 0;
+		emulate_points_multi(emu, &view, o->pcaOutputFlag, mean, var);
+		for (int q = 0; q < np; q++) {
+			for (int i = 0; i < nout; i++) {
+				fprintf(out, "%.17f\n", mean[(size_t)q * nout + i]);
+				fprintf(out, "%.17f\n", var[(size_t)q * nout + i]);
+			}
+			/* the reference always prints nt pairs; in pca mode entries nr..nt-1 are whatever the vectors held */
+			for (int i = nout; i < nt; i++) fprintf(out, "%.17f\n%.17f\n", 0.0, 0.0);
+		}
+		fflush(out);
+		if (rd->eof && rd->pos >= rd->len) break;
+	}
+	free(pts); free(mean); free(var); free(rd);
+	free_multi_emulator(emu);
+	return 0;
+}
+
+static int print_thetas(struct cmdLineOpts *o)
+{
+	FILE *fp = fopen(o->statefile, "r");
+	if (!fp) return perr("Error opening file");
+	multi_modelstruct *model = load_multi_modelstruct(fp);
+	fclose(fp);
+	const int nr = model->nr, d = model->nparams, N = model->nmodel_points;
+	const int nthetas = (int)model->pca_model_array[0]->thetas->size;
+	double vartot = 0;
+	printf("#-- EMULATOR LENGTH SCALES (thetas) IN PCA SPACE -- #\n");
+	for (int i = 0; i < nr; i++) vartot += gsl_vector_get(model->pca_evals_r, i);
+	printf("#-- id\tpca-var\tScale\tNugget");
+	for (int i = 0; i < d; i++) printf("\tlength_%d", i);
+	printf(" -- #\n");
+	for (int i = 0; i < nr; i++) {
+		printf("%d\t", i);
+		printf("%lf\t", gsl_vector_get(model->pca_evals_r, i) / vartot);
+		for (int j = 0; j < nthetas; j++) printf("%lf\t", exp(gsl_vector_get(model->pca_model_array[i]->thetas, j)));
+		printf("\n");
+	}
+	for (int i = 0; i < nr; i++) {
+		char name[256];
+		snprintf(name, sizeof name, "pca_emu_summary_%d.dat", i);
+		fp = fopen(name, "w");
+		if (!fp) continue;
+		for (int j = 0; j < N; j++) {
+			for (int k = 0; k < d; k++) fprintf(fp, "%lf\t", gsl_matrix_get(model->pca_model_array[i]->xmodel, j, k));
+			fprintf(fp, "%lf\n", gsl_vector_get(model->pca_model_array[i]->training_vector, j));
+		}
+		fclose(fp);
+	}
+	return 0;
+}
+
+static struct cmdLineOpts *global_opt_parse(int argc, char **argv)
+{
+	static const char *optString = "r:c:v:zqh?";
+	static const struct option longOpts[] = {
+		{"regression_order", required_argument, NULL, 'r'}, {"covariance_fn", required_argument, NULL, 'c'},
+		{"pca_variance", required_argument, NULL, 'v'},      {"pca_output", no_argument, NULL, 'z'},
+		{"quiet", no_argument, NULL, 'q'},                    {"help", no_argument, NULL, 'h'},
+		{NULL, no_argument, NULL, 0}};
+	struct cmdLineOpts *o = (struct cmdLineOpts *)calloc(1, sizeof *o);
+	o->pca_variance = 0.99;
+	int idx, opt;
+	while ((opt = getopt_long(argc, argv, optString, longOpts, &idx)) != -1) {
+		switch (opt) {
+		case 'r': o->regOrder = atoi(optarg); break;
+		case 'c': o->covFn = atoi(optarg); break;
+		case 'v':
+			o->pca_variance = atof(optarg);
+			if (o->pca_variance < 0.0 || o->pca_variance > 1.0) {
+				fprintf(stderr, "# err pca_variance argument given incorrect value: %lf\n", o->pca_variance);
+				o->pca_variance = 0.95;
+				fprintf(stderr, "# using default value: %lf\n", o->pca_variance);
+			}
+			fprintf(stderr, "# var-frac: %lf\n", o->pca_variance);
+			/* fall through (as the reference does) */
+		case 'z': o->pcaOutputFlag = 1; /* fall through */
+		case 'q': o->quietFlag = 1; break;
+		case 'h':
+		case '?': exit(perr(useage));
+		default: break;
+		}
+	}
+	if (optind >= argc) exit(perr(useage));
+	o->run_mode = argv[optind];
+	if (!strcmp(o->run_mode, "estimate_thetas")) {
+		if (optind + 2 >= argc) exit(perr(useage));
+		o->inputfile = argv[optind + 1];
+		o->statefile = argv[optind + 2];
+	} else {
+		if (optind + 1 >= argc) exit(perr(useage));
+		o->statefile = argv[optind + 1];
+	}
+	return o;
+}
+
+int main(int argc, char **argv)
+{
+	if (argc < 3) return perr(useage);
+	const char *dev = getenv("GPEMU_DEVICE");
+	if (dev) gpemu_host_set_device(atoi(dev));
+	struct cmdLineOpts *o = global_opt_parse(argc, argv);
+	int rc;
+	if (!strcmp(o->run_mode, "estimate_thetas")) rc = estimate_thetas(o);
+	else if (!strcmp(o->run_mode, "interactive_mode")) rc = interactive_mode(o);
+	else if (!strcmp(o->run_mode, "print_thetas")) rc = print_thetas(o);
+	else { free(o); return perr(useage); }
+	free(o);
+	return rc;
+}

@@ -1,0 +1,190 @@
+/*
+ * libemu.h -- host-side (C99) mirror of the reference's libEmu / emulator
+ * interface for the GP hot path, implemented on the MI355X device library
+ * (include/gpemu.h).  Same names, argument meaning and error behaviour as the
+ * reference headers, one header instead of eleven:
+ *
+ *   optstruct.h:25-88        struct optstruct            (field order kept)
+ *   modelstruct.h:28-98      struct modelstruct          (field order kept)
+ *   emulator_struct.h:20-29  struct emulator_struct      (field order kept)
+ *   multi_modelstruct.h:18-61, multivar_support.h:11-20
+ *   libEmu/estimate_threaded.h:18-29  struct estimate_thetas_params
+ *   libEmu/{emulator,regression,estimator-fns,maxmultimin,emulate-fns}.h prototypes
+ *
+ * What differs from the reference, by design:
+ *   - every O(N^2)/O(N^3) operation runs on the GPU; there is no CPU path for them;
+ *   - log det C is 2*sum(log L_ii) instead of log((prod L_ii)^2) (the product under/overflows);
+ *   - evalFnGradMulti shares ONE factorisation between value and gradient;
+ *   - emulate_points() is added: a batch of query points per call.
+ */
+#ifndef GPEMU_LIBEMU_H
+#define GPEMU_LIBEMU_H
+
+#include <stdio.h>
+#include "gsl_compat.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define POWEREXPCOVFN 1
+#define MATERN32 2
+#define MATERN52 3
+
+struct modelstruct;
+
+typedef struct optstruct {
+	int nthetas;
+	int nparams;
+	int nmodel_points;
+	int nemulate_points;
+	int regression_order;
+	int nregression_fns;
+	int fixed_nugget_mode;
+	double fixed_nugget;
+	int cov_fn_index;
+	int use_data_scales;
+	gsl_matrix *grad_ranges;          /* nthetas x 2 search box */
+} optstruct;
+
+typedef struct modelstruct {
+	gsl_matrix *xmodel;               /* nmodel_points x nparams */
+	gsl_vector *training_vector;      /* nmodel_points */
+	gsl_vector *thetas;               /* nthetas */
+	gsl_vector *sample_scales;        /* nparams */
+	struct optstruct *options;
+	void (*makeHVector)(gsl_vector *h_vector, gsl_vector *x_location, int nparams);
+	double (*covariance_fn)(gsl_vector *, gsl_vector *, gsl_vector *, int, int);
+	void (*makeGradMatLength)(gsl_matrix *dCdTheta, gsl_matrix *xmodel, double thetaLength, int index,
+	                          int nmodel_points, int nparams);
+} modelstruct;
+
+typedef struct emulator_struct {
+	int nparams;
+	int nmodel_points;
+	int nregression_fns;
+	int nthetas;
+	struct modelstruct *model;
+	gsl_matrix *cinverse;
+	gsl_vector *beta_vector;
+	gsl_matrix *h_matrix;
+} emulator_struct;
+
+typedef struct multi_modelstruct {
+	int nt;
+	int nr;
+	int nparams;
+	int nmodel_points;
+	int cov_fn_index;
+	int regression_order;
+	gsl_matrix *xmodel;
+	gsl_matrix *training_matrix;
+	gsl_vector *training_mean;
+	modelstruct **pca_model_array;
+	gsl_vector *pca_evals_r;
+	gsl_matrix *pca_evecs_r;
+	gsl_matrix *pca_zmatrix;
+} multi_modelstruct;
+
+typedef struct multi_emulator {
+	int nt;
+	int nr;
+	int nparams;
+	int nmodel_points;
+	int nregression_fns;
+	int nthetas;
+	multi_modelstruct *model;
+	emulator_struct **emu_struct_array;
+} multi_emulator;
+
+struct estimate_thetas_params {
+	struct optstruct *options;
+	struct modelstruct *the_model;
+	gsl_rng *random_number;
+	gsl_matrix *h_matrix;
+	int max_tries;
+	int success_count;
+	double lhood_current;
+	double my_best;
+};
+
+/* ---- libEmu/emulator.h ------------------------------------------------- */
+double covariance_fn_gaussian(gsl_vector *xm, gsl_vector *xn, gsl_vector *thetas, int nthetas, int nparams);
+double covariance_fn_matern_three(gsl_vector *xm, gsl_vector *xn, gsl_vector *thetas, int nthetas, int nparams);
+double covariance_fn_matern_five(gsl_vector *xm, gsl_vector *xn, gsl_vector *thetas, int nthetas, int nparams);
+void derivative_l_gauss(gsl_matrix *dCdTheta, gsl_matrix *xmodel, double thetaLength, int index, int nmodel_points, int nparams);
+void derivative_l_matern_three(gsl_matrix *dCdTheta, gsl_matrix *xmodel, double thetaLength, int index, int nmodel_points, int nparams);
+void derivative_l_matern_five(gsl_matrix *dCdTheta, gsl_matrix *xmodel, double thetaLength, int index, int nmodel_points, int nparams);
+void makeCovMatrix_fnptr(gsl_matrix *cov_matrix, gsl_matrix *xmodel, gsl_vector *thetas, int nmodel_points, int nthetas,
+                         int nparams, double (*covariance_fn_ptr)(gsl_vector *, gsl_vector *, gsl_vector *, int, int));
+void makeKVector_fnptr(gsl_vector *kvector, gsl_matrix *xmodel, gsl_vector *xnew, gsl_vector *thetas, int nmodel_points,
+                       int nthetas, int nparams,
+                       double (*covariance_fn_ptr)(gsl_vector *, gsl_vector *, gsl_vector *, int, int));
+
+/* ---- libEmu/regression.h ------------------------------------------------ */
+void makeHVector_trivial(gsl_vector *h_vector, gsl_vector *x_location, int nparams);
+void makeHVector_linear(gsl_vector *h_vector, gsl_vector *x_location, int nparams);
+void makeHVector_quadratic(gsl_vector *h_vector, gsl_vector *x_location, int nparams);
+void makeHVector_cubic(gsl_vector *h_vector, gsl_vector *x_location, int nparams);
+void makeHMatrix_fnptr(gsl_matrix *h_matrix, gsl_matrix *xmodel, int nmodel_points, int nparams, int nregression_fns,
+                       void (*makeHVector_ptr)(gsl_vector *, gsl_vector *, int));
+
+/* ---- libEmu/maxmultimin.h ------------------------------------------------ */
+double evalFnMulti(const gsl_vector *theta_vec_less_amp, void *params_in);
+void gradFnMulti(const gsl_vector *theta_vec_less_amp, void *params_in, gsl_vector *grad_vec);
+void evalFnGradMulti(const gsl_vector *theta_vec, void *params, double *fnval, gsl_vector *grad_vec);
+double estimateSigmaFull(gsl_vector *thetas_less_amp, void *params_in);
+void maxWithMultiMin(struct estimate_thetas_params *params);
+int doOptimizeMultiMin(double (*fn)(const gsl_vector *, void *),
+                       void (*gradientFn)(const gsl_vector *, void *, gsl_vector *),
+                       void (*fnGradFn)(const gsl_vector *, void *, double *, gsl_vector *),
+                       gsl_vector *thetaInit, gsl_vector *thetaFinal, void *args);
+void set_random_init_value(gsl_rng *rand, gsl_vector *x, gsl_matrix *ranges, int nthetas);
+
+/* ---- libEmu/estimate_threaded.h ------------------------------------------ */
+void estimate_thetas_threaded(modelstruct *the_model, optstruct *options);
+int get_number_cpus(void);
+
+/* ---- modelstruct.h / optstruct.h ------------------------------------------ */
+modelstruct *alloc_modelstruct_2(gsl_matrix *xmodel, gsl_vector *training_vector, int cov_fn_index, int regression_order);
+void free_modelstruct_2(modelstruct *model);
+void dump_modelstruct_2(FILE *fptr, modelstruct *the_model);
+modelstruct *load_modelstruct_2(FILE *fptr);
+void set_global_ptrs(modelstruct *model);
+gsl_vector *fill_sample_scales_vec(gsl_matrix *xmodel);
+void setup_optimization_ranges(optstruct *options, modelstruct *the_model);
+
+/* ---- emulator_struct.h ------------------------------------------------------ */
+emulator_struct *alloc_emulator_struct(modelstruct *model);
+void free_emulator_struct(emulator_struct *e);
+void emulate_point(emulator_struct *e, gsl_vector *point, double *mean, double *variance);
+/* extension: npoints query rows (npoints x nparams), mean/variance arrays of npoints */
+void emulate_points(emulator_struct *e, gsl_matrix *points, double *mean, double *variance);
+
+/* ---- multi_modelstruct.h / multivar_support.h ---------------------------------- */
+multi_modelstruct *alloc_multimodelstruct(gsl_matrix *xmodel_in, gsl_matrix *training_matrix_in, int cov_fn_index,
+                                          int regression_order, double varfrac);
+void gen_pca_decomp(multi_modelstruct *m, double vfrac);
+void gen_pca_model_array(multi_modelstruct *m);
+void dump_multi_modelstruct(FILE *fptr, multi_modelstruct *m);
+multi_modelstruct *load_multi_modelstruct(FILE *fptr);
+double vector_elt_sum(gsl_vector *vec, int nstop);
+void free_multimodelstruct(multi_modelstruct *m);
+multi_emulator *alloc_multi_emulator(multi_modelstruct *model);
+void free_multi_emulator(multi_emulator *e);
+void estimate_multi(multi_modelstruct *m, FILE *outfp);
+void emulate_point_multi(multi_emulator *emu, gsl_vector *the_point, gsl_vector *the_mean, gsl_vector *the_variance);
+void emulate_point_multi_pca(multi_emulator *emu, gsl_vector *the_point, gsl_vector *the_mean, gsl_vector *the_variance);
+/* extension: batched form of the two calls above; outputs are npoints x nt (or x nr) row-major */
+void emulate_points_multi(multi_emulator *emu, gsl_matrix *points, int pca_space, double *mean_out, double *var_out);
+
+/* ---- knobs of this implementation (not in the reference) ------------------------ */
+void gpemu_host_set_device(int device);          /* HIP device used by contexts created from this thread on */
+void gpemu_host_set_seed(unsigned long seed);    /* 0 = /dev/urandom as the reference (estimate_threaded.c:159) */
+void gpemu_host_set_search(int nthreads, int restarts_per_job);   /* defaults: 1 thread (1 GPU stream), 50 restarts */
+void gpemu_host_release(void *params_or_emulator); /* drop the device context cached for a params / emulator pointer */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,330 @@
+/*
+ * multi.c -- multi-output models: PCA of the N x t training matrix, nr independent scalar GPs,
+ * the MODEL_SNAPSHOT_FILE, and back-projection of predictions
+ * (multi_modelstruct.c:38-507, multivar_support.c:20-157 of the reference).
+ *
+ * gsl_eigen_symmv is replaced by a cyclic Jacobi eigen-solver (nt is the number of outputs, tens
+ * at most); eigenvector signs are whatever the solver returns, as with GSL -- only back-projected
+ * outputs are comparable between implementations.
+ */
+#include <assert.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include "libemu.h"
+
+double vector_elt_sum(gsl_vector *vec, int nstop)
+{
+	assert(nstop >= 0);
+	assert((unsigned)nstop <= vec->size);
+	double sum = 0.0;
+	for (int i = 0; i < nstop; i++) sum += gsl_vector_get(vec, i);
+	return sum;
+}
+
+/* symmetric eigen-decomposition A = V diag(w) V^T by cyclic Jacobi rotations; A is n x n row-major and destroyed */
+static void jacobi_eigen(double *A, int n, double *w, double *V)
+{
+	for (int i = 0; i < n; i++)
+		for (int j = 0; j < n; j++) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+	for (int sweep = 0; sweep < 100; sweep++) {
+		double off = 0.0;
+		for (int i = 0; i < n; i++)
+			for (int j = i + 1; j < n; j++) off += A[i * n + j] * A[i * n + j];
+		if (off < 1e-300) break;
+		for (int p = 0; p < n - 1; p++)
+			for (int q = p + 1; q < n; q++) {
+				const double apq = A[p * n + q];
+				if (apq == 0.0) continue;
+				const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+				const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+				const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+				for (int k = 0; k < n; k++) {
+					const double akp = A[k * n + p], akq = A[k * n + q];
+					A[k * n + p] = c * akp - s * akq;
+					A[k * n + q] = s * akp + c * akq;
+				}
+				for (int k = 0; k < n; k++) {
+					const double apk = A[p * n + k], aqk = A[q * n + k];
+					A[p * n + k] = c * apk - s * aqk;
+					A[q * n + k] = s * apk + c * aqk;
+				}
+				for (int k = 0; k < n; k++) {
+					const double vkp = V[k * n + p], vkq = V[k * n + q];
+					V[k * n + p] = c * vkp - s * vkq;
+					V[k * n + q] = s * vkp + c * vkq;
+				}
+			}
+	}
+	for (int i = 0; i < n; i++) w[i] = A[i * n + i];
+}
+
+/* multi_modelstruct.c:172-338 */
+void gen_pca_decomp(multi_modelstruct *m, double vfrac)
+{
+	const int nt = m->nt, N = m->nmodel_points;
+	double *ysub = (double *)malloc(sizeof(double) * (size_t)N * nt);
+	double *cov = (double *)calloc((size_t)nt * nt, sizeof(double));
+	double *w = (double *)malloc(sizeof(double) * (size_t)nt), *V = (double *)malloc(sizeof(double) * (size_t)nt * nt);
+	for (int i = 0; i < nt; i++) {
+		printf("# y(%d) mean: %lf\n", i, gsl_vector_get(m->training_mean, i));
+		for (int j = 0; j < N; j++) ysub[j * nt + i] = gsl_matrix_get(m->training_matrix, j, i) - gsl_vector_get(m->training_mean, i);
+	}
+	for (int a = 0; a < nt; a++)
+		for (int b = 0; b < nt; b++) {
+			double s = 0.0;
+			for (int j = 0; j < N; j++) s += ysub[j * nt + a] * ysub[j * nt + b];
+			cov[a * nt + b] = s * (1.0 / (double)N);
+		}
+	jacobi_eigen(cov, nt, w, V);
+	/* descending eigenvalues, eigenvectors in columns (gsl_eigen_symmv_sort ... GSL_EIGEN_SORT_VAL_DESC) */
+	int *ord = (int *)malloc(sizeof(int) * (size_t)nt);
+	for (int i = 0; i < nt; i++) ord[i] = i;
+	for (int i = 0; i < nt; i++)
+		for (int j = i + 1; j < nt; j++)
+			if (w[ord[j]] > w[ord[i]]) { int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
+	gsl_vector *evals = gsl_vector_alloc(nt);
+	for (int i = 0; i < nt; i++) gsl_vector_set(evals, i, w[ord[i]]);
+	const double total_variance = vector_elt_sum(evals, nt);
+	/* the reference's loop (:267-272): frac is the share of the FIRST i values, tested before i is advanced,
+	 * so one component more than needed is kept, capped at nt-1 */
+	int i = 0;
+	double frac = 0.0;
+	while (frac < vfrac && (i + 1) < nt) {
+		frac = (1.0 / total_variance) * vector_elt_sum(evals, i);
+		i++;
+	}
+	m->nr = i;
+	if (nt == 1) m->nr = 1;
+	m->pca_evals_r = gsl_vector_alloc(m->nr);
+	m->pca_evecs_r = gsl_matrix_alloc(nt, m->nr);
+	fprintf(stderr, "# nr: %d frac: %lf\n", m->nr, frac);
+	for (int r = 0; r < m->nr; r++) {
+		gsl_vector_set(m->pca_evals_r, r, gsl_vector_get(evals, r));
+		for (int t = 0; t < nt; t++) gsl_matrix_set(m->pca_evecs_r, t, r, V[t * nt + ord[r]]);
+	}
+	/* Z = Ysub U_r diag(lambda_r^-1/2) */
+	m->pca_zmatrix = gsl_matrix_alloc(N, m->nr);
+	for (int j = 0; j < N; j++)
+		for (int r = 0; r < m->nr; r++) {
+			double s = 0.0;
+			for (int t = 0; t < nt; t++) s += ysub[j * nt + t] * gsl_matrix_get(m->pca_evecs_r, t, r);
+			gsl_matrix_set(m->pca_zmatrix, j, r, s * (1.0 / sqrt(gsl_vector_get(m->pca_evals_r, r))));
+		}
+	gsl_vector_free(evals);
+	free(ord); free(ysub); free(cov); free(w); free(V);
+}
+
+/* multi_modelstruct.c:121-146 */
+void gen_pca_model_array(multi_modelstruct *m)
+{
+	m->pca_model_array = (modelstruct **)malloc(sizeof(modelstruct *) * (size_t)m->nr);
+	for (int i = 0; i < m->nr; i++) {
+		gsl_vector *z = gsl_vector_alloc(m->nmodel_points);
+		for (int j = 0; j < m->nmodel_points; j++) gsl_vector_set(z, j, gsl_matrix_get(m->pca_zmatrix, j, i));
+		m->pca_model_array[i] = alloc_modelstruct_2(m->xmodel, z, m->cov_fn_index, m->regression_order);
+	}
+}
+
+/* multi_modelstruct.c:38-110 */
+multi_modelstruct *alloc_multimodelstruct(gsl_matrix *xmodel_in, gsl_matrix *training_matrix_in, int cov_fn_index,
+                                          int regression_order, double varfrac)
+{
+	assert(training_matrix_in->size1 == xmodel_in->size1);
+	assert(training_matrix_in->size1 > 0);
+	assert(training_matrix_in->size2 > 0);
+	assert(xmodel_in->size2 > 0);
+	if (regression_order < 0 || regression_order > 3) regression_order = 0;
+	if (varfrac < 0 || varfrac > 1) varfrac = 0.95;
+	if (cov_fn_index != MATERN32 && cov_fn_index != MATERN52) cov_fn_index = POWEREXPCOVFN;
+	multi_modelstruct *m = (multi_modelstruct *)malloc(sizeof(multi_modelstruct));
+	m->nt = (int)training_matrix_in->size2;
+	m->nr = 0;
+	m->nmodel_points = (int)xmodel_in->size1;
+	m->nparams = (int)xmodel_in->size2;
+	m->xmodel = xmodel_in;
+	m->training_matrix = training_matrix_in;
+	m->training_mean = gsl_vector_alloc(m->nt);
+	m->regression_order = regression_order;
+	m->cov_fn_index = cov_fn_index;
+	for (int i = 0; i < m->nt; i++) {
+		gsl_vector_view col = gsl_matrix_column(m->training_matrix, i);
+		gsl_vector_set(m->training_mean, i, vector_elt_sum(&col.vector, m->nmodel_points) / (double)m->nmodel_points);
+	}
+	gen_pca_decomp(m, varfrac);
+	gen_pca_model_array(m);
+	return m;
+}
+
+/* multi_modelstruct.c:346-401 */
+void dump_multi_modelstruct(FILE *fptr, multi_modelstruct *m)
+{
+	assert(fptr);
+	fprintf(fptr, "%d\n", m->nt);
+	fprintf(fptr, "%d\n", m->nr);
+	fprintf(fptr, "%d\n", m->nparams);
+	fprintf(fptr, "%d\n", m->nmodel_points);
+	fprintf(fptr, "%d\n", m->cov_fn_index);
+	fprintf(fptr, "%d\n", m->regression_order);
+	for (int i = 0; i < m->nmodel_points; i++) {
+		for (int j = 0; j < m->nparams; j++) fprintf(fptr, "%.17lf ", gsl_matrix_get(m->xmodel, i, j));
+		fprintf(fptr, "\n");
+	}
+	for (int i = 0; i < m->nmodel_points; i++) {
+		for (int j = 0; j < m->nt; j++) fprintf(fptr, "%.17lf ", gsl_matrix_get(m->training_matrix, i, j));
+		fprintf(fptr, "\n");
+	}
+	for (int i = 0; i < m->nr; i++) fprintf(fptr, "%.17lf ", gsl_vector_get(m->pca_evals_r, i));
+	fprintf(fptr, "\n");
+	for (int i = 0; i < m->nt; i++) {
+		for (int j = 0; j < m->nr; j++) fprintf(fptr, "%.17lf ", gsl_matrix_get(m->pca_evecs_r, i, j));
+		fprintf(fptr, "\n");
+	}
+	for (int i = 0; i < m->nmodel_points; i++) {
+		for (int j = 0; j < m->nr; j++) fprintf(fptr, "%.17lf ", gsl_matrix_get(m->pca_zmatrix, i, j));
+		fprintf(fptr, "\n");
+	}
+	for (int i = 0; i < m->nr; i++) dump_modelstruct_2(fptr, m->pca_model_array[i]);
+}
+
+static int rd_int(FILE *f) { int v = 0; if (fscanf(f, "%d%*c", &v) != 1) { fprintf(stderr, "snapshot: read error\n"); exit(EXIT_FAILURE); } return v; }
+static double rd_dbl(FILE *f) { double v = 0; if (fscanf(f, "%lf%*c", &v) != 1) { fprintf(stderr, "snapshot: read error\n"); exit(EXIT_FAILURE); } return v; }
+
+/* multi_modelstruct.c:406-472 */
+multi_modelstruct *load_multi_modelstruct(FILE *fptr)
+{
+	multi_modelstruct *m = (multi_modelstruct *)malloc(sizeof(multi_modelstruct));
+	m->nt = rd_int(fptr);
+	m->nr = rd_int(fptr);
+	m->nparams = rd_int(fptr);
+	m->nmodel_points = rd_int(fptr);
+	m->cov_fn_index = rd_int(fptr);
+	m->regression_order = rd_int(fptr);
+	const int N = m->nmodel_points, nt = m->nt, nr = m->nr, d = m->nparams;
+	m->xmodel = gsl_matrix_alloc(N, d);
+	m->training_matrix = gsl_matrix_alloc(N, nt);
+	m->training_mean = gsl_vector_alloc(nt);
+	m->pca_model_array = (modelstruct **)malloc(sizeof(modelstruct *) * (size_t)nr);
+	m->pca_evals_r = gsl_vector_alloc(nr);
+	m->pca_evecs_r = gsl_matrix_alloc(nt, nr);
+	m->pca_zmatrix = gsl_matrix_alloc(N, nr);
+	for (int i = 0; i < N; i++) for (int j = 0; j < d; j++) gsl_matrix_set(m->xmodel, i, j, rd_dbl(fptr));
+	for (int i = 0; i < N; i++) for (int j = 0; j < nt; j++) gsl_matrix_set(m->training_matrix, i, j, rd_dbl(fptr));
+	for (int i = 0; i < nr; i++) gsl_vector_set(m->pca_evals_r, i, rd_dbl(fptr));
+	for (int i = 0; i < nt; i++) for (int j = 0; j < nr; j++) gsl_matrix_set(m->pca_evecs_r, i, j, rd_dbl(fptr));
+	for (int i = 0; i < N; i++) for (int j = 0; j < nr; j++) gsl_matrix_set(m->pca_zmatrix, i, j, rd_dbl(fptr));
+	for (int i = 0; i < nr; i++) m->pca_model_array[i] = load_modelstruct_2(fptr);
+	for (int i = 0; i < nt; i++) {
+		gsl_vector_view col = gsl_matrix_column(m->training_matrix, i);
+		gsl_vector_set(m->training_mean, i, vector_elt_sum(&col.vector, N) / (double)N);
+	}
+	return m;
+}
+
+void free_multimodelstruct(multi_modelstruct *m)
+{
+	gsl_vector_free(m->training_mean);
+	for (int i = 0; i < m->nr; i++) {
+		gsl_vector_free(m->pca_model_array[i]->training_vector);
+		gsl_matrix_free(m->pca_model_array[i]->xmodel);
+		free_modelstruct_2(m->pca_model_array[i]);
+	}
+	free(m->pca_model_array);
+	gsl_matrix_free(m->xmodel);
+	gsl_matrix_free(m->training_matrix);
+	gsl_vector_free(m->pca_evals_r);
+	gsl_matrix_free(m->pca_evecs_r);
+	gsl_matrix_free(m->pca_zmatrix);
+	free(m);
+}
+
+/* multivar_support.c:20-28: the nr scalar GPs are independent; the reference trains them one after the other */
+void estimate_multi(multi_modelstruct *m, FILE *outfp)
+{
+	for (int i = 0; i < m->nr; i++)
+		estimate_thetas_threaded(m->pca_model_array[i], m->pca_model_array[i]->options);
+	dump_multi_modelstruct(outfp, m);
+}
+
+/* multivar_support.c:30-52 */
+multi_emulator *alloc_multi_emulator(multi_modelstruct *m)
+{
+	multi_emulator *e = (multi_emulator *)malloc(sizeof(multi_emulator));
+	e->nt = m->nt; e->nr = m->nr; e->nparams = m->nparams; e->nmodel_points = m->nmodel_points;
+	e->nregression_fns = m->pca_model_array[0]->options->nregression_fns;
+	e->nthetas = m->pca_model_array[0]->options->nthetas;
+	e->model = m;
+	e->emu_struct_array = (emulator_struct **)malloc(sizeof(emulator_struct *) * (size_t)e->nr);
+	for (int i = 0; i < e->nr; i++) e->emu_struct_array[i] = alloc_emulator_struct(m->pca_model_array[i]);
+	return e;
+}
+
+void free_multi_emulator(multi_emulator *e)
+{
+	for (int i = 0; i < e->nr; i++) free_emulator_struct(e->emu_struct_array[i]);
+	free(e->emu_struct_array);
+	free_multimodelstruct(e->model);
+	free(e);
+}
+
+/* npoints x nr PCA-space results -> npoints x nt observable-space results (multivar_support.c:126-151) */
+static void backproject(const multi_emulator *emu, int npoints, const double *mp, const double *vp, double *mean_out, double *var_out)
+{
+	const int nt = emu->nt, nr = emu->nr;
+	const multi_modelstruct *m = emu->model;
+	for (int q = 0; q < npoints; q++)
+		for (int i = 0; i < nt; i++) {
+			double ms = 0.0, vs = 0.0;
+			for (int j = 0; j < nr; j++) {
+				const double u = gsl_matrix_get(m->pca_evecs_r, i, j), lam = gsl_vector_get(m->pca_evals_r, j);
+				ms += u * sqrt(lam) * mp[(size_t)q * nr + j];
+				vs += pow(u, 2.0) * lam * vp[(size_t)q * nr + j];
+			}
+			mean_out[(size_t)q * nt + i] = gsl_vector_get(m->training_mean, i) + ms;
+			var_out[(size_t)q * nt + i] = vs;
+		}
+}
+
+void emulate_points_multi(multi_emulator *emu, gsl_matrix *points, int pca_space, double *mean_out, double *var_out)
+{
+	const int np = (int)points->size1, nr = emu->nr;
+	double *mp = (double *)malloc(sizeof(double) * (size_t)np * nr), *vp = (double *)malloc(sizeof(double) * (size_t)np * nr);
+	double *mc = (double *)malloc(sizeof(double) * (size_t)np), *vc = (double *)malloc(sizeof(double) * (size_t)np);
+	for (int c = 0; c < nr; c++) {
+		emulate_points(emu->emu_struct_array[c], points, mc, vc);
+		for (int q = 0; q < np; q++) { mp[(size_t)q * nr + c] = mc[q]; vp[(size_t)q * nr + c] = vc[q]; }
+	}
+	if (pca_space) {
+		memcpy(mean_out, mp, sizeof(double) * (size_t)np * nr);
+		memcpy(var_out, vp, sizeof(double) * (size_t)np * nr);
+	} else {
+		backproject(emu, np, mp, vp, mean_out, var_out);
+	}
+	free(mp); free(vp); free(mc); free(vc);
+}
+
+static void one_point(multi_emulator *emu, gsl_vector *the_point, gsl_vector *the_mean, gsl_vector *the_variance, int pca_space)
+{
+	gsl_matrix view;
+	const int n = pca_space ? emu->nr : emu->nt;
+	double *q = (double *)malloc(sizeof(double) * the_point->size);
+	double *mo = (double *)malloc(sizeof(double) * (size_t)n), *vo = (double *)malloc(sizeof(double) * (size_t)n);
+	for (size_t i = 0; i < the_point->size; i++) q[i] = gsl_vector_get(the_point, i);
+	view.size1 = 1; view.size2 = the_point->size; view.tda = the_point->size; view.data = q; view.block = NULL; view.owner = 0;
+	emulate_points_multi(emu, &view, pca_space, mo, vo);
+	for (int i = 0; i < n; i++) { gsl_vector_set(the_mean, i, mo[i]); gsl_vector_set(the_variance, i, vo[i]); }
+	free(q); free(mo); free(vo);
+}
+
+/* multivar_support.c:78-86 */
+void emulate_point_multi_pca(multi_emulator *emu, gsl_vector *the_point, gsl_vector *the_mean, gsl_vector *the_variance)
+{
+	one_point(emu, the_point, the_mean, the_variance, 1);
+}
+
+/* multivar_support.c:103-157 */
+void emulate_point_multi(multi_emulator *emu, gsl_vector *the_point, gsl_vector *the_mean, gsl_vector *the_variance)
+{
+	one_point(emu, the_point, the_mean, the_variance, 0);
+}

@@ -1,0 +1,348 @@
+/*
+ * optimizer.c -- the search driver above the device likelihood: random restarts + a BFGS
+ * minimiser of -logL (libEmu/maxmultimin.c:47-136, 633-807; libEmu/estimate_threaded.c:78-334).
+ *
+ * gsl_multimin's vector_bfgs2 is not available (no GSL): the minimiser below is a textbook
+ * BFGS with a strong-Wolfe bracketing/zoom line search (Nocedal & Wright alg. 3.5/3.6, cubic
+ * interpolation), driven with the reference's constants: first step 1.5, line-search
+ * sigma 0.5 (rho 0.01), stop at |g| < 0.1 or after 30 iterations, "no progress" ends a run.
+ * Trajectories are not comparable with GSL's (the reference seeds from /dev/urandom anyway).
+ * Every function/gradient pair is ONE device call (evalFnGradMulti shares the factorisation).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <unistd.h>
+#include <pthread.h>
+#include <sys/time.h>
+#include "libemu.h"
+
+#define SCREWUPVALUE -2000
+#define SCREWUPVALUE_T -20000
+
+static unsigned long g_seed = 0;
+static int g_nthreads = 0, g_restarts = 50;
+void gpemu_host_set_seed(unsigned long seed) { g_seed = seed; }
+void gpemu_host_set_search(int nthreads, int restarts_per_job)
+{
+	if (nthreads > 0) g_nthreads = nthreads;
+	if (restarts_per_job > 0) g_restarts = restarts_per_job;
+}
+
+/* libEmu/maxmultimin.c:789-804 */
+void set_random_init_value(gsl_rng *rand, gsl_vector *x, gsl_matrix *ranges, int nthetas)
+{
+	for (int i = 0; i < nthetas; i++) {
+		const double lo = gsl_matrix_get(ranges, i, 0), hi = gsl_matrix_get(ranges, i, 1);
+		gsl_vector_set(x, i, gsl_rng_uniform(rand) * (hi - lo) + lo);
+	}
+}
+
+/* ------------------------------------------------------------------ BFGS */
+struct fdf {
+	void (*fdf)(const gsl_vector *, void *, double *, gsl_vector *);
+	void *args;
+	int n;
+	int nevals;
+};
+
+static double dot(const double *a, const double *b, int n) { double s = 0; for (int i = 0; i < n; i++) s += a[i] * b[i]; return s; }
+
+/* phi(alpha) = f(x + alpha p), dphi = g(x + alpha p).p ; NaN/inf values are reported as +inf so the search backs off */
+static double phi(struct fdf *F, const double *x, const double *p, double alpha, double *gout, double *dphi, gsl_vector *xt, gsl_vector *gt)
+{
+	double f;
+	for (int i = 0; i < F->n; i++) gsl_vector_set(xt, i, x[i] + alpha * p[i]);
+	F->fdf(xt, F->args, &f, gt);
+	F->nevals++;
+	for (int i = 0; i < F->n; i++) gout[i] = gsl_vector_get(gt, i);
+	*dphi = dot(gout, p, F->n);
+	if (isnan(f) || isinf(f)) { f = INFINITY; *dphi = INFINITY; }
+	return f;
+}
+
+static double cubic_min(double a, double fa, double da, double b, double fb, double db)
+{
+	/* minimiser of the cubic through (a,fa,da),(b,fb,db); falls back to bisection */
+	const double d1 = da + db - 3.0 * (fa - fb) / (a - b);
+	const double rad = d1 * d1 - da * db;
+	if (!(rad >= 0.0) || isinf(fb) || isinf(db)) return 0.5 * (a + b);
+	const double d2 = (b > a ? 1.0 : -1.0) * sqrt(rad);
+	double t = b - (b - a) * (db + d2 - d1) / (db - da + 2.0 * d2);
+	const double lo = fmin(a, b), hi = fmax(a, b), w = hi - lo;
+	if (!(t > lo + 0.1 * w && t < hi - 0.1 * w)) t = 0.5 * (a + b);
+	return t;
+}
+
+/* strong Wolfe line search; returns 0 and (alpha,f,g) on success, 1 if no acceptable step was found */
+static int line_search(struct fdf *F, const double *x, double f0, const double *g0, const double *p, double alpha1,
+                       double rho, double sigma, double *alpha_out, double *f_out, double *g_out, gsl_vector *xt, gsl_vector *gt)
+{
+	const int n = F->n;
+	const double d0 = dot(g0, p, n);
+	if (!(d0 < 0.0)) return 1;
+	double a_prev = 0.0, f_prev = f0, d_prev = d0;
+	double a = alpha1, fa, da;
+	double lo = 0, flo = f0, dlo = d0, hi = 0, fhi = 0, dhi = 0;
+	int bracketed = 0;
+	double *g = (double *)malloc(sizeof(double) * (size_t)n);
+	for (int it = 0; it < 12 && !bracketed; it++) {
+		fa = phi(F, x, p, a, g, &da, xt, gt);
+		if (fa > f0 + rho * a * d0 || (it > 0 && fa >= f_prev)) {
+			lo = a_prev; flo = f_prev; dlo = d_prev; hi = a; fhi = fa; dhi = da; bracketed = 1; break;
+		}
+		if (fabs(da) <= -sigma * d0) { *alpha_out = a; *f_out = fa; memcpy(g_out, g, sizeof(double) * (size_t)n); free(g); return 0; }
+		if (da >= 0.0) { lo = a; flo = fa; dlo = da; hi = a_prev; fhi = f_prev; dhi = d_prev; bracketed = 1; break; }
+		a_prev = a; f_prev = fa; d_prev = da;
+		a *= 2.5;
+	}
+	if (!bracketed) { free(g); return 1; }
+	for (int it = 0; it < 16; it++) {
+		a = cubic_min(lo, flo, dlo, hi, fhi, dhi);
+		fa = phi(F, x, p, a, g, &da, xt, gt);
+		if (fa > f0 + rho * a * d0 || fa >= flo) {
+			hi = a; fhi = fa; dhi = da;
+		} else {
+			if (fabs(da) <= -sigma * d0) { *alpha_out = a; *f_out = fa; memcpy(g_out, g, sizeof(double) * (size_t)n); free(g); return 0; }
+			if (da * (hi - lo) >= 0.0) { hi = lo; fhi = flo; dhi = dlo; }
+			lo = a; flo = fa; dlo = da;
+		}
+		if (fabs(hi - lo) < 1e-10 * fmax(1.0, fabs(lo))) break;
+	}
+	/* accept the best sufficient-decrease point seen, if any */
+	if (lo > 0.0 && flo < f0) {
+		fa = phi(F, x, p, lo, g, &da, xt, gt);
+		*alpha_out = lo; *f_out = fa; memcpy(g_out, g, sizeof(double) * (size_t)n);
+		free(g);
+		return (fa < f0) ? 0 : 1;
+	}
+	free(g);
+	return 1;
+}
+
+/* libEmu/maxmultimin.c:633-778 */
+int doOptimizeMultiMin(double (*fn)(const gsl_vector *, void *),
+                       void (*gradientFn)(const gsl_vector *, void *, gsl_vector *),
+                       void (*fnGradFn)(const gsl_vector *, void *, double *, gsl_vector *),
+                       gsl_vector *thetaInit, gsl_vector *thetaFinal, void *args)
+{
+	(void)fn; (void)gradientFn;
+	struct estimate_thetas_params *params = (struct estimate_thetas_params *)args;
+	const int nthetas = params->options->nthetas;
+	const int n = nthetas - 1;                 /* the amplitude is set by the data (estimateSigma) */
+	const int stepmax = 30;
+	const double stepSizeInit = 1.5, tolerance = 0.5, epsAbs = 0.1;
+	int status = GSL_CONTINUE, stepcount = 0;
+
+	struct fdf F = {fnGradFn, args, n, 0};
+	double *x = (double *)malloc(sizeof(double) * (size_t)n), *g = (double *)malloc(sizeof(double) * (size_t)n);
+	double *p = (double *)malloc(sizeof(double) * (size_t)n), *gn = (double *)malloc(sizeof(double) * (size_t)n);
+	double *s = (double *)malloc(sizeof(double) * (size_t)n), *yv = (double *)malloc(sizeof(double) * (size_t)n);
+	double *Hy = (double *)malloc(sizeof(double) * (size_t)n);
+	double *H = (double *)calloc((size_t)n * n, sizeof(double));
+	gsl_vector *xt = gsl_vector_alloc(n), *gt = gsl_vector_alloc(n);
+	for (int i = 0; i < n; i++) { x[i] = gsl_vector_get(thetaInit, i + 1); H[i * n + i] = 1.0; }
+
+	double f, dd;
+	{
+		double zero_p[64] = {0};
+		double *zp = (n <= 64) ? zero_p : (double *)calloc((size_t)n, sizeof(double));
+		f = phi(&F, x, zp, 0.0, g, &dd, xt, gt);
+		if (zp != zero_p) free(zp);
+	}
+	if (isinf(f)) status = GSL_ENOPROG;
+	while (status == GSL_CONTINUE && stepcount < stepmax) {
+		const double gnorm = sqrt(dot(g, g, n));
+		if (gnorm < epsAbs) { status = GSL_SUCCESS; break; }
+		for (int i = 0; i < n; i++) { double t = 0; for (int j = 0; j < n; j++) t -= H[i * n + j] * g[j]; p[i] = t; }
+		double alpha1 = 1.0;
+		if (stepcount == 0) { const double pn = sqrt(dot(p, p, n)); alpha1 = stepSizeInit / (pn > 0 ? pn : 1.0); }
+		if (!(dot(g, p, n) < 0.0)) {            /* not a descent direction: reset to steepest descent */
+			memset(H, 0, sizeof(double) * (size_t)n * n);
+			for (int i = 0; i < n; i++) { H[i * n + i] = 1.0; p[i] = -g[i]; }
+			alpha1 = stepSizeInit / (gnorm > 0 ? gnorm : 1.0);
+		}
+		double alpha, fnew;
+		if (line_search(&F, x, f, g, p, alpha1, 0.01, tolerance, &alpha, &fnew, gn, xt, gt)) {
+			status = GSL_ENOPROG;               /* maxmultimin.c:703-707: no progress ends the run */
+			break;
+		}
+		for (int i = 0; i < n; i++) { s[i] = alpha * p[i]; yv[i] = gn[i] - g[i]; x[i] += s[i]; g[i] = gn[i]; }
+		f = fnew;
+		const double sy = dot(s, yv, n);
+		if (sy > 1e-12 * sqrt(dot(s, s, n) * dot(yv, yv, n))) {
+			/* H <- (I - s y^T/sy) H (I - y s^T/sy) + s s^T/sy */
+			for (int i = 0; i < n; i++) { double t = 0; for (int j = 0; j < n; j++) t += H[i * n + j] * yv[j]; Hy[i] = t; }
+			const double yHy = dot(yv, Hy, n);
+			for (int i = 0; i < n; i++)
+				for (int j = 0; j < n; j++)
+					H[i * n + j] += (1.0 + yHy / sy) * s[i] * s[j] / sy - (Hy[i] * s[j] + s[i] * Hy[j]) / sy;
+		}
+		stepcount++;
+	}
+	if (status == GSL_CONTINUE && sqrt(dot(g, g, n)) < epsAbs) status = GSL_SUCCESS;
+	if (stepcount == stepmax) fprintf(stderr, "# (error) multimin: no converge at stepmax %d\n", stepmax);
+
+	for (int i = 0; i < n; i++) gsl_vector_set(xt, i, x[i]);
+	const double sigma_final = log(estimateSigmaFull(xt, args));       /* maxmultimin.c:757 */
+	gsl_vector_set(thetaFinal, 0, sigma_final);
+	for (int i = 0; i < n; i++) gsl_vector_set(thetaFinal, i + 1, x[i]);
+	free(x); free(g); free(p); free(gn); free(s); free(yv); free(Hy); free(H);
+	gsl_vector_free(xt); gsl_vector_free(gt);
+	return status;
+}
+
+/* libEmu/maxmultimin.c:47-136 */
+void maxWithMultiMin(struct estimate_thetas_params *params)
+{
+	const int nthetas = params->options->nthetas;
+	const int N = params->options->nmodel_points, d = params->options->nparams, nreg = params->options->nregression_fns;
+	int tries = 0, success_count = 0;
+	double bestLHood = SCREWUPVALUE;
+	gsl_vector *xInit = gsl_vector_alloc(nthetas), *xFinal = gsl_vector_calloc(nthetas);
+	gsl_vector *xBest = gsl_vector_calloc(nthetas), *xTest = gsl_vector_alloc(nthetas - 1);
+
+	params->h_matrix = gsl_matrix_alloc(N, nreg);                       /* left for the caller to free (:75) */
+	makeHMatrix_fnptr(params->h_matrix, params->the_model->xmodel, N, d, nreg, params->the_model->makeHVector);
+
+	while (tries < params->max_tries) {
+		set_random_init_value(params->random_number, xInit, params->options->grad_ranges, nthetas);
+		const int status = doOptimizeMultiMin(&evalFnMulti, &gradFnMulti, &evalFnGradMulti, xInit, xFinal, params);
+		if (status == GSL_SUCCESS) success_count++;
+		for (int i = 0; i < nthetas - 1; i++) gsl_vector_set(xTest, i, gsl_vector_get(xFinal, i + 1));
+		const double likelihood = -1 * evalFnMulti(xTest, params);
+		if (likelihood > bestLHood && (isnan(likelihood) == 0 && isinf(likelihood) == 0)) {
+			bestLHood = likelihood;
+			gsl_vector_memcpy(xBest, xFinal);
+		}
+		tries++;
+		gsl_vector_set_zero(xFinal);
+	}
+	if (bestLHood == SCREWUPVALUE) fprintf(stderr, "maximisation didn't work at all, relax your ranges\n");
+	gsl_vector_memcpy(params->the_model->thetas, xBest);
+	params->lhood_current = bestLHood;
+	params->success_count = success_count;
+	gsl_vector_free(xInit); gsl_vector_free(xFinal); gsl_vector_free(xBest); gsl_vector_free(xTest);
+}
+
+/* ------------------------------------------------------------------ restart pool */
+int get_number_cpus(void)
+{
+	long n = sysconf(_SC_NPROCESSORS_ONLN);
+	if (n < 1) n = 1;
+	printf("# NCPUS: %ld\n", n);
+	return (int)n;
+}
+
+static unsigned long seed_noblock(void)
+{
+	unsigned long seed = 0;
+	FILE *f = fopen("/dev/urandom", "r");
+	if (f) { if (fread(&seed, sizeof seed, 1, f) != 1) seed = 0; fclose(f); }
+	if (!seed) { struct timeval tv; gettimeofday(&tv, 0); seed = (unsigned long)(tv.tv_sec + tv.tv_usec); }
+	return seed;
+}
+
+struct pool {
+	pthread_mutex_t job_lock, result_lock;
+	int ntries, jobnumber;
+	gsl_vector *best_thetas;
+	double best_likelyhood_val;
+};
+
+struct worker { struct pool *pool; struct estimate_thetas_params params; int id; };
+
+static void *worker_main(void *arg)
+{
+	struct worker *w = (struct worker *)arg;
+	struct pool *P = w->pool;
+	for (;;) {
+		int job;
+		pthread_mutex_lock(&P->job_lock);
+		job = (P->jobnumber == P->ntries) ? -1 : P->jobnumber++;
+		pthread_mutex_unlock(&P->job_lock);
+		if (job < 0) break;
+		if (w->params.h_matrix) { gsl_matrix_free(w->params.h_matrix); w->params.h_matrix = NULL; }
+		maxWithMultiMin(&w->params);
+		const double val = w->params.lhood_current;
+		if (val > w->params.my_best) w->params.my_best = val;
+		pthread_mutex_lock(&P->result_lock);
+		if (val > P->best_likelyhood_val) {
+			gsl_vector_memcpy(P->best_thetas, w->params.the_model->thetas);
+			P->best_likelyhood_val = val;
+			printf("# worker %d won with %g\n", w->id, val);
+		}
+		pthread_mutex_unlock(&P->result_lock);
+	}
+	return NULL;
+}
+
+/* libEmu/estimate_threaded.c:78-237.  The reference starts one pthread per CPU, each running jobs of 50 restarts
+ * on its own copy of the model.  Here a worker is a host thread with its own device context (HIP stream + HBM
+ * workspace); the default is one worker (the GPU serialises the N^3 work anyway), GPEMU_NTHREADS / GPEMU_JOBS /
+ * gpemu_host_set_search change it; jobs default to the worker count as in the reference (:101-103). */
+void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
+{
+	int nthreads = g_nthreads > 0 ? g_nthreads : 1;
+	const char *env = getenv("GPEMU_NTHREADS");
+	if (env && atoi(env) > 0) nthreads = atoi(env);
+	int njobs = nthreads;
+	env = getenv("GPEMU_JOBS");
+	if (env && atoi(env) > 0) njobs = atoi(env);
+	if (njobs < nthreads) njobs = nthreads;
+	int restarts = g_restarts;
+	env = getenv("GPEMU_RESTARTS");
+	if (env && atoi(env) > 0) restarts = atoi(env);
+	unsigned long seed = g_seed;
+	env = getenv("GPEMU_SEED");
+	if (env && atol(env) > 0) seed = (unsigned long)atol(env);
+
+	struct pool P;
+	pthread_mutex_init(&P.job_lock, NULL);
+	pthread_mutex_init(&P.result_lock, NULL);
+	P.ntries = njobs; P.jobnumber = 0;
+	P.best_thetas = gsl_vector_calloc(options->nthetas);
+	P.best_likelyhood_val = SCREWUPVALUE_T;
+
+	struct worker *W = (struct worker *)calloc((size_t)nthreads, sizeof *W);
+	pthread_t *tid = (pthread_t *)calloc((size_t)nthreads, sizeof *tid);
+	for (int i = 0; i < nthreads; i++) {
+		W[i].pool = &P; W[i].id = i;
+		/* private modelstruct: own thetas; design / training data are read-only and shared */
+		modelstruct *m = (modelstruct *)malloc(sizeof(modelstruct));
+		*m = *the_model;
+		m->thetas = gsl_vector_calloc(options->nthetas);
+		W[i].params.the_model = m;
+		W[i].params.options = options;
+		W[i].params.max_tries = restarts;
+		W[i].params.my_best = SCREWUPVALUE_T;
+		W[i].params.h_matrix = NULL;
+		W[i].params.random_number = gsl_rng_alloc(gsl_rng_default);
+		gsl_rng_set(W[i].params.random_number, seed ? seed + 7919UL * (unsigned long)i : seed_noblock());
+	}
+	for (int i = 0; i < nthreads; i++)
+		if (pthread_create(&tid[i], NULL, worker_main, &W[i])) { perror("pthread_create"); exit(EXIT_FAILURE); }
+	for (int i = 0; i < nthreads; i++)
+		if (pthread_join(tid[i], NULL)) { perror("pthread_join"); exit(EXIT_FAILURE); }
+
+	printf("-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=\n");
+	for (int i = 0; i < nthreads; i++) {
+		printf("thread(%d)\tlog-L: %lf\tthetas:", i, W[i].params.my_best);
+		for (int j = 0; j < options->nthetas; j++) printf("%lf ", exp(gsl_vector_get(W[i].params.the_model->thetas, j)));
+		printf("\n");
+	}
+	printf("-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=\n");
+	for (int i = 0; i < nthreads; i++) {
+		gpemu_host_release(&W[i].params);
+		gsl_rng_free(W[i].params.random_number);
+		if (W[i].params.h_matrix) gsl_matrix_free(W[i].params.h_matrix);
+		gsl_vector_free(W[i].params.the_model->thetas);
+		free(W[i].params.the_model);
+	}
+	gsl_vector_memcpy(the_model->thetas, P.best_thetas);
+	gsl_vector_free(P.best_thetas);
+	pthread_mutex_destroy(&P.job_lock);
+	pthread_mutex_destroy(&P.result_lock);
+	free(W); free(tid);
+}

@@ -1,0 +1,125 @@
+/* Drives the host-side libEmu mirror (csrc/host/libemu.h) the way the reference's own callers do
+ * (gsl_multimin callbacks on an estimate_thetas_params; alloc_emulator_struct + emulate_point) and prints
+ * the results for tests/test_host_api.py to compare with the oracle.
+ *
+ *   host_api_driver eval  INPUT_MODEL_FILE cov_fn order theta_less_amp...
+ *   host_api_driver emu   INPUT_MODEL_FILE cov_fn order QUERY_FILE theta_full...
+ *   host_api_driver roundtrip SNAPSHOT_IN SNAPSHOT_OUT
+ *   host_api_driver multi SNAPSHOT QUERY_FILE
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "libemu.h"
+
+static int read_model(const char *name, gsl_matrix **x, gsl_matrix **y)
+{
+	FILE *in = fopen(name, "r");
+	int nt, d, n;
+	if (!in || fscanf(in, "%d %d %d", &nt, &d, &n) != 3) return 0;
+	*x = gsl_matrix_alloc(n, d);
+	*y = gsl_matrix_alloc(n, nt);
+	for (int i = 0; i < n; i++) for (int j = 0; j < d; j++) if (fscanf(in, "%lf", gsl_matrix_ptr(*x, i, j)) != 1) return 0;
+	for (int i = 0; i < n; i++) for (int j = 0; j < nt; j++) if (fscanf(in, "%lf", gsl_matrix_ptr(*y, i, j)) != 1) return 0;
+	fclose(in);
+	return 1;
+}
+
+static gsl_matrix *read_queries(const char *name, int d)
+{
+	FILE *in = fopen(name, "r");
+	double v, *buf = NULL;
+	size_t n = 0, cap = 0;
+	while (in && fscanf(in, "%lf", &v) == 1) {
+		if (n == cap) { cap = cap ? 2 * cap : 1024; buf = (double *)realloc(buf, cap * sizeof(double)); }
+		buf[n++] = v;
+	}
+	if (in) fclose(in);
+	gsl_matrix *q = gsl_matrix_alloc(n / d, d);
+	memcpy(q->data, buf, (n / d) * d * sizeof(double));
+	free(buf);
+	return q;
+}
+
+int main(int argc, char **argv)
+{
+	if (argc < 3) return 2;
+	if (!strcmp(argv[1], "roundtrip")) {
+		FILE *in = fopen(argv[2], "r");
+		multi_modelstruct *m = load_multi_modelstruct(in);
+		fclose(in);
+		FILE *out = fopen(argv[3], "w");
+		dump_multi_modelstruct(out, m);
+		fclose(out);
+		printf("nt %d nr %d N %d d %d\n", m->nt, m->nr, m->nmodel_points, m->nparams);
+		return 0;
+	}
+	if (!strcmp(argv[1], "multi")) {
+		FILE *in = fopen(argv[2], "r");
+		multi_modelstruct *m = load_multi_modelstruct(in);
+		fclose(in);
+		multi_emulator *e = alloc_multi_emulator(m);
+		gsl_matrix *q = read_queries(argv[3], m->nparams);
+		gsl_vector *mean = gsl_vector_alloc(m->nt), *var = gsl_vector_alloc(m->nt), *pt = gsl_vector_alloc(m->nparams);
+		for (size_t i = 0; i < q->size1; i++) {
+			for (int k = 0; k < m->nparams; k++) gsl_vector_set(pt, k, gsl_matrix_get(q, i, k));
+			emulate_point_multi(e, pt, mean, var);
+			printf("pred");
+			for (int t = 0; t < m->nt; t++) printf(" %.17g %.17g", gsl_vector_get(mean, t), gsl_vector_get(var, t));
+			printf("\n");
+		}
+		return 0;
+	}
+	gsl_matrix *x, *ymat;
+	if (!read_model(argv[2], &x, &ymat)) return 3;
+	const int cov = atoi(argv[3]), order = atoi(argv[4]);
+	gsl_vector *y = gsl_vector_alloc(x->size1);
+	for (size_t i = 0; i < x->size1; i++) gsl_vector_set(y, i, gsl_matrix_get(ymat, i, 0));
+	modelstruct *model = alloc_modelstruct_2(x, y, cov, order);
+	const int nthetas = model->options->nthetas;
+
+	if (!strcmp(argv[1], "eval")) {
+		struct estimate_thetas_params params;
+		memset(&params, 0, sizeof params);
+		params.options = model->options;
+		params.the_model = model;
+		gsl_vector *th = gsl_vector_alloc(nthetas - 1), *g = gsl_vector_alloc(nthetas - 1), *g2 = gsl_vector_alloc(nthetas - 1);
+		for (int i = 0; i < nthetas - 1; i++) gsl_vector_set(th, i, atof(argv[5 + i]));
+		const double f = evalFnMulti(th, &params);
+		printf("evalFnMulti %.17g\n", f);
+		printf("estimateSigmaFull %.17g\n", estimateSigmaFull(th, &params));
+		if (cov == POWEREXPCOVFN) {
+			gradFnMulti(th, &params, g);
+			printf("gradFnMulti");
+			for (int i = 0; i < nthetas - 1; i++) printf(" %.17g", gsl_vector_get(g, i));
+			printf("\n");
+			double f2;
+			evalFnGradMulti(th, &params, &f2, g2);
+			printf("evalFnGradMulti %.17g", f2);
+			for (int i = 0; i < nthetas - 1; i++) printf(" %.17g", gsl_vector_get(g2, i));
+			printf("\n");
+		}
+		gpemu_host_release(&params);
+	} else if (!strcmp(argv[1], "emu")) {
+		gsl_matrix *q = read_queries(argv[5], (int)x->size2);
+		for (int i = 0; i < nthetas; i++) gsl_vector_set(model->thetas, i, atof(argv[6 + i]));
+		emulator_struct *e = alloc_emulator_struct(model);
+		printf("beta");
+		for (int a = 0; a < e->nregression_fns; a++) printf(" %.17g", gsl_vector_get(e->beta_vector, a));
+		printf("\n");
+		printf("cinverse00 %.17g %.17g\n", gsl_matrix_get(e->cinverse, 0, 0),
+		       gsl_matrix_get(e->cinverse, e->nmodel_points - 1, 0));
+		gsl_vector *pt = gsl_vector_alloc(x->size2);
+		for (size_t i = 0; i < q->size1; i++) {
+			double m, v;
+			for (size_t k = 0; k < x->size2; k++) gsl_vector_set(pt, k, gsl_matrix_get(q, i, k));
+			emulate_point(e, pt, &m, &v);
+			printf("pred %.17g %.17g\n", m, v);
+		}
+		double *mm = (double *)malloc(sizeof(double) * q->size1), *vv = (double *)malloc(sizeof(double) * q->size1);
+		emulate_points(e, q, mm, vv);
+		for (size_t i = 0; i < q->size1; i++) printf("batch %.17g %.17g\n", mm[i], vv[i]);
+		free_emulator_struct(e);
+	}
+	return 0;
+}

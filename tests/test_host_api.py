@@ -1,0 +1,206 @@
+"""The C host layer (csrc/host, libEmuMI.so) that mirrors the reference's libEmu interface and the
+interactive_emulator CLI, driven the way the reference's callers drive them; results checked against the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from madaiemulator_amd import build, synth
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INP = os.path.join(ROOT, "tests", "golden", "ref_inputs")
+UNI = os.path.join(INP, "uni-simple.input_model_file.dat")
+TWOD = os.path.join(INP, "uni-2d-param.input_model_file.dat")
+MULTI = os.path.join(INP, "multi-simple.input_model_file.dat")
+RTOL = 1e-8
+
+
+@pytest.fixture(scope="module")
+def driver(tmp_path_factory):
+    build.build_all()
+    exe = str(tmp_path_factory.mktemp("drv") / "host_api_driver")
+    subprocess.check_call(["gcc", "-std=gnu99", "-O1", "-I", os.path.join(ROOT, "include"), "-I", build.HOST_SRC,
+                           "-o", exe, os.path.join(ROOT, "tests", "c", "host_api_driver.c"),
+                           "-L", build.LIBDIR, "-lEmuMI", "-lgpemu_hip", f"-Wl,-rpath,{build.LIBDIR}", "-lm"])
+    return exe
+
+
+def run(cmd, **kw):
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, **kw)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return out.stdout
+
+
+def parse(stdout):
+    res = {}
+    for line in stdout.splitlines():
+        if line.startswith("#") or not line.strip():
+            continue
+        k, *vals = line.split()
+        try:
+            res.setdefault(k, []).append([float(v) for v in vals])
+        except ValueError:
+            pass
+    return res
+
+
+def test_host_library_exports_reference_symbols():
+    import ctypes
+    build.build_all()
+    lib = ctypes.CDLL(build.HIP_LIB, mode=ctypes.RTLD_GLOBAL)
+    lib = ctypes.CDLL(build.HOST_LIB)
+    for name in ("evalFnMulti", "gradFnMulti", "evalFnGradMulti", "estimateSigmaFull", "maxWithMultiMin",
+                 "doOptimizeMultiMin", "set_random_init_value", "estimate_thetas_threaded", "alloc_modelstruct_2",
+                 "free_modelstruct_2", "dump_modelstruct_2", "load_modelstruct_2", "set_global_ptrs",
+                 "fill_sample_scales_vec", "setup_optimization_ranges", "alloc_emulator_struct", "free_emulator_struct",
+                 "emulate_point", "makeCovMatrix_fnptr", "makeKVector_fnptr", "makeHMatrix_fnptr", "makeHVector_linear",
+                 "covariance_fn_gaussian", "covariance_fn_matern_three", "covariance_fn_matern_five",
+                 "alloc_multimodelstruct", "gen_pca_decomp", "dump_multi_modelstruct", "load_multi_modelstruct",
+                 "alloc_multi_emulator", "emulate_point_multi", "emulate_point_multi_pca", "estimate_multi"):
+        assert hasattr(lib, name), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path,d,order", [(UNI, 1, 0), (UNI, 1, 1), (TWOD, 2, 1)])
+def test_evalfn_gradfn_like_gsl_multimin_would_call_them(driver, path, d, order):
+    X, Y = synth.read_input_model_file(path)
+    y = Y[:, 0]
+    th = np.array([-3.0] + [-0.4 - 0.3 * k for k in range(d)])
+    res = parse(run([driver, "eval", path, "1", str(order)] + [repr(float(t)) for t in th]))
+    o = O.eval_fn_multi(1, order, X, y, th)
+    g, _ = O.grad_fn_multi(1, order, X, y, th)
+    assert res["evalFnMulti"][0][0] == pytest.approx(o["value"], rel=RTOL)
+    assert res["estimateSigmaFull"][0][0] == pytest.approx(o["sigma2"], rel=RTOL)
+    assert np.allclose(res["gradFnMulti"][0], g, rtol=1e-7, atol=1e-7 * np.abs(g).max())
+    assert res["evalFnGradMulti"][0][0] == pytest.approx(o["value"], rel=RTOL)
+    assert np.allclose(res["evalFnGradMulti"][0][1:], g, rtol=1e-7, atol=1e-7 * np.abs(g).max())
+
+
+@pytest.mark.gpu
+def test_evalfn_matern_returns_nan_like_the_reference(driver):
+    # amp is zeroed by evalFnMulti and read raw by the Matern kernels -> C = theta_1 I with theta_1 < 0 -> GSL_NAN
+    out = subprocess.run([driver, "eval", UNI, "2", "0", "-3.0", "0.0"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0
+    assert "evalfnmulti nan" in out.stdout.lower()
+    assert "non postive def" in out.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cov,order", [(1, 0), (1, 1), (3, 1), (2, 0)])
+def test_emulator_struct_and_emulate_point(driver, tmp_path, cov, order):
+    X, Y = synth.read_input_model_file(TWOD)
+    y = Y[:, 0]
+    th = np.array([-0.2, -3.5, -1.0, -0.7]) if cov == 1 else np.array([1.3, 0.02, np.log(0.8)])
+    Q = np.vstack([synth.queries(40, 2, 3), X[:2]])
+    qf = tmp_path / "q.dat"
+    np.savetxt(qf, Q, fmt="%.17g")
+    res = parse(run([driver, "emu", TWOD, str(cov), str(order), str(qf)] + [repr(float(t)) for t in th]))
+    e = O.Emulator(cov, order, X, y, th)
+    m, v, _ = e.emulate(Q)
+    kappa = O.cov(cov, Q[0], Q[0], th)
+    pred = np.array(res["pred"])
+    batch = np.array(res["batch"])
+    assert np.allclose(res["beta"][0], e.beta, rtol=RTOL)
+    assert np.max(np.abs(pred[:, 0] - m)) <= RTOL * max(1.0, np.abs(m).max())
+    assert np.max(np.abs(pred[:, 1] - v)) <= RTOL * kappa
+    assert np.array_equal(pred, batch)                      # one point at a time == one batch
+    assert res["cinverse00"][0][0] == pytest.approx(e.cinverse[0, 0], rel=RTOL)
+
+
+@pytest.mark.gpu
+def test_cli_train_snapshot_predict_end_to_end(driver, tmp_path):
+    """test/uni-simple of the reference: estimate_thetas --regression_order=1, then interactive_mode on its
+    sample locations (BASELINE.json configs[0]); the snapshot must round-trip byte for byte and the predictions
+    must equal the oracle's emulate_point at the thetas the snapshot holds."""
+    cli = build.CLI_BIN
+    snap = tmp_path / "univariate_snapshot_file"
+    env = dict(os.environ, GPEMU_SEED="12345", GPEMU_RESTARTS="4")
+    run([cli, "estimate_thetas", UNI, str(snap), "--regression_order=1"], env=env)
+    toks = snap.read_text().split()
+    nt, nr, d, N, cov, order = (int(t) for t in toks[:6])
+    assert (nt, nr, d, N, cov, order) == (1, 1, 1, 34, 1, 1)
+    # byte-exact dump -> load -> dump
+    snap2 = tmp_path / "snap2"
+    run([driver, "roundtrip", str(snap), str(snap2)])
+    assert snap.read_bytes() == snap2.read_bytes()
+    # thetas sit after: 6 header ints, N*d, N*nt, nr evals, nt*nr evecs, N*nr z, then the model block
+    pos = 6 + N * d + N * nt + nr + nt * nr + N * nr
+    nthetas = int(toks[pos])
+    blk = pos + 10 + 2 * nthetas + N * d
+    z = np.array(toks[blk:blk + N], float)
+    thetas = np.array(toks[blk + N:blk + N + nthetas], float)
+    assert nthetas == 3 and np.all(np.isfinite(thetas))       # BFGS is unbounded (as in the reference): only the start points respect grad_ranges
+    X, Y = synth.read_input_model_file(UNI)
+    qpath = os.path.join(INP, "uni-simple.sample_locations.dat")
+    out = run([cli, "interactive_mode", str(snap)], stdin=open(qpath))
+    lines = out.split()
+    assert lines[:6] == ["1", "param_0", "2", "mean_0", "variance_0"] + lines[5:6]
+    vals = np.array(lines[5:], float).reshape(-1, 2)
+    Q = np.array(open(qpath).read().split(), float).reshape(-1, 1)
+    assert len(vals) == len(Q) == 100
+    # oracle prediction in PCA space, then the reference's back-projection (nt = nr = 1)
+    e = O.Emulator(1, 1, X, z, thetas)
+    m, v, _ = e.emulate(Q)
+    lam = float(toks[6 + N * d + N * nt])
+    u = float(toks[6 + N * d + N * nt + nr])
+    mean = Y[:, 0].mean() + u * np.sqrt(lam) * m
+    var = u * u * lam * v
+    assert np.max(np.abs(vals[:, 0] - mean)) < 1e-7 * max(1.0, np.abs(mean).max())
+    assert np.max(np.abs(vals[:, 1] - var)) < 1e-7 * max(1e-3, np.abs(var).max())
+    # the emulator actually learnt the curve: training points are reproduced
+    out2 = run([cli, "interactive_mode", str(snap), "-q"], input="\n".join(repr(float(x)) for x in X[:5, 0]) + "\n")
+    got = np.array(out2.split(), float).reshape(-1, 2)
+    assert np.max(np.abs(got[:, 0] - Y[:5, 0])) < 1e-6
+
+
+@pytest.mark.gpu
+def test_multi_output_pca_snapshot_and_backprojection(driver, tmp_path):
+    """test/multi-simple (N=100, d=3, t=6): PCA keeps nr <= t-1 components; predictions at the training points
+    come back in the observable space close to the training outputs."""
+    cli = build.CLI_BIN
+    snap = tmp_path / "multi_snapshot_file"
+    env = dict(os.environ, GPEMU_SEED="777", GPEMU_RESTARTS="2")
+    run([cli, "estimate_thetas", MULTI, str(snap), "--regression_order=0"], env=env)
+    toks = snap.read_text().split()
+    nt, nr, d, N = (int(t) for t in toks[:4])
+    assert (nt, d, N) == (6, 3, 100) and 1 <= nr <= nt - 1
+    X, Y = synth.read_input_model_file(MULTI)
+    qf = tmp_path / "q.dat"
+    np.savetxt(qf, X[:10], fmt="%.17g")
+    res = parse(run([driver, "multi", str(snap), str(qf)]))
+    pred = np.array(res["pred"]).reshape(10, nt, 2)
+    # oracle: emulate_point per PCA component at the snapshot's thetas, then the reference's back-projection
+    snapd = parse_snapshot(toks)
+    m_pca, v_pca = np.empty((10, nr)), np.empty((10, nr))
+    for c, comp in enumerate(snapd["models"]):
+        e = O.Emulator(comp["cov"], comp["order"], comp["X"], comp["z"], comp["thetas"])
+        m_pca[:, c], v_pca[:, c], _ = e.emulate(X[:10])
+    ybar = snapd["Y"].mean(axis=0)
+    for q in range(10):
+        mo, vo = O.pca_backproject(ybar, snapd["evals"], snapd["evecs"], m_pca[q], v_pca[q])
+        assert np.max(np.abs(pred[q, :, 0] - mo)) < 1e-7 * max(1.0, np.abs(mo).max())
+        assert np.max(np.abs(pred[q, :, 1] - vo)) < 1e-7 * max(1e-3, np.abs(vo).max())
+    # and the emulator is a sensible fit of the training outputs (PCA truncation + nugget only)
+    assert np.max(np.abs(pred[:, :, 0] - Y[:10])) < 0.2
+
+
+def parse_snapshot(toks):
+    """MODEL_SNAPSHOT_FILE grammar"""
+    it = iter(toks)
+    nxt = lambda n, typ=float: np.array([typ(next(it)) for _ in range(n)])
+    nt, nr, d, N, cov, order = (int(next(it)) for _ in range(6))
+    out = dict(nt=nt, nr=nr, d=d, N=N, X=nxt(N * d).reshape(N, d), Y=nxt(N * nt).reshape(N, nt), evals=nxt(nr),
+               evecs=nxt(nt * nr).reshape(nt, nr), Z=nxt(N * nr).reshape(N, nr), models=[])
+    for _ in range(nr):
+        nthetas, dd, NN, _nemu, order_c, nreg, _fnm = (int(next(it)) for _ in range(7))
+        _fn = float(next(it))
+        cov_c, _uds = int(next(it)), int(next(it))
+        ranges = nxt(2 * nthetas).reshape(nthetas, 2)
+        Xc = nxt(NN * dd).reshape(NN, dd)
+        z = nxt(NN)
+        th = nxt(nthetas)
+        scales = nxt(dd)
+        out["models"].append(dict(cov=cov_c, order=order_c, X=Xc, z=z, thetas=th, ranges=ranges, scales=scales))
+    return out
