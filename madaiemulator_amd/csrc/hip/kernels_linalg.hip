@@ -206,18 +206,18 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs &a)
 // ---------------------------------------------------------------------------
 // Leaf = two kernels on the 64x64 diagonal block at (c0,c0) of T:
 //
-//  leaf_factor_kernel (1 workgroup, 1 wave): right-looking Cholesky, one matrix
-//    row per lane held in 64 VGPR pairs, no barriers; column k of L goes to LDS
-//    (transposed image, so the rank-1 update reads two l_ck per ds_read_b128 as
-//    wave-uniform broadcasts).  The 64 sequential pivots are the critical path
-//    of the whole factorisation: the next pivot is updated through an SGPR
-//    broadcast ahead of the LDS round trip, and 1/sqrt is the hardware estimate
-//    plus two Newton steps.  A pivot <= 0 (or NaN) records its 1-based global
-//    index in *info (atomicMin) -- GSL_EDOM of gsl_linalg_cholesky_decomp
-//    (maxmultimin.c:325-350).
+//  leaf_factor_kernel (1 workgroup, 4 waves): the block sits in LDS and is
+//    factored in four 16-column panels.  A panel is factored by wave 0, one
+//    matrix row per lane, 16 VGPR pairs, SGPR (readlane) broadcasts, no LDS in
+//    the pivot chain; VALU fp64 issues at 16 cycles per wave-instruction on
+//    gfx950 (a quarter of the MFMA rate, measured), so everything outside the
+//    panel -- the rank-16 trailing updates -- runs on the MFMA across all four
+//    waves.  1/sqrt is the hardware estimate plus two Newton steps.  A pivot
+//    <= 0 (or NaN) records its 1-based global index in *info (atomicMin) --
+//    GSL_EDOM of gsl_linalg_cholesky_decomp (maxmultimin.c:325-350).
 //  leaf_solve_kernel (4 waves, 16 panel rows each): X L^T = B in place on the
 //    fp64 MFMA.  L is staged in LDS, each wave first inverts one 16x16 diagonal
-//    block, then per row tile  X_j^T = Linv_jj (B_j^T - sum_{i<j} L_ji X_i^T):
+//    block (nilpotent series on the MFMA, tri_inverse16), then per row tile  X_j^T = Linv_jj (B_j^T - sum_{i<j} L_ji X_i^T):
 //    the D registers of one MFMA are exactly the B operand of the next (k slot
 //    of lane group g in step r is g+4r in both maps), so the chain never leaves
 //    registers.
@@ -233,70 +233,191 @@ __device__ __forceinline__ double bcast_lane(double v, int srclane)
 	return __hiloint2double(hi, lo);
 }
 
-__global__ __launch_bounds__(64) void leaf_factor_kernel(double *T, long ld, int c0, int *info)
+// one 16-column panel (columns 16P..16P+15) of the 64x64 block in LDS, rows 16P..63, row per lane (wave 0)
+template <int P>
+__device__ __forceinline__ void panel_factor(double *A, int lane, int &bad)
 {
-	__shared__ double Lt[LEAF * LP];       // Lt[k*LP + c] = L[c][k]
-	const int lane = threadIdx.x;
-	double a[LEAF];
-	{
-		const double *rp = T + (long)(c0 + lane) * ld + c0;
+	double a[16];
 #pragma unroll
-		for (int k = 0; k < LEAF; k += 2) {
-			d2_t v = *reinterpret_cast<const d2_t *>(rp + k);
-			a[k] = v[0];
-			a[k + 1] = v[1];
-		}
+	for (int c = 0; c < 16; c += 2) {
+		d2_t v = *reinterpret_cast<const d2_t *>(&A[lane * LP + 16 * P + c]);
+		a[c] = v[0]; a[c + 1] = v[1];
 	}
-	int bad = 0;
 #pragma unroll
-	for (int k = 0; k < LEAF; k++) {
-		const double p = bcast_lane(a[k], k);          // current pivot a_kk (lane k, register k)
-		if (!(p > 0.0) && bad == 0) bad = k + 1;
-		// rs = 1/sqrt(p): hardware estimate + two Newton steps (full double precision)
+	for (int k = 0; k < 16; k++) {
+		const double p = bcast_lane(a[k], 16 * P + k);
+		if (!(p > 0.0) && bad == 0) bad = 16 * P + k + 1;
 		double rs = __builtin_amdgcn_rsq(p);
-		{
-			double t = p * rs;
-			double e = fma(-t, rs, 1.0);
-			rs = fma(rs * 0.5, e, rs);
-			t = p * rs;
-			e = fma(-t, rs, 1.0);
-			rs = fma(rs * 0.5, e, rs);
-		}
-		const double lik = (lane == k) ? p * rs : a[k] * rs;   // l_kk = sqrt(p), l_ik = a_ik / l_kk
+		{ double t = p * rs; double e = fma(-t, rs, 1.0); rs = fma(rs * 0.5, e, rs); t = p * rs; e = fma(-t, rs, 1.0); rs = fma(rs * 0.5, e, rs); }
+		const double lik = (lane == 16 * P + k) ? p * rs : a[k] * rs;
 		a[k] = lik;
-		Lt[k * LP + lane] = lik;
-		if (k + 1 < LEAF) {
-			// next pivot column first, through SGPRs: keeps the LDS round trip off the pivot chain
-			a[k + 1] = fma(-lik, bcast_lane(lik, k + 1), a[k + 1]);
-			// a_ic -= l_ik * l_ck for c >= k+2; l_ck pairs are wave-uniform 16-byte LDS reads
-			constexpr int dummy = 0; (void)dummy;
-			const int cs = k + 2;
-			if (cs < LEAF) {
-				int c = cs;
-				if (c & 1) { a[c] = fma(-lik, Lt[k * LP + c], a[c]); c++; }
 #pragma unroll
-				for (; c + 1 < LEAF; c += 2) {
-					const d2_t v = *reinterpret_cast<const d2_t *>(&Lt[k * LP + c]);
-					a[c] = fma(-lik, v[0], a[c]);
-					a[c + 1] = fma(-lik, v[1], a[c + 1]);
-				}
-			}
+		for (int c = k + 1; c < 16; c++)
+			a[c] = fma(-lik, bcast_lane(lik, 16 * P + c), a[c]);
+	}
+	if (lane >= 16 * P) {
+#pragma unroll
+		for (int c = 0; c < 16; c += 2) {
+			d2_t v = {a[c], a[c + 1]};
+			*reinterpret_cast<d2_t *>(&A[lane * LP + 16 * P + c]) = v;
 		}
 	}
-	if (bad && lane == 0) atomicMin(info, c0 + bad);
-	double *wp = T + (long)(c0 + lane) * ld + c0;
-#pragma unroll
-	for (int k = 0; k < LEAF; k++)
-		if (k <= lane) wp[k] = a[k];
 }
+// trailing update after panel P: tiles (ti,tj), P < tj <= ti <= 3, C -= Pan_ti Pan_tj^T on the MFMA
+template <int P>
+__device__ __forceinline__ void panel_update(double *A, int wave, int lane)
+{
+	const int g = lane >> 4, q = lane & 15;
+	int t = 0;
+#pragma unroll
+	for (int ti = P + 1; ti < 4; ti++)
+#pragma unroll
+		for (int tj = P + 1; tj <= ti; tj++) {
+			if ((t & 3) == wave) {
+				d4_t c;
+#pragma unroll
+				for (int r = 0; r < 4; r++) c[r] = A[(16 * ti + g + 4 * r) * LP + 16 * tj + q];
+#pragma unroll
+				for (int r = 0; r < 4; r++) {
+					const double a = -A[(16 * ti + q) * LP + 16 * P + g + 4 * r];
+					const double b = A[(16 * tj + q) * LP + 16 * P + g + 4 * r];
+					c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+				}
+#pragma unroll
+				for (int r = 0; r < 4; r++) A[(16 * ti + g + 4 * r) * LP + 16 * tj + q] = c[r];
+			}
+			t++;
+		}
+}
+
+__global__ __launch_bounds__(256) void leaf_factor_kernel(double *T, long ld, int c0, int *info)
+{
+	__shared__ double A[LEAF * LP];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	double *D = T + (long)c0 * ld + c0;
+	{
+		double v[16];
+#pragma unroll
+		for (int u = 0; u < 16; u++) v[u] = D[(long)(wave + 4 * u) * ld + lane];
+#pragma unroll
+		for (int u = 0; u < 16; u++) A[(wave + 4 * u) * LP + lane] = v[u];
+	}
+	__syncthreads();
+	int bad = 0;
+	if (wave == 0) panel_factor<0>(A, lane, bad);
+	__syncthreads();
+	panel_update<0>(A, wave, lane);
+	__syncthreads();
+	if (wave == 0) panel_factor<1>(A, lane, bad);
+	__syncthreads();
+	panel_update<1>(A, wave, lane);
+	__syncthreads();
+	if (wave == 0) panel_factor<2>(A, lane, bad);
+	__syncthreads();
+	panel_update<2>(A, wave, lane);
+	__syncthreads();
+	if (wave == 0) panel_factor<3>(A, lane, bad);
+	__syncthreads();
+	if (tid == 0 && bad) atomicMin(info, c0 + bad);
+#pragma unroll
+	for (int u = 0; u < 16; u++) {
+		const int r = wave + 4 * u;
+		if (lane <= r) D[(long)r * ld + lane] = A[r * LP + lane];
+	}
+}
+
+// 1/x: hardware estimate + two Newton steps (an fp64 divide costs ~10 dependent VALU ops at 16 cycles each)
+__device__ __forceinline__ double fast_rcp(double x)
+{
+	double y = __builtin_amdgcn_rcp(x);
+	double e = fma(-x, y, 1.0);
+	y = fma(y, e, y);
+	e = fma(-x, y, 1.0);
+	return fma(y, e, y);
+}
+
+// inverse of the 16x16 lower-triangular diagonal block `o` of M (LDS, stride LP), written back over it.
+// L = D (I + N), N strictly lower => (I+N)^-1 = (I - N)(I + N^2)(I + N^4)(I + N^8) exactly (N^16 = 0):
+// five 16x16x16 products on the MFMA; the D registers of a product are the B operand of the next one,
+// the A operand goes through a private 16x17 LDS tile.
+__device__ __forceinline__ void tri_inverse16(double *M, int o, double *tile, int lane)
+{
+	const int g = lane >> 4, q = lane & 15;
+	// B/D-layout element (row g+4r, col q); A-layout element (row q, k g+4r)
+	double dinv_row[4], dinv_q;
+	dinv_q = fast_rcp(M[(o + q) * LP + o + q]);
+#pragma unroll
+	for (int r = 0; r < 4; r++) dinv_row[r] = fast_rcp(M[(o + g + 4 * r) * LP + o + g + 4 * r]);
+	d4_t nB;      // N in B layout: N[row][col] = L[row][col]/L[row][row], row > col
+	double nA[4]; // N in A layout: N[q][g+4r]
+#pragma unroll
+	for (int r = 0; r < 4; r++) {
+		const int row = g + 4 * r;
+		nB[r] = (row > q) ? M[(o + row) * LP + o + q] * dinv_row[r] : 0.0;
+		const int k = g + 4 * r;
+		nA[r] = (q > k) ? M[(o + q) * LP + o + k] * dinv_q : 0.0;
+	}
+	// S = N*N
+	d4_t S = {0, 0, 0, 0};
+#pragma unroll
+	for (int r = 0; r < 4; r++) S = __builtin_amdgcn_mfma_f64_16x16x4f64(nA[r], nB[r], S, 0, 0, 0);
+	// Q = (I - N)(I + S)
+	d4_t B1, Q = {0, 0, 0, 0};
+#pragma unroll
+	for (int r = 0; r < 4; r++) B1[r] = S[r] + ((g + 4 * r == q) ? 1.0 : 0.0);
+#pragma unroll
+	for (int r = 0; r < 4; r++) {
+		const double a = ((q == g + 4 * r) ? 1.0 : 0.0) - nA[r];
+		Q = __builtin_amdgcn_mfma_f64_16x16x4f64(a, B1[r], Q, 0, 0, 0);
+	}
+	// two more doublings: S <- S*S ; Q <- Q (I + S)
+#pragma unroll
+	for (int it = 0; it < 2; it++) {
+		double sA[4], qA[4];
+#pragma unroll
+		for (int r = 0; r < 4; r++) tile[(g + 4 * r) * 17 + q] = S[r];
+#pragma unroll
+		for (int r = 0; r < 4; r++) sA[r] = tile[q * 17 + g + 4 * r];
+		d4_t S2 = {0, 0, 0, 0};
+#pragma unroll
+		for (int r = 0; r < 4; r++) S2 = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[r], S[r], S2, 0, 0, 0);
+#pragma unroll
+		for (int r = 0; r < 4; r++) tile[(g + 4 * r) * 17 + q] = Q[r];
+#pragma unroll
+		for (int r = 0; r < 4; r++) qA[r] = tile[q * 17 + g + 4 * r];
+		d4_t B2, Q2 = {0, 0, 0, 0};
+#pragma unroll
+		for (int r = 0; r < 4; r++) B2[r] = S2[r] + ((g + 4 * r == q) ? 1.0 : 0.0);
+#pragma unroll
+		for (int r = 0; r < 4; r++) Q2 = __builtin_amdgcn_mfma_f64_16x16x4f64(qA[r], B2[r], Q2, 0, 0, 0);
+		S = S2;
+		Q = Q2;
+	}
+	// Linv = (I+N)^-1 D^-1 : column q scaled by 1/L[q][q]; D layout element (row g+4r, col q)
+#pragma unroll
+	for (int r = 0; r < 4; r++) M[(o + g + 4 * r) * LP + o + q] = Q[r] * dinv_q;
+}
+
 
 __global__ __launch_bounds__(256) void leaf_solve_kernel(double *T, long ld, int c0, int m_below)
 {
 	__shared__ double M[LEAF * LP];        // L; diagonal 16x16 blocks replaced by their inverses
 	__shared__ double Xs[4][16 * 17];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int g = lane >> 4, q = lane & 15;
+	// this wave's 16 panel rows: all 16 values per lane requested up front (one memory latency, overlapped
+	// with staging L and inverting the diagonal blocks)
+	const int prow0 = (blockIdx.x * 4 + wave) * 16;
+	int prow = prow0 + q;
+	const bool valid = prow < m_below;
+	if (!valid) prow = m_below - 1;
+	double *bp = T + (long)(c0 + LEAF + prow) * ld + c0;
+	d4_t R[4];
+#pragma unroll
+	for (int j = 0; j < 4; j++)
+#pragma unroll
+		for (int r = 0; r < 4; r++) R[j][r] = bp[16 * j + g + 4 * r];
 	{
-		// 16 rows per wave, all loads issued before the first LDS store (an un-unrolled loop serialises 16 L2 latencies)
 		const double *D = T + (long)c0 * ld + c0;
 		double v[16];
 #pragma unroll
@@ -305,49 +426,13 @@ __global__ __launch_bounds__(256) void leaf_solve_kernel(double *T, long ld, int
 		for (int u = 0; u < 16; u++) M[(wave + 4 * u) * LP + lane] = v[u];
 	}
 	__syncthreads();
-	{
-		// wave w inverts diagonal block w: row i = lane&15 (the four 16-lane groups do identical work)
-		const int i = lane & 15, o = 16 * wave;
-		double l[16], x[16];
-#pragma unroll
-		for (int m = 0; m < 16; m++) {
-			l[m] = M[(o + i) * LP + o + m];
-			x[m] = (m == i) ? 1.0 : 0.0;
-		}
-		const double inv_ii = 1.0 / M[(o + i) * LP + o + i];
-		double *xs = Xs[wave];
-#pragma unroll
-		for (int m = 0; m < 16; m++) {
-			if (i == m) {
-#pragma unroll
-				for (int c = 0; c < 16; c++) xs[m * 17 + c] = (c <= m) ? x[c] * inv_ii : 0.0;
-			}
-#pragma unroll
-			for (int c = 0; c <= m; c++) {
-				const double xm = xs[m * 17 + c];
-				if (i > m) x[c] = fma(-l[m], xm, x[c]);
-			}
-		}
-		__syncthreads();      // every wave has finished reading its diagonal block of M
-#pragma unroll
-		for (int m = 0; m < 16; m++)
-			if (lane < 16) M[(o + m) * LP + o + lane] = xs[m * 17 + lane];
-	}
+	tri_inverse16(M, 16 * wave, Xs[wave], lane);      // wave w inverts diagonal block w
 	__syncthreads();
-
-	const int g = lane >> 4, q = lane & 15;
-	const int prow0 = (blockIdx.x * 4 + wave) * 16;
 	if (prow0 >= m_below) return;
-	int prow = prow0 + q;
-	const bool valid = prow < m_below;
-	if (!valid) prow = m_below - 1;
-	double *bp = T + (long)(c0 + LEAF + prow) * ld + c0;
 	d4_t X[4];
 #pragma unroll
 	for (int j = 0; j < 4; j++) {
-		d4_t acc;
-#pragma unroll
-		for (int r = 0; r < 4; r++) acc[r] = bp[16 * j + g + 4 * r];
+		d4_t acc = R[j];
 #pragma unroll
 		for (int i = 0; i < j; i++)
 #pragma unroll
@@ -371,7 +456,7 @@ __global__ __launch_bounds__(256) void leaf_solve_kernel(double *T, long ld, int
 
 hipError_t launch_leaf(hipStream_t s, double *T, long ld, int c0, int m_below, int *info)
 {
-	hipLaunchKernelGGL(leaf_factor_kernel, dim3(1), dim3(64), 0, s, T, ld, c0, info);
+	hipLaunchKernelGGL(leaf_factor_kernel, dim3(1), dim3(256), 0, s, T, ld, c0, info);
 	if (m_below > 0)
 		hipLaunchKernelGGL(leaf_solve_kernel, dim3((m_below + 63) / 64), dim3(256), 0, s, T, ld, c0, m_below);
 	return hipGetLastError();
