@@ -24,6 +24,8 @@ using namespace gpemu;
 		}                                                                                       \
 	} while (0)
 
+static int g_leaf128 = 0;                // 128-column fused leaves (env GPEMU_LEAF128=1); measured 3 % slower than 64
+static int g_lookahead = 0;              // two-stream schedule of the outer panels (env GPEMU_LOOKAHEAD=1); see DESIGN.md
 static int g_nb_top = 512;              // width of the right-looking outer panels (env GPEMU_NB_TOP)
 constexpr int INFO_NONE = 0x7f7f7f7f;   // "no failed pivot": what hipMemsetAsync(.., 0x7f, ..) leaves in *info
 
@@ -83,11 +85,11 @@ static double gemm_flops(const GemmArgs &a)
 	return fl;
 }
 
-static hipError_t gemm(gpemu_ctx *ctx, const GemmArgs &a)
+static hipError_t gemm(gpemu_ctx *ctx, const GemmArgs &a, hipStream_t stream = nullptr)
 {
 	const double fl = prof_on(ctx, GPEMU_PROF_GEMM) ? gemm_flops(a) : 0.0;
 	ProfScope ps(ctx, GPEMU_PROF_GEMM, fl, 0.0);
-	return launch_gemm(ctx->stream, a);
+	return launch_gemm(stream ? stream : ctx->stream, a);
 }
 
 // ---------------------------------------------------------------------------
@@ -112,9 +114,42 @@ extern "C" int gpemu_ctx_create(gpemu_ctx **out, int device)
 	gpemu_ctx *ctx = new gpemu_ctx();
 	ctx->device = device;
 	if (hipSetDevice(device) != hipSuccess) { delete ctx; return GPEMU_ERR_HIP; }
-	if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return GPEMU_ERR_HIP; }
+	{
+		int least = 0, greatest = 0;
+		if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = 0; greatest = 0; }
+		if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, greatest) != hipSuccess) {
+			delete ctx;
+			return GPEMU_ERR_HIP;
+		}
+		// The look-ahead stream is kept off a slice of the chip (GPEMU_RESERVE_CUS, default 32 of 256 CUs) so
+		// that the latency-bound panel kernels of the critical stream do not share MFMA pipes with the bulk
+		// trailing update (measured: sharing slows the 64x64 factor kernel 5x and cancels the overlap).
+		const char *la0 = getenv("GPEMU_LOOKAHEAD");
+		const bool want_second = la0 ? atoi(la0) != 0 : g_lookahead != 0;   // only the look-ahead schedule uses it
+		int reserve = 32;
+		const char *rs = getenv("GPEMU_RESERVE_CUS");
+		if (rs) reserve = atoi(rs);
+		hipDeviceProp_t prop;
+		int ncu = 256;
+		if (hipGetDeviceProperties(&prop, device) == hipSuccess) ncu = prop.multiProcessorCount;
+		hipError_t e2 = want_second ? hipErrorUnknown : hipSuccess;
+		if (want_second && reserve > 0 && reserve < ncu) {
+			std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+			for (int i = 0; i < ncu - reserve; i++) mask[i / 32] |= (1u << (i % 32));
+			e2 = hipExtStreamCreateWithCUMask(&ctx->stream2, (uint32_t)mask.size(), mask.data());
+		}
+		if (want_second && e2 != hipSuccess) {
+			(void)hipGetLastError();
+			e2 = hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, least);
+		}
+		if (e2 != hipSuccess) {
+			delete ctx;
+			return GPEMU_ERR_HIP;
+		}
+	}
 	ctx->res_len = 64 * 64 + 8;
 	if (hipMalloc(&ctx->dInfo, sizeof(int)) != hipSuccess ||
+	    hipMalloc(&ctx->dDiagInv, 8 * 256 * sizeof(double)) != hipSuccess ||
 	    hipMalloc(&ctx->dRes, ctx->res_len * sizeof(double)) != hipSuccess ||
 	    hipHostMalloc((void **)&ctx->hRes, ctx->res_len * sizeof(double)) != hipSuccess ||
 	    hipHostMalloc((void **)&ctx->hInfo, sizeof(int)) != hipSuccess) {
@@ -123,6 +158,10 @@ extern "C" int gpemu_ctx_create(gpemu_ctx **out, int device)
 	}
 	const char *ng = getenv("GPEMU_NO_GRAPH");
 	if (ng && ng[0] == '1') ctx->use_graph = false;
+	const char *la = getenv("GPEMU_LOOKAHEAD");
+	if (la) g_lookahead = atoi(la) != 0;
+	const char *l128 = getenv("GPEMU_LEAF128");
+	if (l128) g_leaf128 = atoi(l128) != 0;
 	const char *nbt = getenv("GPEMU_NB_TOP");
 	if (nbt && atoi(nbt) >= LEAF) g_nb_top = (atoi(nbt) / LEAF) * LEAF;
 	*out = ctx;
@@ -150,12 +189,16 @@ extern "C" void gpemu_ctx_destroy(gpemu_ctx *ctx)
 	if (!ctx) return;
 	hipSetDevice(ctx->device);
 	if (ctx->stream) hipStreamSynchronize(ctx->stream);
+	if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
 	free_model(ctx);
 	for (auto e : ctx->prof.ev) hipEventDestroy(e);
 	if (ctx->dInfo) hipFree(ctx->dInfo);
+	if (ctx->dDiagInv) hipFree(ctx->dDiagInv);
 	if (ctx->dRes) hipFree(ctx->dRes);
 	if (ctx->hRes) hipHostFree(ctx->hRes);
 	if (ctx->hInfo) hipHostFree(ctx->hInfo);
+	for (auto e : ctx->ev_pool) hipEventDestroy(e);
+	if (ctx->stream2) hipStreamDestroy(ctx->stream2);
 	if (ctx->stream) hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -285,12 +328,13 @@ static int make_cov_params(gpemu_ctx *ctx, const double *thetas, int nthetas, Co
 //   T rows [Np+Rp,Np+Rp+Np)  : identity -> U = L^-T (only with inv)
 // potrf_rec(c0,n) factors the column panel [c0,c0+n) for every row below it.
 // ---------------------------------------------------------------------------
-static hipError_t trailing_update(gpemu_ctx *ctx, int c0, int k, int ncols, int inv)
+static hipError_t trailing_update(gpemu_ctx *ctx, int c0, int k, int col_off, int ncols, int inv, hipStream_t stream = nullptr)
 {
-	// C[rows >= c0+k, cols c0+k .. c0+k+ncols) -= P P^T with P = the factored panel columns [c0, c0+k)
+	// C[rows >= r0, cols r0 .. r0+ncols) -= P P^T with P = the factored panel columns [c0, c0+k) and
+	// r0 = c0 + k + col_off (rows above r0 belong to the upper triangle of those columns)
 	const long ld = ctx->Np;
-	const int r0 = c0 + k;
-	const int row_end = ctx->Np + ctx->Rp + (inv ? r0 : 0);   // identity rows < r0 have fill-in in the panel
+	const int r0 = c0 + k + col_off;
+	const int row_end = ctx->Np + ctx->Rp + (inv ? c0 + k : 0);   // identity rows < c0+k have fill-in in the panel
 	GemmArgs g;
 	memset(&g, 0, sizeof g);
 	g.C = ctx->dT + (long)r0 * ld + r0;
@@ -302,9 +346,18 @@ static hipError_t trailing_update(gpemu_ctx *ctx, int c0, int k, int ncols, int 
 	g.k0 = 0; g.k1 = k;
 	g.alpha = -1.0; g.beta = 1;
 	g.tri = 1; g.diag_off = 0;
-	return gemm(ctx, g);
+	return gemm(ctx, g, stream);
 }
 
+static hipEvent_t next_event(gpemu_ctx *ctx)
+{
+	if (ctx->ev_next == ctx->ev_pool.size()) {
+		hipEvent_t e;
+		hipEventCreateWithFlags(&e, hipEventDisableTiming);
+		ctx->ev_pool.push_back(e);
+	}
+	return ctx->ev_pool[ctx->ev_next++];
+}
 
 static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv)
 {
@@ -315,32 +368,71 @@ static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv)
 		ProfScope ps(ctx, GPEMU_PROF_LEAF, 0.0, 0.0);
 		return launch_leaf(ctx->stream, ctx->dT, ld, c0, row_end - (c0 + LEAF), ctx->dInfo);
 	}
+	if (n == 2 * LEAF && g_leaf128) {
+		const int row_end = base_end + (inv ? c0 + 2 * LEAF : 0);
+		ProfScope ps(ctx, GPEMU_PROF_LEAF, 0.0, 0.0);
+		return launch_leaf128(ctx->stream, ctx->dT, ld, c0, row_end - (c0 + 2 * LEAF), ctx->dInfo, ctx->dDiagInv);
+	}
 	if (n > g_nb_top) {
 		// right-looking over panels of g_nb_top columns: the trailing update touches the whole remaining
 		// matrix (thousands of tiles, K = panel width), which fills the chip far better than the few huge-K
 		// tiles a pure recursion would produce at the top levels
+		const bool profiling = ctx->prof.cls != GPEMU_PROF_NONE && ctx->prof.cls != GPEMU_PROF_POTRF;
+		const bool ahead = g_lookahead && ctx->stream2 && !profiling && c0 == 0 && n == ctx->Np;
+		hipEvent_t ev_bulk_prev = nullptr;
 		for (int c = c0; c < c0 + n; c += g_nb_top) {
 			const int nb = std::min(g_nb_top, c0 + n - c);
 			hipError_t e = potrf_rec(ctx, c, nb, inv);
 			if (e != hipSuccess) return e;
 			const int rest = c0 + n - (c + nb);
-			if (rest > 0) {
-				e = trailing_update(ctx, c, nb, rest, inv);
+			if (rest <= 0) continue;
+			if (!ahead) {
+				e = trailing_update(ctx, c, nb, 0, rest, inv);
+				if (e != hipSuccess) return e;
+				continue;
+			}
+			// look-ahead: the next panel's columns are updated on the critical stream so that its
+			// factorisation (a chain of small latency-bound kernels) can start at once, while the bulk of the
+			// update runs beside it on the second stream.  Both pieces touch disjoint column ranges; the piece
+			// of step j on the critical stream waits for the bulk of step j-1, which updated the same columns.
+			const int nb_next = std::min(g_nb_top, rest);
+			hipEvent_t ev_panel = next_event(ctx);
+			e = hipEventRecord(ev_panel, ctx->stream);
+			if (e != hipSuccess) return e;
+			if (ev_bulk_prev) {
+				e = hipStreamWaitEvent(ctx->stream, ev_bulk_prev, 0);
+				if (e != hipSuccess) return e;
+				ev_bulk_prev = nullptr;
+			}
+			e = trailing_update(ctx, c, nb, 0, nb_next, inv);
+			if (e != hipSuccess) return e;
+			if (rest > nb_next) {
+				e = hipStreamWaitEvent(ctx->stream2, ev_panel, 0);
+				if (e != hipSuccess) return e;
+				e = trailing_update(ctx, c, nb, nb_next, rest - nb_next, inv, ctx->stream2);
+				if (e != hipSuccess) return e;
+				ev_bulk_prev = next_event(ctx);
+				e = hipEventRecord(ev_bulk_prev, ctx->stream2);
 				if (e != hipSuccess) return e;
 			}
+		}
+		if (ev_bulk_prev) {
+			hipError_t e = hipStreamWaitEvent(ctx->stream, ev_bulk_prev, 0);
+			if (e != hipSuccess) return e;
 		}
 		return hipSuccess;
 	}
 	const int n1 = ((n / LEAF + 1) / 2) * LEAF;
 	hipError_t e = potrf_rec(ctx, c0, n1, inv);
 	if (e != hipSuccess) return e;
-	e = trailing_update(ctx, c0, n1, n - n1, inv);
+	e = trailing_update(ctx, c0, n1, 0, n - n1, inv);
 	if (e != hipSuccess) return e;
 	return potrf_rec(ctx, c0 + n1, n - n1, inv);
 }
 
 static int run_potrf(gpemu_ctx *ctx, int inv)
 {
+	ctx->ev_next = 0;
 	const bool profiling = ctx->prof.cls == GPEMU_PROF_GEMM || ctx->prof.cls == GPEMU_PROF_LEAF;
 	double fl = (double)ctx->Np * ctx->Np * ctx->Np / 3.0;
 	ProfScope ps(ctx, GPEMU_PROF_POTRF, fl, 0.0);
@@ -974,6 +1066,7 @@ extern "C" int gpemu_test_potrf(gpemu_ctx *ctx, int n, double *a, int *info)
 			h[(size_t)i * Np + j] = (i < n) ? a[(size_t)i * n + j] : (i == j ? 1.0 : 0.0);
 	hipError_t e = hipMalloc(&tmp.dT, h.size() * 8);
 	if (e == hipSuccess) e = hipMalloc(&tmp.dInfo, sizeof(int));
+	tmp.dDiagInv = ctx->dDiagInv;
 	int big = INFO_NONE;
 	if (e == hipSuccess) e = hipMemcpy(tmp.dT, h.data(), h.size() * 8, hipMemcpyHostToDevice);
 	if (e == hipSuccess) e = hipMemcpy(tmp.dInfo, &big, sizeof(int), hipMemcpyHostToDevice);
@@ -984,7 +1077,7 @@ extern "C" int gpemu_test_potrf(gpemu_ctx *ctx, int n, double *a, int *info)
 	if (e == hipSuccess) e = hipMemcpy(&inf, tmp.dInfo, sizeof(int), hipMemcpyDeviceToHost);
 	if (tmp.dT) hipFree(tmp.dT);
 	if (tmp.dInfo) hipFree(tmp.dInfo);
-	tmp.dT = nullptr; tmp.dInfo = nullptr; tmp.stream = nullptr;
+	tmp.dT = nullptr; tmp.dInfo = nullptr; tmp.stream = nullptr; tmp.dDiagInv = nullptr;
 	HIPCHK(ctx, e);
 	if (info) *info = (inf >= INFO_NONE) ? 0 : inf;
 	for (int i = 0; i < n; i++)

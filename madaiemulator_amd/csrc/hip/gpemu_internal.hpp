@@ -59,7 +59,10 @@ struct ProfState {
 
 struct gpemu_ctx {
 	int device = 0;
-	hipStream_t stream = nullptr;
+	hipStream_t stream = nullptr;      // panel / critical-path stream (high priority)
+	hipStream_t stream2 = nullptr;     // look-ahead stream: the bulk of each trailing update
+	std::vector<hipEvent_t> ev_pool;   // fork/join events of the look-ahead schedule
+	size_t ev_next = 0;
 	std::string err;
 
 	// model
@@ -74,6 +77,7 @@ struct gpemu_ctx {
 	double *dT = nullptr;
 	size_t T_rows = 0;           // allocated rows
 	int *dInfo = nullptr;
+	double *dDiagInv = nullptr;  // eight inverted 16x16 diagonal blocks of the current 128-column leaf
 	double *dGramPart = nullptr; // [Np/128][Rp*Rp]
 	double *dRes = nullptr;      // Rp*Rp gram + logdet + spare
 	double *hRes = nullptr;      // pinned mirror
@@ -127,6 +131,7 @@ hipError_t launch_grad_partials(hipStream_t s, const double *S, long lds, int so
 // ---- kernels_linalg.hip
 hipError_t launch_gemm(hipStream_t s, const GemmArgs &a);
 hipError_t launch_leaf(hipStream_t s, double *T, long ld, int c0, int m_below, int *info);
+hipError_t launch_leaf128(hipStream_t s, double *T, long ld, int c0, int m_below, int *info, double *dinv);
 hipError_t launch_gram_partials(hipStream_t s, const double *Z, long ld, int Np, int nrhs, int Rp, double *part);
 hipError_t launch_finish(hipStream_t s, const double *part, int nparts, int Rp, int nrhs, const double *T, long ld,
                          int N, double *res);

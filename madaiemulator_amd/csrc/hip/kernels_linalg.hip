@@ -14,7 +14,12 @@ namespace gpemu {
 typedef double d4_t __attribute__((ext_vector_type(4)));
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
-constexpr int LDS_S = GEMM_BK + 2;   // row stride (doubles): conflict-free ds_read_b64 fragments
+// LDS row stride (doubles).  Fragments are read as ds_read_b128: lane (q = lane&15, g = lane>>4) takes the
+// two doubles k = 8t+2g, 8t+2g+1 of its row and feeds them to MFMA k-steps 2t and 2t+1 (A and B use the same
+// k permutation, so the contraction is unchanged).  With a 20-double stride the four 16-lane groups of a
+// b128 read hit 64 distinct banks; the former 18-double stride with ds_read2_b64 (what hipcc emitted for
+// scalar reads) measured 40 % bank-conflict cycles (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).
+constexpr int LDS_S = GEMM_BK + 4;
 
 // ---------------------------------------------------------------------------
 // GEMM  C[m x n] = beta*C + alpha * A[m x K] * B[n x K]^T   (row-major, k contiguous in A and B)
@@ -23,22 +28,25 @@ constexpr int LDS_S = GEMM_BK + 2;   // row stride (doubles): conflict-free ds_r
 // 16x16 MFMA tiles.  MFMA f64 16x16x4 operand maps (cdna_hip_programming.md
 // section 3): A lane l -> A[row l&15][k l>>4], B lane l -> B[k l>>4][col l&15],
 // D reg r -> D[row (l>>4)+4r][col l&15].
-// Three tile shapes (128x128, 128x64, 64x64): the fp64 MFMA rate per CU is low
+// Tile shapes 128x128 (4 or 8 waves), 128x64, 64x64: the fp64 MFMA rate per CU is low
 // (one 16x16x4 per 64 cycles per SIMD), so short or narrow updates need many
 // small tiles to cover 256 CUs while the big trailing updates want 128x128
 // for L2 traffic; launch_gemm picks per call.
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int MINW>
-__global__ __launch_bounds__(256, MINW) void gemm_nt_kernel(GemmArgs g)
+// (A persistent variant -- grid = resident workgroups, tile loop with the next tile's first chunk and the C
+// tile prefetched under the epilogue -- was measured 5-10 % slower on the big updates (register pressure,
+// imbalance of the static tile stride in triangular mode) and only ~10 % faster on the narrow ones; not kept.)
+template <int BM, int BN, int MINW, int WGM = 2, int WGN = 2>
+__global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs g)
 {
-	constexpr int WM = BM / 2, WN = BN / 2;
+	constexpr int NT = 64 * WGM * WGN;              // threads: WGM x WGN waves
+	constexpr int WM = BM / WGM, WN = BN / WGN;
 	constexpr int TM = WM / 16, TN = WN / 16;
-	constexpr int AIT = BM * 8 / 256, BIT = BN * 8 / 256;
+	constexpr int AIT = BM * 8 / NT, BIT = BN * 8 / NT;
 	__shared__ double As[2][BM * LDS_S];
 	__shared__ double Bs[2][BN * LDS_S];
 
 	const int tiles_m = (g.m + BM - 1) / BM;
-	const int tiles_n = (g.n + BN - 1) / BN;
 	// natural order: consecutive blocks (which the dispatcher deals round-robin over the 8 XCDs) walk down a
 	// tile column, so one XCD keeps re-using 1/8 of the A panels and every B panel; measured equal to grouped /
 	// XCD-chunked orders at these sizes (the operands sit in the 256 MB Infinity Cache).
@@ -59,7 +67,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel(GemmArgs g)
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;
 	const int wave = tid >> 6;
-	const int wm = wave >> 1, wn = wave & 1;
+	const int wm = wave / WGN, wn = wave % WGN;
 
 	// staging map: (row, 16-byte segment) pairs per operand per thread
 	const double *ag[AIT];
@@ -67,7 +75,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel(GemmArgs g)
 	int lofs_a[AIT], lofs_b[BIT];
 #pragma unroll
 	for (int it = 0; it < AIT; it++) {
-		int idx = tid + 256 * it;
+		int idx = tid + NT * it;
 		int row = idx >> 3, seg = idx & 7;
 		int ar = tm * BM + row; if (ar > g.m - 1) ar = g.m - 1;
 		ag[it] = g.A + (long)ar * g.lda + 2 * seg;
@@ -75,7 +83,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel(GemmArgs g)
 	}
 #pragma unroll
 	for (int it = 0; it < BIT; it++) {
-		int idx = tid + 256 * it;
+		int idx = tid + NT * it;
 		int row = idx >> 3, seg = idx & 7;
 		int br = tn * BN + row; if (br > g.n - 1) br = g.n - 1;
 		bg[it] = g.B + (long)br * g.ldb + 2 * seg;
@@ -88,8 +96,8 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel(GemmArgs g)
 #pragma unroll
 		for (int j = 0; j < TN; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
 
-	const int a_base = (wm * WM + (lane & 15)) * LDS_S + (lane >> 4);
-	const int b_base = (wn * WN + (lane & 15)) * LDS_S + (lane >> 4);
+	const int a_base = (wm * WM + (lane & 15)) * LDS_S + 2 * (lane >> 4);
+	const int b_base = (wn * WN + (lane & 15)) * LDS_S + 2 * (lane >> 4);
 
 	if (kb < ke) {
 		d2_t ra[AIT], rb[BIT];
@@ -115,17 +123,19 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel(GemmArgs g)
 			const double *as = As[cur];
 			const double *bs = Bs[cur];
 #pragma unroll
-			for (int s = 0; s < GEMM_BK / 4; s++) {
-				double a[TM], b[TN];
+			for (int t = 0; t < GEMM_BK / 8; t++) {
+				d2_t a[TM], b[TN];
 #pragma unroll
-				for (int i = 0; i < TM; i++) a[i] = as[a_base + i * 16 * LDS_S + 4 * s];
+				for (int i = 0; i < TM; i++) a[i] = *reinterpret_cast<const d2_t *>(&as[a_base + i * 16 * LDS_S + 8 * t]);
 #pragma unroll
-				for (int j = 0; j < TN; j++) b[j] = bs[b_base + j * 16 * LDS_S + 4 * s];
+				for (int j = 0; j < TN; j++) b[j] = *reinterpret_cast<const d2_t *>(&bs[b_base + j * 16 * LDS_S + 8 * t]);
 #pragma unroll
-				for (int i = 0; i < TM; i++)
+				for (int h = 0; h < 2; h++)
 #pragma unroll
-					for (int j = 0; j < TN; j++)
-						acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+					for (int i = 0; i < TM; i++)
+#pragma unroll
+						for (int j = 0; j < TN; j++)
+							acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][h], b[j][h], acc[i][j], 0, 0, 0);
 			}
 			if (more) {
 #pragma unroll
@@ -183,7 +193,7 @@ int g_gemm_force_cfg = -1;   // test/bench hook: 0 = 128x128, 1 = 128x64, 2 = 64
 int choose_gemm_cfg(const GemmArgs &a)
 {
 	if (g_gemm_force_cfg >= 0) return g_gemm_force_cfg;
-	return count_tiles(a, 128, 128) >= 2048 ? 0 : 2;
+	return count_tiles(a, 128, 128) >= 2048 ? 3 : 2;
 }
 
 hipError_t launch_gemm(hipStream_t s, const GemmArgs &a)
@@ -196,6 +206,9 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs &a)
 	} else if (cfg == 1) {
 		const int T = ((a.m + 127) / 128) * ((a.n + 63) / 64);
 		hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 2>), dim3(T), dim3(256), 0, s, a);
+	} else if (cfg == 3) {
+		const int T = ((a.m + 127) / 128) * ((a.n + 127) / 128);
+		hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 4, 4, 2>), dim3(T), dim3(512), 0, s, a);
 	} else {
 		const int T = ((a.m + 63) / 64) * ((a.n + 63) / 64);
 		hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4>), dim3(T), dim3(256), 0, s, a);
@@ -234,19 +247,19 @@ __device__ __forceinline__ double bcast_lane(double v, int srclane)
 }
 
 // one 16-column panel (columns 16P..16P+15) of the 64x64 block in LDS, rows 16P..63, row per lane (wave 0)
-template <int P>
-__device__ __forceinline__ void panel_factor(double *A, int lane, int &bad)
+template <int P, int LD>
+__device__ __forceinline__ void panel_factor(double *A, int lane, int &bad, int bad_off)
 {
 	double a[16];
 #pragma unroll
 	for (int c = 0; c < 16; c += 2) {
-		d2_t v = *reinterpret_cast<const d2_t *>(&A[lane * LP + 16 * P + c]);
+		d2_t v = *reinterpret_cast<const d2_t *>(&A[lane * LD + 16 * P + c]);
 		a[c] = v[0]; a[c + 1] = v[1];
 	}
 #pragma unroll
 	for (int k = 0; k < 16; k++) {
 		const double p = bcast_lane(a[k], 16 * P + k);
-		if (!(p > 0.0) && bad == 0) bad = 16 * P + k + 1;
+		if (!(p > 0.0) && bad == 0) bad = bad_off + 16 * P + k + 1;
 		double rs = __builtin_amdgcn_rsq(p);
 		{ double t = p * rs; double e = fma(-t, rs, 1.0); rs = fma(rs * 0.5, e, rs); t = p * rs; e = fma(-t, rs, 1.0); rs = fma(rs * 0.5, e, rs); }
 		const double lik = (lane == 16 * P + k) ? p * rs : a[k] * rs;
@@ -259,12 +272,12 @@ __device__ __forceinline__ void panel_factor(double *A, int lane, int &bad)
 #pragma unroll
 		for (int c = 0; c < 16; c += 2) {
 			d2_t v = {a[c], a[c + 1]};
-			*reinterpret_cast<d2_t *>(&A[lane * LP + 16 * P + c]) = v;
+			*reinterpret_cast<d2_t *>(&A[lane * LD + 16 * P + c]) = v;
 		}
 	}
 }
 // trailing update after panel P: tiles (ti,tj), P < tj <= ti <= 3, C -= Pan_ti Pan_tj^T on the MFMA
-template <int P>
+template <int P, int LD>
 __device__ __forceinline__ void panel_update(double *A, int wave, int lane)
 {
 	const int g = lane >> 4, q = lane & 15;
@@ -276,15 +289,15 @@ __device__ __forceinline__ void panel_update(double *A, int wave, int lane)
 			if ((t & 3) == wave) {
 				d4_t c;
 #pragma unroll
-				for (int r = 0; r < 4; r++) c[r] = A[(16 * ti + g + 4 * r) * LP + 16 * tj + q];
+				for (int r = 0; r < 4; r++) c[r] = A[(16 * ti + g + 4 * r) * LD + 16 * tj + q];
 #pragma unroll
 				for (int r = 0; r < 4; r++) {
-					const double a = -A[(16 * ti + q) * LP + 16 * P + g + 4 * r];
-					const double b = A[(16 * tj + q) * LP + 16 * P + g + 4 * r];
+					const double a = -A[(16 * ti + q) * LD + 16 * P + g + 4 * r];
+					const double b = A[(16 * tj + q) * LD + 16 * P + g + 4 * r];
 					c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 				}
 #pragma unroll
-				for (int r = 0; r < 4; r++) A[(16 * ti + g + 4 * r) * LP + 16 * tj + q] = c[r];
+				for (int r = 0; r < 4; r++) A[(16 * ti + g + 4 * r) * LD + 16 * tj + q] = c[r];
 			}
 			t++;
 		}
@@ -304,19 +317,19 @@ __global__ __launch_bounds__(256) void leaf_factor_kernel(double *T, long ld, in
 	}
 	__syncthreads();
 	int bad = 0;
-	if (wave == 0) panel_factor<0>(A, lane, bad);
+	if (wave == 0) panel_factor<0, LP>(A, lane, bad, 0);
 	__syncthreads();
-	panel_update<0>(A, wave, lane);
+	panel_update<0, LP>(A, wave, lane);
 	__syncthreads();
-	if (wave == 0) panel_factor<1>(A, lane, bad);
+	if (wave == 0) panel_factor<1, LP>(A, lane, bad, 0);
 	__syncthreads();
-	panel_update<1>(A, wave, lane);
+	panel_update<1, LP>(A, wave, lane);
 	__syncthreads();
-	if (wave == 0) panel_factor<2>(A, lane, bad);
+	if (wave == 0) panel_factor<2, LP>(A, lane, bad, 0);
 	__syncthreads();
-	panel_update<2>(A, wave, lane);
+	panel_update<2, LP>(A, wave, lane);
 	__syncthreads();
-	if (wave == 0) panel_factor<3>(A, lane, bad);
+	if (wave == 0) panel_factor<3, LP>(A, lane, bad, 0);
 	__syncthreads();
 	if (tid == 0 && bad) atomicMin(info, c0 + bad);
 #pragma unroll
@@ -340,22 +353,23 @@ __device__ __forceinline__ double fast_rcp(double x)
 // L = D (I + N), N strictly lower => (I+N)^-1 = (I - N)(I + N^2)(I + N^4)(I + N^8) exactly (N^16 = 0):
 // five 16x16x16 products on the MFMA; the D registers of a product are the B operand of the next one,
 // the A operand goes through a private 16x17 LDS tile.
-__device__ __forceinline__ void tri_inverse16(double *M, int o, double *tile, int lane)
+template <int LD>
+__device__ __forceinline__ void tri_inverse16_to(const double *M, int o, double *tile, int lane, double *dst, int dst_ld)
 {
 	const int g = lane >> 4, q = lane & 15;
 	// B/D-layout element (row g+4r, col q); A-layout element (row q, k g+4r)
 	double dinv_row[4], dinv_q;
-	dinv_q = fast_rcp(M[(o + q) * LP + o + q]);
+	dinv_q = fast_rcp(M[(o + q) * LD + o + q]);
 #pragma unroll
-	for (int r = 0; r < 4; r++) dinv_row[r] = fast_rcp(M[(o + g + 4 * r) * LP + o + g + 4 * r]);
+	for (int r = 0; r < 4; r++) dinv_row[r] = fast_rcp(M[(o + g + 4 * r) * LD + o + g + 4 * r]);
 	d4_t nB;      // N in B layout: N[row][col] = L[row][col]/L[row][row], row > col
 	double nA[4]; // N in A layout: N[q][g+4r]
 #pragma unroll
 	for (int r = 0; r < 4; r++) {
 		const int row = g + 4 * r;
-		nB[r] = (row > q) ? M[(o + row) * LP + o + q] * dinv_row[r] : 0.0;
+		nB[r] = (row > q) ? M[(o + row) * LD + o + q] * dinv_row[r] : 0.0;
 		const int k = g + 4 * r;
-		nA[r] = (q > k) ? M[(o + q) * LP + o + k] * dinv_q : 0.0;
+		nA[r] = (q > k) ? M[(o + q) * LD + o + k] * dinv_q : 0.0;
 	}
 	// S = N*N
 	d4_t S = {0, 0, 0, 0};
@@ -395,9 +409,14 @@ __device__ __forceinline__ void tri_inverse16(double *M, int o, double *tile, in
 	}
 	// Linv = (I+N)^-1 D^-1 : column q scaled by 1/L[q][q]; D layout element (row g+4r, col q)
 #pragma unroll
-	for (int r = 0; r < 4; r++) M[(o + g + 4 * r) * LP + o + q] = Q[r] * dinv_q;
+	for (int r = 0; r < 4; r++) dst[(g + 4 * r) * dst_ld + q] = Q[r] * dinv_q;
 }
 
+
+__device__ __forceinline__ void tri_inverse16(double *M, int o, double *tile, int lane)
+{
+	tri_inverse16_to<LP>(M, o, tile, lane, M + o * LP + o, LP);     // in place over the diagonal block
+}
 
 __global__ __launch_bounds__(256) void leaf_solve_kernel(double *T, long ld, int c0, int m_below)
 {
@@ -452,6 +471,228 @@ __global__ __launch_bounds__(256) void leaf_solve_kernel(double *T, long ld, int
 			for (int r = 0; r < 4; r++) bp[16 * j + g + 4 * r] = xj[r];
 		}
 	}
+}
+
+// ---------------------------------------------------------------------------
+// 128-column leaf: the same two steps on a 128x128 diagonal block, one launch each instead of five
+// (factor, solve, K=64 update, factor, solve on 64-column halves) -- the chain of small dependent
+// kernels is the critical path of the factorisation, so fewer, fatter links win.
+//
+//  leaf128_factor_kernel (1 workgroup): block in LDS (133 KB).  A11 = chol (four 16-column panels as
+//    above); A21 <- A21 L11^-T on the MFMA (needs the inverses of L11's 16x16 diagonal blocks);
+//    A22 -= A21 A21^T (MFMA, K = 64); A22 = chol.  The eight inverted 16x16 diagonal blocks are
+//    written to `dinv` for the panel solve.
+//  leaf128_solve_kernel (16 panel rows per wave): X L^T = B for the rows below, L and the inverted
+//    diagonal blocks staged in LDS; left half as a dependent MFMA chain, the cross update with four
+//    independent accumulators, then the right half chain.
+// ---------------------------------------------------------------------------
+constexpr int L2 = 128;
+constexpr int LP2 = L2 + 2;
+
+// rows [row0,row0+16) of the block: X_j^T = Inv_j (R_j^T - sum_{i<j} L_ji X_i^T), j = j0..j1-1, in place in LDS
+template <int J0, int J1, int LD>
+__device__ __forceinline__ void solve_rows_lds(double *A, int row0, const double *inv, int lane)
+{
+	const int g = lane >> 4, q = lane & 15;
+	d4_t X[J1 - J0];
+#pragma unroll
+	for (int j = J0; j < J1; j++) {
+		d4_t acc;
+#pragma unroll
+		for (int r = 0; r < 4; r++) acc[r] = A[(row0 + q) * LD + 16 * j + g + 4 * r];
+#pragma unroll
+		for (int i = J0; i < j; i++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) {
+				const double a = -A[(16 * j + q) * LD + 16 * i + g + 4 * r];
+				acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[i - J0][r], acc, 0, 0, 0);
+			}
+		d4_t xj = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			const double a = inv[j * 256 + q * 16 + g + 4 * r];
+			xj = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[r], xj, 0, 0, 0);
+		}
+		X[j - J0] = xj;
+	}
+	// the X tiles are written only after every read of this wave's rows (acc loads above) is done
+#pragma unroll
+	for (int j = J0; j < J1; j++)
+#pragma unroll
+		for (int r = 0; r < 4; r++) A[(row0 + q) * LD + 16 * j + g + 4 * r] = X[j - J0][r];
+}
+
+__global__ __launch_bounds__(256) void leaf128_factor_kernel(double *T, long ld, int c0, int *info, double *dinv)
+{
+	__shared__ double A[L2 * LP2];
+	__shared__ double Inv[8 * 256];
+	__shared__ double Xs[4][16 * 17];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int g = lane >> 4, q = lane & 15;
+	double *D = T + (long)c0 * ld + c0;
+	// stage the lower block rows (row r: columns 0..127 -- whole rows keep the loads 512-byte contiguous)
+#pragma unroll 4
+	for (int u = 0; u < 32; u++) {
+		const int r = wave + 4 * u;
+		const d2_t v = *reinterpret_cast<const d2_t *>(D + (long)r * ld + 2 * lane);
+		*reinterpret_cast<d2_t *>(&A[r * LP2 + 2 * lane]) = v;
+	}
+	__syncthreads();
+	int bad = 0;
+	double *A11 = A, *A22 = A + 64 * LP2 + 64;
+	// ---- A11 = chol
+	if (wave == 0) panel_factor<0, LP2>(A11, lane, bad, 0);
+	__syncthreads();
+	panel_update<0, LP2>(A11, wave, lane);
+	__syncthreads();
+	if (wave == 0) panel_factor<1, LP2>(A11, lane, bad, 0);
+	__syncthreads();
+	panel_update<1, LP2>(A11, wave, lane);
+	__syncthreads();
+	if (wave == 0) panel_factor<2, LP2>(A11, lane, bad, 0);
+	__syncthreads();
+	panel_update<2, LP2>(A11, wave, lane);
+	__syncthreads();
+	if (wave == 0) panel_factor<3, LP2>(A11, lane, bad, 0);
+	__syncthreads();
+	// ---- inverses of L11's diagonal blocks, then A21 <- A21 L11^-T (wave w: rows 64+16w..)
+	tri_inverse16_to<LP2>(A, 16 * wave, Xs[wave], lane, Inv + wave * 256, 16);
+	__syncthreads();
+	solve_rows_lds<0, 4, LP2>(A, 64 + 16 * wave, Inv, lane);
+	__syncthreads();
+	// ---- A22 -= A21 A21^T : lower tiles (ti,tj) of the 64x64 block, K = 64
+	{
+		int t = 0;
+#pragma unroll
+		for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+			for (int tj = 0; tj <= ti; tj++) {
+				if ((t & 3) == wave) {
+					d4_t c;
+#pragma unroll
+					for (int r = 0; r < 4; r++) c[r] = A22[(16 * ti + g + 4 * r) * LP2 + 16 * tj + q];
+#pragma unroll
+					for (int kb = 0; kb < 4; kb++)
+#pragma unroll
+						for (int r = 0; r < 4; r++) {
+							const double a = -A[(64 + 16 * ti + q) * LP2 + 16 * kb + g + 4 * r];
+							const double b = A[(64 + 16 * tj + q) * LP2 + 16 * kb + g + 4 * r];
+							c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+						}
+#pragma unroll
+					for (int r = 0; r < 4; r++) A22[(16 * ti + g + 4 * r) * LP2 + 16 * tj + q] = c[r];
+				}
+				t++;
+			}
+	}
+	__syncthreads();
+	// ---- A22 = chol
+	if (wave == 0) panel_factor<0, LP2>(A22, lane, bad, 64);
+	__syncthreads();
+	panel_update<0, LP2>(A22, wave, lane);
+	__syncthreads();
+	if (wave == 0) panel_factor<1, LP2>(A22, lane, bad, 64);
+	__syncthreads();
+	panel_update<1, LP2>(A22, wave, lane);
+	__syncthreads();
+	if (wave == 0) panel_factor<2, LP2>(A22, lane, bad, 64);
+	__syncthreads();
+	panel_update<2, LP2>(A22, wave, lane);
+	__syncthreads();
+	if (wave == 0) panel_factor<3, LP2>(A22, lane, bad, 64);
+	__syncthreads();
+	tri_inverse16_to<LP2>(A, 64 + 16 * wave, Xs[wave], lane, Inv + (4 + wave) * 256, 16);
+	if (tid == 0 && bad) atomicMin(info, c0 + bad);
+	__syncthreads();
+	// ---- write L (lower triangle) and the eight inverted diagonal blocks
+#pragma unroll 4
+	for (int u = 0; u < 32; u++) {
+		const int r = wave + 4 * u;
+		if (lane <= r) D[(long)r * ld + lane] = A[r * LP2 + lane];
+		if (lane + 64 <= r) D[(long)r * ld + lane + 64] = A[r * LP2 + lane + 64];
+	}
+	for (int e = tid; e < 8 * 256; e += 256) dinv[e] = Inv[e];
+}
+
+__global__ __launch_bounds__(256) void leaf128_solve_kernel(double *T, long ld, int c0, int m_below, const double *dinv)
+{
+	__shared__ double M[L2 * LP2];
+	__shared__ double Inv[8 * 256];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int g = lane >> 4, q = lane & 15;
+	const int prow0 = (blockIdx.x * 4 + wave) * 16;
+	int prow = prow0 + q;
+	const bool valid = prow < m_below;
+	if (!valid) prow = m_below - 1;
+	double *bp = T + (long)(c0 + L2 + prow) * ld + c0;
+	d4_t R[8];
+#pragma unroll
+	for (int j = 0; j < 8; j++)
+#pragma unroll
+		for (int r = 0; r < 4; r++) R[j][r] = bp[16 * j + g + 4 * r];
+	{
+		const double *D = T + (long)c0 * ld + c0;
+#pragma unroll 8
+		for (int u = 0; u < 32; u++) {
+			const int r = wave + 4 * u;
+			const d2_t v = *reinterpret_cast<const d2_t *>(D + (long)r * ld + 2 * lane);
+			*reinterpret_cast<d2_t *>(&M[r * LP2 + 2 * lane]) = v;
+		}
+		for (int e = tid; e < 8 * 256; e += 256) Inv[e] = dinv[e];
+	}
+	__syncthreads();
+	if (prow0 >= m_below) return;
+	d4_t X[8];
+	// left half: dependent chain
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		d4_t acc = R[j];
+#pragma unroll
+		for (int i = 0; i < j; i++)
+#pragma unroll
+			for (int r = 0; r < 4; r++)
+				acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-M[(16 * j + q) * LP2 + 16 * i + g + 4 * r], X[i][r], acc, 0, 0, 0);
+		d4_t xj = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+		for (int r = 0; r < 4; r++) xj = __builtin_amdgcn_mfma_f64_16x16x4f64(Inv[j * 256 + q * 16 + g + 4 * r], acc[r], xj, 0, 0, 0);
+		X[j] = xj;
+	}
+	// cross update R_j -= L_ji X_i (j = 4..7, i = 0..3): four independent accumulators, i outermost
+#pragma unroll
+	for (int i = 0; i < 4; i++)
+#pragma unroll
+		for (int r = 0; r < 4; r++)
+#pragma unroll
+			for (int j = 4; j < 8; j++)
+				R[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-M[(16 * j + q) * LP2 + 16 * i + g + 4 * r], X[i][r], R[j], 0, 0, 0);
+	// right half chain
+#pragma unroll
+	for (int j = 4; j < 8; j++) {
+		d4_t acc = R[j];
+#pragma unroll
+		for (int i = 4; i < j; i++)
+#pragma unroll
+			for (int r = 0; r < 4; r++)
+				acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-M[(16 * j + q) * LP2 + 16 * i + g + 4 * r], X[i][r], acc, 0, 0, 0);
+		d4_t xj = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+		for (int r = 0; r < 4; r++) xj = __builtin_amdgcn_mfma_f64_16x16x4f64(Inv[j * 256 + q * 16 + g + 4 * r], acc[r], xj, 0, 0, 0);
+		X[j] = xj;
+	}
+	if (valid) {
+#pragma unroll
+		for (int j = 0; j < 8; j++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) bp[16 * j + g + 4 * r] = X[j][r];
+	}
+}
+
+hipError_t launch_leaf128(hipStream_t s, double *T, long ld, int c0, int m_below, int *info, double *dinv)
+{
+	hipLaunchKernelGGL(leaf128_factor_kernel, dim3(1), dim3(256), 0, s, T, ld, c0, info, dinv);
+	if (m_below > 0)
+		hipLaunchKernelGGL(leaf128_solve_kernel, dim3((m_below + 63) / 64), dim3(256), 0, s, T, ld, c0, m_below, dinv);
+	return hipGetLastError();
 }
 
 hipError_t launch_leaf(hipStream_t s, double *T, long ld, int c0, int m_below, int *info)
