@@ -109,11 +109,18 @@ def main():
 
     rank, world_size, local_rank = shard.world()
     distributed = world_size > 1
+    backend = os.environ.get("BENCH_BACKEND", "nccl")     # "gloo": rehearse the N>1 path with ranks sharing one GPU
+    ndev = max(1, torch.cuda.device_count())
+    dev_index = local_rank % ndev
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+    tdev = "cuda" if backend == "nccl" else "cpu"
     ngpus = world_size
 
     def barrier():
@@ -127,7 +134,7 @@ def main():
     seed = 20261003 + 2
     K, W = args.steps, args.warmup
 
-    dev = local_rank if distributed else 0
+    dev = dev_index if distributed else 0
     X, y = synth.design(N, d, seed)
     nstreams = max(1, args.streams)
     ctxs = [abi.Context(dev) for _ in range(nstreams)]      # one HIP stream + HBM workspace each
@@ -143,7 +150,7 @@ def main():
     if rank == 0:
         from oracle import oracle as O
         Xg, yg = synth.design(512, d, seed)
-        g = abi.Context(local_rank if distributed else 0)
+        g = abi.Context(dev)
         g.set_model(kind, order, Xg, yg)
         thg = synth.default_thetas(kind, d)
         got = g.loglik(thg)
@@ -177,7 +184,7 @@ def main():
     for l in lasts:
         assert l["status"] == 0 and np.isfinite(l["value"]), l
     if distributed:
-        tt = torch.tensor([tA], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([tA], dtype=torch.float64, device=tdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         tA = float(tt.item())
         # the single collective of the path: gather (value, thetas...) per rank, arg-max on every rank
@@ -206,7 +213,7 @@ def main():
         barrier()
         tB = time.perf_counter() - t0
         if distributed:
-            tt = torch.tensor([tB], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([tB], dtype=torch.float64, device=tdev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             tB = float(tt.item())
         mean = ctx.download(dm, (per,))
@@ -223,9 +230,16 @@ def main():
             ctx.loglik_enqueue(theta(2000 + i))
         p = ctx.prof_end()
         ach = p["flops"] / (p["ms"] * 1e-3) / 1e12
+        # HBM bytes per launch from the PMC passes committed under profiles/ (separate rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE runs of the same evaluation; FETCH_SIZE is the raw counter, see the .txt next to it)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+        if args.workload == "c3" and os.path.exists(tpath):
+            tj = json.load(open(tpath))["gemm_nt_kernel"]
+            traffic = (tj["fetch_bytes_raw"] + tj["write_bytes"]) / tj["launches"]
         roof = {"bound": "mfma", "kernel": "gemm_nt_kernel (potrf trailing update, v_mfma_f64_16x16x4_f64)",
                 "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS,
-                "traffic": None, "launches": p["n"], "avg_launch_us": p["ms"] * 1e3 / max(p["n"], 1),
+                "traffic": traffic, "launches": p["n"], "avg_launch_us": p["ms"] * 1e3 / max(p["n"], 1),
                 "flops_per_eval": p["flops"] / 3}
         ctx.prof_begin(abi.PROF_POTRF)
         for i in range(3):
