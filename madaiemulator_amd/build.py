@@ -21,6 +21,7 @@ INCLUDE = os.path.join(ROOT, "include")
 HIP_LIB = os.path.join(LIBDIR, "libgpemu_hip.so")
 HOST_LIB = os.path.join(LIBDIR, "libEmuMI.so")
 CLI_BIN = os.path.join(LIBDIR, "interactive_emulator")
+EPP_LIB = os.path.join(LIBDIR, "libEmuPlusPlusMI.so")
 
 
 def _newer(target, sources):
@@ -69,6 +70,13 @@ def build_host(force=False, verbose=False):
     if force or _newer(HOST_LIB, deps + [HIP_LIB]):
         cmd = ["gcc", "-std=gnu99", "-O2", "-fPIC", "-shared", "-Wall", "-I", INCLUDE, "-I", HOST_SRC,
                "-o", HOST_LIB] + lib_srcs + ["-L", LIBDIR, "-lgpemu_hip", "-Wl,-rpath,$ORIGIN", "-lm", "-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    cpp = os.path.join(HOST_SRC, "EmuPlusPlus.cpp")
+    if os.path.exists(cpp) and (force or _newer(EPP_LIB, deps + [cpp, HOST_LIB])):
+        cmd = ["g++", "-std=c++11", "-O2", "-fPIC", "-shared", "-Wall", "-I", INCLUDE, "-I", HOST_SRC, "-o", EPP_LIB, cpp,
+               "-L", LIBDIR, "-lEmuMI", "-lgpemu_hip", "-Wl,-rpath,$ORIGIN", "-lm", "-lpthread"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -193,6 +193,16 @@ void evalFnGradMulti(const gsl_vector *theta_vec, void *params_in, double *fnval
 	double *g = (double *)malloc(sizeof(double) * (size_t)(nthetas - 1));
 	int info = 0;
 	int rc = gpemu_loglik_grad(ctx, th, nthetas, fnval, NULL, NULL, g, &info);
+	if (rc == GPEMU_ERR_NOT_PD) {
+		/* The reference would return GSL_NAN from evalFnMulti and then exit(EXIT_FAILURE) inside gradFnMulti
+		 * (maxmultimin.c:349,495) -- a line-search trial point that is numerically not positive definite kills
+		 * the whole training run.  Here the pair reports NaN value AND NaN gradient and the line search backs off. */
+		note_not_pd("evalFnGradMulti", th, nthetas);
+		*fnval = GSL_NAN;
+		for (int i = 0; i < nthetas - 1; i++) gsl_vector_set(grad_vec, i, GSL_NAN);
+		free(g); free(th);
+		return;
+	}
 	if (rc) grad_failure(ctx, rc, th, nthetas);
 	for (int i = 0; i < nthetas - 1; i++) gsl_vector_set(grad_vec, i, g[i]);
 	free(g); free(th);

@@ -178,6 +178,11 @@ void emulate_point_multi_pca(multi_emulator *emu, gsl_vector *the_point, gsl_vec
 /* extension: batched form of the two calls above; outputs are npoints x nt (or x nr) row-major */
 void emulate_points_multi(multi_emulator *emu, gsl_matrix *points, int pca_space, double *mean_out, double *var_out);
 
+/* ---- libRbind/rbind.h: the batched likelihood entry point, R-free (rbind.c:626-724) ---------------- */
+void callEvalLhoodList(double *xmodel_in, int *nparams_in, double *pointList_in, int *nevalPoints_in,
+                       double *training_in, int *nmodelPoints_in, int *nthetas_in, double *answer,
+                       int *cov_fn_index_in, int *regression_order_in);
+
 /* ---- knobs of this implementation (not in the reference) ------------------------ */
 void gpemu_host_set_device(int device);          /* HIP device used by contexts created from this thread on */
 void gpemu_host_set_seed(unsigned long seed);    /* 0 = /dev/urandom as the reference (estimate_threaded.c:159) */

@@ -186,6 +186,61 @@ def test_multi_output_pca_snapshot_and_backprojection(driver, tmp_path):
     assert np.max(np.abs(pred[:, :, 0] - Y[:10])) < 0.2
 
 
+@pytest.mark.gpu
+def test_call_eval_lhood_list_without_r():
+    """libRbind's batched likelihood entry (rbind.c:626-724): flat .C() signature, column-major arrays"""
+    import ctypes as C
+    build.build_all()
+    C.CDLL(build.HIP_LIB, mode=C.RTLD_GLOBAL)
+    lib = C.CDLL(build.HOST_LIB)
+    X, Y = synth.read_input_model_file(TWOD)
+    y = Y[:, 0]
+    N, d = X.shape
+    nthetas = d + 2
+    rows = np.array([[-3.0, -1.0, -0.7, 0.0], [-4.0, -0.5, -0.9, 0.0], [-2.5, -1.5, -0.2, 0.0]])   # {nug, lengths..., unused}
+    ans = np.zeros(len(rows))
+    dp = C.POINTER(C.c_double)
+    ip = lambda v: C.byref(C.c_int(v))
+    xin = np.asfortranarray(X).ravel(order="F").copy()
+    pin = np.asfortranarray(rows).ravel(order="F").copy()
+    lib.callEvalLhoodList(xin.ctypes.data_as(dp), ip(d), pin.ctypes.data_as(dp), ip(len(rows)), y.ctypes.data_as(dp),
+                          ip(N), ip(nthetas), ans.ctypes.data_as(dp), ip(1), ip(1))
+    for r, a in zip(rows, ans):
+        assert a == pytest.approx(O.eval_fn_multi(1, 1, X, y, r[:nthetas - 1])["value"], rel=RTOL)
+
+
+@pytest.mark.gpu
+def test_emuplusplus_class(tmp_path):
+    """the C++ query class: QueryEmulator returns means and sqrt(variance) (EmuPlusPlus.cpp:137-178)"""
+    build.build_all()
+    exe = str(tmp_path / "emupp_driver")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-I", os.path.join(ROOT, "include"), "-I", build.HOST_SRC, "-o", exe,
+                           os.path.join(ROOT, "tests", "c", "emupp_driver.cpp"), "-L", build.LIBDIR, "-lEmuPlusPlusMI",
+                           "-lEmuMI", "-lgpemu_hip", f"-Wl,-rpath,{build.LIBDIR}", "-lm"])
+    snap = tmp_path / "snap"
+    env = dict(os.environ, GPEMU_SEED="99", GPEMU_RESTARTS="2")
+    run([build.CLI_BIN, "estimate_thetas", MULTI, str(snap), "--regression_order=0"], env=env)
+    X, Y = synth.read_input_model_file(MULTI)
+    qf = tmp_path / "q.dat"
+    np.savetxt(qf, np.vstack([X[:4], synth.queries(6, 3, 1) * 0.1]), fmt="%.17g")
+    res = parse(run([exe, str(snap), str(qf)]))
+    cli = np.array(run([build.CLI_BIN, "interactive_mode", str(snap), "-q"], stdin=open(qf)).split(), float).reshape(10, -1, 2)
+    single = np.array(res["single"]).reshape(10, -1, 2)
+    batch = np.array(res["batch"]).reshape(10, -1, 2)
+    assert res["info"][0][:2] == [3.0, 6.0]
+    assert np.array_equal(single, batch, equal_nan=True)
+    assert np.allclose(single[:, :, 0], cli[:, :, 0], rtol=1e-12, atol=1e-12)
+    # Errors = sqrt(variance): at a training point the variance is 0 up to rounding, sqrt of a tiny negative is NaN
+    # exactly as in the reference (EmuPlusPlus.cpp:176)
+    ok = cli[:, :, 1] > 0
+    assert ok.sum() > 30
+    assert np.allclose(single[:, :, 1][ok] ** 2, cli[:, :, 1][ok], rtol=1e-9, atol=1e-14)
+    rest = single[:, :, 1][~ok]                      # the CLI prints %.17f: variances below 5e-18 read as 0
+    assert np.all(np.isnan(rest) | (np.nan_to_num(rest) < 1e-6))
+    pca = parse(run([exe, str(snap), str(qf), "pca"]))
+    assert int(pca["info"][0][1]) == int(open(snap).read().split()[1])          # number_outputs == nr in PCA mode
+
+
 def parse_snapshot(toks):
     """MODEL_SNAPSHOT_FILE grammar"""
     it = iter(toks)
