@@ -374,3 +374,70 @@ def test_error_codes(gpu_ctx):
         ctx.set_model(1, 3, np.zeros((40, 30)), np.zeros(40))
     assert e.value.code == abi.ERR_ARG                                     # 1 + nregression_fns > 64
     ctx.close()
+
+
+# ------------------------------------------------------------------ BASELINE.json configs[3] and configs[4]
+def test_config4_eight_pca_components_n4096_d16(gpu_ctx):
+    """N=4096, d=16, multi-output model whose PCA keeps 8 components: the 8 scalar GPs share the design (one
+    upload) and differ in the training vector; each likelihood is checked against one LAPACK factorisation."""
+    from madaiemulator_amd import shard
+    N, d, nt = 4096, 16, 9
+    X, y = synth.design(N, d, 20261003 + 3)
+    Y = synth.multi_outputs(X, y, nt)
+    Yc = Y - Y.mean(axis=0)
+    w, U = np.linalg.eigh(Yc.T @ Yc / N)
+    order = np.argsort(w)[::-1][:8]
+    Z = Yc @ U[:, order] / np.sqrt(w[order])                 # multi_modelstruct.c:295-316
+    th = synth.default_thetas(1, d)
+    gpu_ctx.set_model(1, 1, X, Z[:, 0])
+    Cm = gpu_ctx.cov_matrix(th)
+    cf = sl.cho_factor(Cm, lower=True, overwrite_a=True, check_finite=False)
+    logdet = 2.0 * np.log(np.diag(cf[0])).sum()
+    H = O.hmatrix(1, X)
+    AH = sl.cho_solve(cf, H, check_finite=False)
+
+    def component(c):
+        gpu_ctx.set_training(Z[:, c])
+        r = gpu_ctx.loglik(th)
+        assert r["status"] == 0
+        return [r["value"], r["sigma2"]]
+
+    got = shard.farm_components(component, 8, 2, rank=0, world_size=1)
+    for c in range(8):
+        z = Z[:, c]
+        Az = sl.cho_solve(cf, z, check_finite=False)
+        beta = np.linalg.solve(H.T @ AH, H.T @ Az)
+        r = z - H @ beta
+        quad = r @ sl.cho_solve(cf, r, check_finite=False)
+        ref = -(-0.5 * logdet - N / 2.0 * 1.83788 - 0.5 * quad)
+        assert got[c, 0] == pytest.approx(ref, rel=RTOL)
+        assert got[c, 1] == pytest.approx(z @ sl.cho_solve(cf, r, check_finite=False) / N, rel=RTOL)
+
+
+def test_config5_n16384_powexp(gpu_ctx):
+    """N=16384, d=8, pow-exp (one rank's share of the hyper-parameter search): an evaluation against LAPACK,
+    theta sensitivity, and the y-scaling property."""
+    N, d = 16384, 8
+    X, y = synth.design(N, d, 20261003 + 4)
+    gpu_ctx.set_model(1, 0, X, y)
+    th = synth.default_thetas(1, d)
+    a = gpu_ctx.loglik(th)
+    assert a["status"] == 0 and a["info"] == 0 and np.isfinite(a["value"])
+    Cm = gpu_ctx.cov_matrix(th)
+    cf = sl.cho_factor(Cm, lower=True, overwrite_a=True, check_finite=False)
+    logdet = 2.0 * np.log(np.diag(cf[0])).sum()
+    H = np.ones((N, 1))
+    AyH = sl.cho_solve(cf, np.column_stack([y, H]), check_finite=False)
+    beta = (H.T @ AyH[:, 0]) / (H.T @ AyH[:, 1])
+    r = y - H[:, 0] * beta[0]
+    quad = r @ sl.cho_solve(cf, r, check_finite=False)
+    del Cm, cf
+    assert a["logdet"] == pytest.approx(logdet, rel=RTOL)
+    assert a["beta"][0] == pytest.approx(beta[0], rel=1e-7, abs=1e-9)
+    assert a["quad"] == pytest.approx(quad, rel=RTOL)
+    assert a["value"] == pytest.approx(-(-0.5 * logdet - N / 2.0 * 1.83788 - 0.5 * quad), rel=RTOL)
+    b = gpu_ctx.loglik(synth.perturbed_thetas(1, d, 3, 0))
+    assert b["value"] != a["value"] and np.isfinite(b["value"])
+    gpu_ctx.set_training(3.0 * y)
+    c = gpu_ctx.loglik(th)
+    assert c["quad"] == pytest.approx(9.0 * a["quad"], rel=1e-12) and c["logdet"] == a["logdet"]
