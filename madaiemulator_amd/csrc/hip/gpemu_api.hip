@@ -308,15 +308,19 @@ static int make_cov_params(gpemu_ctx *ctx, const double *thetas, int nthetas, Co
 		p->amp = exp(thetas[0]);
 		p->nug = exp(thetas[1]);
 		p->eps = 0.0000000001;
+		double wmax = 0.0;
 		for (int k = 0; k < ctx->d; k++) {
 			double r = exp(thetas[k + 2]);
-			p->w[k] = -0.5 / (r * r);
+			p->w[k] = sqrt(0.5) / r;
+			if (p->w[k] > wmax) wmax = p->w[k];
 		}
+		p->cand = 2.0 * ctx->d * (p->eps * wmax) * (p->eps * wmax) + 1e-300;
 	} else {
 		p->amp = thetas[0];
 		p->nug = thetas[1];
 		p->eps = 0.0000000000000001;
 		p->w[0] = 1.0 / exp(thetas[2]);
+		p->cand = 2.0 * ctx->d * (p->eps * p->w[0]) * (p->eps * p->w[0]) + 1e-300;
 	}
 	return GPEMU_OK;
 }

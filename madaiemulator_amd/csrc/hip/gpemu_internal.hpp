@@ -19,14 +19,18 @@ constexpr int GEMM_BK = 16;
 inline int round_up(int x, int m) { return ((x + m - 1) / m) * m; }
 
 // Covariance parameters handed to kernels by value.
-// pow-exp (emulator.c:101-152): amp = exp(t0), nug = exp(t1), w[k] = -0.5/exp(t_{k+2})^2, eps = 1e-10
-// Matern  (emulator.c:344-386, 438-480): amp = t0, nug = t1, w[0] = 1/exp(t2), eps = 1e-16
+// pow-exp (emulator.c:101-152): amp = exp(t0), nug = exp(t1), w[k] = sqrt(0.5)/exp(t_{k+2}) (coordinate scale:
+//   exponent = -sum ((x_k-y_k) w_k)^2), eps = 1e-10
+// Matern  (emulator.c:344-386, 438-480): amp = t0, nug = t1, w[0] = 1/exp(t2) (all coordinates), eps = 1e-16
+// cand: upper bound of sum ((x_k-y_k) w_k)^2 over pairs with every |x_k-y_k| < eps (plus rounding slack); only
+//   those pairs run the exact per-coordinate "same point" test of the nugget rule.
 struct CovParams {
 	int kind;
 	int d;
 	double amp;
 	double nug;
 	double eps;
+	double cand;
 	double w[GPEMU_MAX_PARAMS];
 };
 

@@ -13,28 +13,44 @@ namespace gpemu {
 constexpr int FT = 64;            // fill tile edge
 constexpr int DCH = 8;            // dimensions handled per register chunk
 
-__device__ __forceinline__ double cov_finalize(const CovParams &p, double acc, bool same)
+// VALU fp64 issues at 16 cycles per wave-instruction on gfx950 (measured), so the fill is bound by its
+// fp64 operation count, not by the 8 bytes it writes per element.  Everything below is about fewer fp64 ops:
+// coordinates are pre-scaled while staging (2 ops per dimension), exp and sqrt are short table / Newton
+// forms, and the exact "same point" test of the nugget rule runs only for pairs whose distance makes it possible.
+
+// exp(x) for x <= 0: x = (32 m + j) ln2/32 + r, |r| <= ln2/64; exp = 2^m * 2^(j/32) * P6(r).  ~1 ulp.
+__device__ __forceinline__ double fast_exp_neg(double x, const double *tab /* LDS: 2^(j/32), j < 32 */)
 {
-	double c;
-	if (p.kind == GPEMU_POWEREXP) {
-		c = exp(acc) * p.amp;                                   // emulator.c:141
-	} else {
-		const double dist = sqrt(acc);                          // emulator.c:373 / :467
-		const double s = dist * p.w[0];                          // distance / rho
-		if (p.kind == GPEMU_MATERN32) {
-			const double root3 = 1.732050808;                   // emulator.c:359 (literal)
-			c = (dist > 0.0) ? p.amp * (1 + root3 * s) * exp(-root3 * s) : p.amp;
-		} else {
-			const double root5 = 2.236067978;                   // emulator.c:452 (literal)
-			c = (dist > 0.0) ? p.amp * (1 + root5 * s + (5.0 / 3.0) * s * s) * exp(-root5 * s) : p.amp;
-		}
-	}
-	if (same) c += p.nug;                                       // emulator.c:147-150 / :382-384 / :476-478
-	return c;
+	x = fmax(x, -800.0);
+	const double kf = rint(x * 46.166241308446828384);              // 32 / ln 2
+	double r = fma(kf, -2.16608493865351192653e-02, x);             // ln2_hi / 32 (exact product with kf)
+	r = fma(kf, -5.96317165397058693751e-12, r);                    // ln2_lo / 32
+	const int ki = (int)kf;
+	double p = fma(r, 1.0 / 720.0, 1.0 / 120.0);
+	p = fma(p, r, 1.0 / 24.0);
+	p = fma(p, r, 1.0 / 6.0);
+	p = fma(p, r, 0.5);
+	p = fma(p, r, 1.0);
+	p = fma(p, r, 1.0);
+	return ldexp(tab[ki & 31] * p, ki >> 5);
+}
+
+// sqrt(a), a >= 0: hardware rsqrt estimate + two Heron corrections
+__device__ __forceinline__ double fast_sqrt(double a)
+{
+	const double y = __builtin_amdgcn_rsq(a);
+	double s = a * y;
+	const double h = 0.5 * y;
+	s = fma(fma(-s, s, a), h, s);
+	s = fma(fma(-s, s, a), h, s);
+	return (a > 0.0) ? s : 0.0;
 }
 
 // out[r][c] = cov(Xr[r], Xc[c]);  rows/cols beyond nr/nc (padding up to the
 // launch grid) get identity (square factorisation matrix) or zero.
+// p.w[k] is the per-dimension scale applied while staging: pow-exp sqrt(0.5)/r_k (so the exponent is
+// -sum d'^2), Matern 1/rho (so sqrt(sum d'^2) is distance/rho).  p.eps is the reference's per-coordinate
+// "same point" threshold on the UNSCALED coordinates; p.cand bounds sum d'^2 for pairs that can pass it.
 __global__ __launch_bounds__(256) void cov_fill_kernel(double *out, long ld, const double *Xr, int nr,
                                                        const double *Xc, int nc, int d, CovParams p, int mode)
 {
@@ -42,13 +58,15 @@ __global__ __launch_bounds__(256) void cov_fill_kernel(double *out, long ld, con
 	if ((mode & FILL_LOWER) && tc > tr) return;
 
 	__shared__ double xr_s[FT * (GPEMU_MAX_PARAMS + 1)];
+	__shared__ double tab[32];
 	const int tid = threadIdx.x;
 	const int sd = d + 1;
 	for (int e = tid; e < FT * d; e += 256) {
 		int r = e / d, k = e % d;
 		int gr = tr * FT + r;
-		xr_s[r * sd + k] = (gr < nr) ? Xr[(long)gr * d + k] : 0.0;
+		xr_s[r * sd + k] = (gr < nr) ? Xr[(long)gr * d + k] * p.w[(p.kind == GPEMU_POWEREXP) ? k : 0] : 0.0;
 	}
+	if (tid < 32) tab[tid] = exp2((double)tid * (1.0 / 32.0));
 	__syncthreads();
 
 	const int col = tc * FT + (tid & 63);
@@ -56,17 +74,15 @@ __global__ __launch_bounds__(256) void cov_fill_kernel(double *out, long ld, con
 	const bool colv = col < nc;
 
 	double acc[16];
-	int cnt[16];
 #pragma unroll
-	for (int t = 0; t < 16; t++) { acc[t] = 0.0; cnt[t] = 0; }
+	for (int t = 0; t < 16; t++) acc[t] = 0.0;
 
 	for (int k0 = 0; k0 < d; k0 += DCH) {
-		double xc[DCH], wk[DCH];
+		double xc[DCH];
 #pragma unroll
 		for (int k = 0; k < DCH; k++) {
 			const bool kv = (k0 + k) < d;
-			xc[k] = (kv && colv) ? Xc[(long)col * d + k0 + k] : 0.0;
-			wk[k] = kv ? ((p.kind == GPEMU_POWEREXP) ? p.w[k0 + k] : 1.0) : 0.0;
+			xc[k] = (kv && colv) ? Xc[(long)col * d + k0 + k] * p.w[(p.kind == GPEMU_POWEREXP) ? (k0 + k) : 0] : 0.0;
 		}
 #pragma unroll
 		for (int t = 0; t < 16; t++) {
@@ -74,9 +90,8 @@ __global__ __launch_bounds__(256) void cov_fill_kernel(double *out, long ld, con
 #pragma unroll
 			for (int k = 0; k < DCH; k++) {
 				if (k0 + k < d) {
-					const double diff = fabs(xr[k] - xc[k]);
-					acc[t] += wk[k] * diff * diff;
-					cnt[t] += (diff < p.eps) ? 1 : 0;
+					const double diff = xr[k] - xc[k];
+					acc[t] = fma(diff, diff, acc[t]);
 				}
 			}
 		}
@@ -87,8 +102,28 @@ __global__ __launch_bounds__(256) void cov_fill_kernel(double *out, long ld, con
 		const int row = tr * FT + rsub + 4 * t;
 		double v;
 		if (row < nr && colv) {
-			v = cov_finalize(p, acc[t], cnt[t] == d);
-			if ((mode & FILL_CLAMP) && v < 1E-10) v = 0.0;          // emulator.c:588-590
+			const double a = acc[t];
+			if (p.kind == GPEMU_POWEREXP) {
+				v = fast_exp_neg(-a, tab) * p.amp;                                  // emulator.c:133,141
+			} else {
+				const double sdist = fast_sqrt(a);                                  // distance / rho
+				if (p.kind == GPEMU_MATERN32) {
+					const double root3 = 1.732050808;                               // emulator.c:359 (literal)
+					v = p.amp * (1 + root3 * sdist) * fast_exp_neg(-root3 * sdist, tab);
+				} else {
+					const double root5 = 2.236067978;                               // emulator.c:452 (literal)
+					v = p.amp * (1 + root5 * sdist + (5.0 / 3.0) * sdist * sdist) * fast_exp_neg(-root5 * sdist, tab);
+				}
+			}
+			if (a <= p.cand) {
+				// rare: the two points may coincide in every coordinate -> exact test on the raw coordinates
+				// (emulator.c:136-150 / :368-384 / :462-478: nugget wherever ALL |x_k - y_k| < eps)
+				int cnt = 0;
+				for (int k = 0; k < d; k++)
+					cnt += (fabs(Xr[(long)row * d + k] - Xc[(long)col * d + k]) < p.eps) ? 1 : 0;
+				if (cnt == d) v += p.nug;
+			}
+			if ((mode & FILL_CLAMP) && v < 1E-10) v = 0.0;                          // emulator.c:588-590
 		} else {
 			v = ((mode & FILL_IDENT_PAD) && row == col) ? 1.0 : 0.0;
 		}
