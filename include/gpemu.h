@@ -88,6 +88,22 @@ int gpemu_loglik_enqueue(gpemu_ctx *ctx, const double *thetas, int nthetas);
 int gpemu_loglik_collect(gpemu_ctx *ctx, double *neg_loglik, double *sigma2, double *beta,
                          double *logdet, double *quad, int *info);
 
+/* ---- a11 over a list of thetas: callEvalLhoodList (libRbind/rbind.c:626-724) and the
+ * independent restarts of estimate_thetas_threaded (libEmu/estimate_threaded.c:101-113).
+ * nb likelihood evaluations of the SAME model at nb theta vectors (thetas = nb rows of
+ * nthetas), factored in lock-step on the device: every kernel handles all nb matrices, so
+ * the latency-bound panel chain is paid once per batch.  Outputs are arrays of nb (beta:
+ * nb*nreg), any may be NULL; status[b] is what gpemu_loglik would have returned for element b
+ * (GPEMU_OK / GPEMU_ERR_NOT_PD / GPEMU_ERR_REGRESSION) and the function itself returns
+ * GPEMU_OK when the batch ran.  Workspace: nb * (N+64) * N * 8 bytes of HBM. */
+#define GPEMU_MAX_BATCH 64
+int gpemu_loglik_batch(gpemu_ctx *ctx, int nb, const double *thetas, int nthetas,
+                       double *neg_loglik, double *sigma2, double *beta, double *logdet,
+                       double *quad, int *info, int *status);
+int gpemu_loglik_batch_enqueue(gpemu_ctx *ctx, int nb, const double *thetas, int nthetas);
+int gpemu_loglik_batch_collect(gpemu_ctx *ctx, int nb, double *neg_loglik, double *sigma2,
+                               double *beta, double *logdet, double *quad, int *info, int *status);
+
 /* ---- a12: gradFnMulti + getGradientCn (maxmultimin.c:416-550,571-608)
  * grad[nthetas-1] as the reference defines it (literal formulas, SURVEY
  * App. A.3): thetas are the FULL vector with theta[0] ignored (set to 0 for
@@ -131,6 +147,12 @@ int gpemu_sync(gpemu_ctx *ctx);
 #define GPEMU_PROF_POTRF   4   /* whole factorisation (graph launch) */
 int gpemu_prof_begin(gpemu_ctx *ctx, int kernel_class);
 int gpemu_prof_end(gpemu_ctx *ctx, int *nlaunches, double *total_ms, double *flops, double *bytes);
+
+/* Diagnostics: with GPEMU_TRACE=1 in the environment at gpemu_ctx_create, every GEMM / leaf kernel of a
+ * factorisation records its first-workgroup start and last-workgroup end on the device wall clock; this writes
+ * "tag | start_ns end_ns sum_of_workgroup_ns workgroups sum_of_workgroup_shader_clocks" lines for the last factorisation.  Contexts of one GPU share the clock, so the files
+ * of concurrent contexts merge into one timeline (tools/trace_timeline.py). */
+int gpemu_trace_dump(gpemu_ctx *ctx, const char *path);
 
 /* ---- low-level building blocks exported for parity tests ------------ */
 /* C[m*n] = beta*C + alpha * A[m*K] * B[n*K]^T, host row-major buffers */

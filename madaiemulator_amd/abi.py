@@ -33,6 +33,9 @@ SYMBOLS = {
     "gpemu_loglik": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip]),
     "gpemu_loglik_enqueue": (C.c_int, [C.c_void_p, _dp, C.c_int]),
     "gpemu_loglik_collect": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _ip]),
+    "gpemu_loglik_batch": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _ip]),
+    "gpemu_loglik_batch_enqueue": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int]),
+    "gpemu_loglik_batch_collect": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _ip]),
     "gpemu_grad": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _ip]),
     "gpemu_loglik_grad": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _dp, _dp, _dp, _ip]),
     "gpemu_predict_setup": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _ip]),
@@ -46,6 +49,7 @@ SYMBOLS = {
     "gpemu_sync": (C.c_int, [C.c_void_p]),
     "gpemu_prof_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "gpemu_prof_end": (C.c_int, [C.c_void_p, _ip, _dp, _dp, _dp]),
+    "gpemu_trace_dump": (C.c_int, [C.c_void_p, C.c_char_p]),
     "gpemu_test_gemm_nt": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, _dp, _dp, _dp]),
     "gpemu_test_gemm_bench": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, _dp, _dp]),
@@ -173,6 +177,26 @@ class Context:
         return dict(value=v.value, sigma2=s2.value, beta=beta, logdet=ld.value, quad=qd.value, info=info.value,
                     status=rc)
 
+    def loglik_batch_enqueue(self, thetas):
+        th = _a(thetas).reshape(-1, np.shape(thetas)[-1])
+        self._nb = th.shape[0]
+        self._chk(self.L.gpemu_loglik_batch_enqueue(self.h, th.shape[0], _p(th), th.shape[1]))
+
+    def loglik_batch_collect(self):
+        nb = self._nb
+        v, s2, ld, qd = (np.full(nb, np.nan) for _ in range(4))
+        beta = np.full((nb, self.nreg), np.nan)
+        info = np.zeros(nb, dtype=np.int32)
+        status = np.zeros(nb, dtype=np.int32)
+        self._chk(self.L.gpemu_loglik_batch_collect(self.h, nb, _p(v), _p(s2), _p(beta), _p(ld), _p(qd),
+                                                    info.ctypes.data_as(_ip), status.ctypes.data_as(_ip)))
+        return dict(value=v, sigma2=s2, beta=beta, logdet=ld, quad=qd, info=info, status=status)
+
+    def loglik_batch(self, thetas):
+        """nb evaluations in lock-step (thetas: nb x nthetas) -> dict of arrays, as loglik() per element"""
+        self.loglik_batch_enqueue(thetas)
+        return self.loglik_batch_collect()
+
     # -- a12 ---------------------------------------------------------------
     def grad(self, thetas):
         th = _a(thetas)
@@ -252,6 +276,9 @@ class Context:
         n = B.shape[0]
         self._chk(self.L.gpemu_test_gemm_nt(self.h, m, n, k, alpha, beta, _p(A), _p(B), _p(Cm)))
         return Cm
+
+    def trace_dump(self, path):
+        self._chk(self.L.gpemu_trace_dump(self.h, str(path).encode()))
 
     def gemm_bench(self, m, n, k, ld=0, cfg=-1, tri=0, beta=1, reps=5):
         ms, fl = C.c_double(0), C.c_double(0)

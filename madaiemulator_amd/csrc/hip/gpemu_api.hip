@@ -26,7 +26,7 @@ using namespace gpemu;
 
 static int g_leaf128 = 0;                // 128-column fused leaves (env GPEMU_LEAF128=1); measured 3 % slower than 64
 static int g_lookahead = 0;              // two-stream schedule of the outer panels (env GPEMU_LOOKAHEAD=1); see DESIGN.md
-static int g_nb_top = 512;              // width of the right-looking outer panels (env GPEMU_NB_TOP)
+static int g_nb_top = 0;            // outer panel width (env GPEMU_NB_TOP); 0 = automatic: 512 for one matrix, 1024 for a lock-step batch
 constexpr int INFO_NONE = 0x7f7f7f7f;   // "no failed pivot": what hipMemsetAsync(.., 0x7f, ..) leaves in *info
 
 static int fail(gpemu_ctx *ctx, int code, const char *msg)
@@ -63,6 +63,16 @@ struct ProfScope {
 	~ProfScope() { if (on) prof_mark(ctx); }
 };
 
+// GPEMU_TRACE: next {start,end} slot of the per-launch device timestamps (nullptr when tracing is off / full)
+static unsigned long long *trace_slot(gpemu_ctx *ctx, const char *fmt, int a = 0, int b = 0, int c = 0)
+{
+	if (!ctx->dTrace || ctx->trace_next >= ctx->trace_cap) return nullptr;
+	char buf[96];
+	snprintf(buf, sizeof buf, fmt, a, b, c);
+	ctx->trace_tag.push_back(buf);
+	return ctx->dTrace + 8 * (size_t)ctx->trace_next++;
+}
+
 // algorithmic flops of one GEMM call: 2 * (k-range) summed over the output elements the call owns
 // (lower trapezoid for tri; rows of an upper-triangular A start at k = row - kstart_off; rows of a
 // lower-triangular B end at k = col - kend_off)
@@ -85,10 +95,17 @@ static double gemm_flops(const GemmArgs &a)
 	return fl;
 }
 
-static hipError_t gemm(gpemu_ctx *ctx, const GemmArgs &a, hipStream_t stream = nullptr)
+static hipError_t gemm(gpemu_ctx *ctx, const GemmArgs &a_in, hipStream_t stream = nullptr)
 {
-	const double fl = prof_on(ctx, GPEMU_PROF_GEMM) ? gemm_flops(a) : 0.0;
+	GemmArgs a = a_in;
+	a.trace = trace_slot(ctx, "gemm m=%d n=%d k=%d", a.m, a.n, a.k1 - a.k0);
+	const double fl = prof_on(ctx, GPEMU_PROF_GEMM) ? gemm_flops(a) * (a.nbatch > 1 ? a.nbatch : 1) : 0.0;
 	ProfScope ps(ctx, GPEMU_PROF_GEMM, fl, 0.0);
+	if (ps.on) {
+		char buf[96];
+		snprintf(buf, sizeof buf, "gemm m=%d n=%d k=%d tri=%d flops=%.4g", a.m, a.n, a.k1 - a.k0, a.tri, fl);
+		ctx->prof.tag.push_back(buf);
+	}
 	return launch_gemm(stream ? stream : ctx->stream, a);
 }
 
@@ -124,6 +141,17 @@ extern "C" int gpemu_ctx_create(gpemu_ctx **out, int device)
 		// The look-ahead stream is kept off a slice of the chip (GPEMU_RESERVE_CUS, default 32 of 256 CUs) so
 		// that the latency-bound panel kernels of the critical stream do not share MFMA pipes with the bulk
 		// trailing update (measured: sharing slows the 64x64 factor kernel 5x and cancels the overlap).
+		{
+			const char *tr = getenv("GPEMU_TRACE");
+			if (tr && atoi(tr) > 0) {
+				ctx->trace_cap = 4096;
+				if (hipMalloc(&ctx->dTrace, (size_t)ctx->trace_cap * 64) != hipSuccess) { ctx->dTrace = nullptr; ctx->trace_cap = 0; }
+			}
+		}
+		{ const char *lp = getenv("GPEMU_GEMM_LDS_PAD"); if (lp) gpemu::g_gemm_lds_pad = atoi(lp); }
+		{ const char *lp = getenv("GPEMU_GEMM_BIG_TILES"); if (lp && atoi(lp) > 0) gpemu::g_gemm_big_tiles = atoi(lp); }
+		{ const char *lp = getenv("GPEMU_GEMM_BIG_CFG"); if (lp) gpemu::g_gemm_big_cfg = atoi(lp); }
+		{ const char *lp = getenv("GPEMU_LEAF_PRIO"); if (lp) gpemu::g_leaf_prio = atoi(lp); }
 		const char *la0 = getenv("GPEMU_LOOKAHEAD");
 		const bool want_second = la0 ? atoi(la0) != 0 : g_lookahead != 0;   // only the look-ahead schedule uses it
 		int reserve = 32;
@@ -156,6 +184,7 @@ extern "C" int gpemu_ctx_create(gpemu_ctx **out, int device)
 		gpemu_ctx_destroy(ctx);
 		return GPEMU_ERR_HIP;
 	}
+	ctx->batch_cap = 1;
 	const char *ng = getenv("GPEMU_NO_GRAPH");
 	if (ng && ng[0] == '1') ctx->use_graph = false;
 	const char *la = getenv("GPEMU_LOOKAHEAD");
@@ -193,6 +222,7 @@ extern "C" void gpemu_ctx_destroy(gpemu_ctx *ctx)
 	free_model(ctx);
 	for (auto e : ctx->prof.ev) hipEventDestroy(e);
 	if (ctx->dInfo) hipFree(ctx->dInfo);
+	if (ctx->dTrace) hipFree(ctx->dTrace);
 	if (ctx->dDiagInv) hipFree(ctx->dDiagInv);
 	if (ctx->dRes) hipFree(ctx->dRes);
 	if (ctx->hRes) hipHostFree(ctx->hRes);
@@ -243,13 +273,43 @@ extern "C" int gpemu_dev_download(gpemu_ctx *ctx, void *dst, const void *src, si
 // ---------------------------------------------------------------------------
 // model
 // ---------------------------------------------------------------------------
-static int ensure_T(gpemu_ctx *ctx, size_t rows)
+// workspace for nb tall matrices of rows_each rows, packed one after the other (stride rows_each * Np)
+static int ensure_T(gpemu_ctx *ctx, size_t rows_each, int nb = 1)
 {
+	const size_t rows = rows_each * (size_t)nb;
+	ctx->nb = nb;
+	ctx->T_stride = rows_each * (size_t)ctx->Np;
 	if (ctx->T_rows >= rows) return GPEMU_OK;
 	free_graphs(ctx);
-	if (ctx->dT) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); hipFree(ctx->dT); ctx->dT = nullptr; }
-	HIPCHK(ctx, hipMalloc(&ctx->dT, rows * (size_t)ctx->Np * sizeof(double)));
+	if (ctx->dT) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); hipFree(ctx->dT); ctx->dT = nullptr; ctx->T_rows = 0; }
+	if (hipMalloc(&ctx->dT, rows * (size_t)ctx->Np * sizeof(double)) != hipSuccess) {
+		(void)hipGetLastError();
+		ctx->dT = nullptr;
+		return fail(ctx, GPEMU_ERR_HIP, "out of device memory for the factorisation workspace (smaller batch?)");
+	}
 	ctx->T_rows = rows;
+	return GPEMU_OK;
+}
+
+// per-matrix result slots (info word, Gram partials, Gram + log det, pinned mirrors) for a batch of nb
+static int ensure_batch_slots(gpemu_ctx *ctx, int nb)
+{
+	if (nb <= ctx->batch_cap && ctx->dGramPart) return GPEMU_OK;
+	if (nb < ctx->batch_cap) nb = ctx->batch_cap;
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	free_graphs(ctx);                      // captured launches hold the old pointers
+	if (ctx->dInfo) hipFree(ctx->dInfo);
+	if (ctx->dRes) hipFree(ctx->dRes);
+	if (ctx->hRes) hipHostFree(ctx->hRes);
+	if (ctx->hInfo) hipHostFree(ctx->hInfo);
+	if (ctx->dGramPart) hipFree(ctx->dGramPart);
+	ctx->dInfo = nullptr; ctx->dRes = nullptr; ctx->hRes = nullptr; ctx->hInfo = nullptr; ctx->dGramPart = nullptr;
+	HIPCHK(ctx, hipMalloc(&ctx->dInfo, (size_t)nb * sizeof(int)));
+	HIPCHK(ctx, hipMalloc(&ctx->dRes, (size_t)nb * ctx->res_len * sizeof(double)));
+	HIPCHK(ctx, hipHostMalloc((void **)&ctx->hRes, (size_t)nb * ctx->res_len * sizeof(double)));
+	HIPCHK(ctx, hipHostMalloc((void **)&ctx->hInfo, (size_t)nb * sizeof(int)));
+	HIPCHK(ctx, hipMalloc(&ctx->dGramPart, (size_t)nb * (ctx->Np / 64) * ctx->Rp * ctx->Rp * sizeof(double)));
+	ctx->batch_cap = nb;
 	return GPEMU_OK;
 }
 
@@ -272,7 +332,7 @@ extern "C" int gpemu_set_model(gpemu_ctx *ctx, int kind, int order, int N, int d
 	HIPCHK(ctx, hipMalloc(&ctx->dX, (size_t)N * d * sizeof(double)));
 	HIPCHK(ctx, hipMalloc(&ctx->dY, (size_t)N * sizeof(double)));
 	HIPCHK(ctx, hipMalloc(&ctx->dRrows, (size_t)ctx->Rp * ctx->Np * sizeof(double)));
-	HIPCHK(ctx, hipMalloc(&ctx->dGramPart, (size_t)(ctx->Np / 64) * ctx->Rp * ctx->Rp * sizeof(double)));
+	HIPCHK(ctx, hipMalloc(&ctx->dGramPart, (size_t)ctx->batch_cap * (ctx->Np / 64) * ctx->Rp * ctx->Rp * sizeof(double)));
 	HIPCHK(ctx, hipMemcpyAsync(ctx->dX, ctx->hX.data(), (size_t)N * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
 	HIPCHK(ctx, hipMemcpyAsync(ctx->dY, ctx->hY.data(), (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
 	HIPCHK(ctx, launch_build_rrows(ctx->stream, ctx->dRrows, ctx->Np, ctx->Rp, ctx->dX, ctx->dY, N, d, order));
@@ -350,6 +410,7 @@ static hipError_t trailing_update(gpemu_ctx *ctx, int c0, int k, int col_off, in
 	g.k0 = 0; g.k1 = k;
 	g.alpha = -1.0; g.beta = 1;
 	g.tri = 1; g.diag_off = 0;
+	g.nbatch = ctx->nb; g.bsC = g.bsA = g.bsB = (long)ctx->T_stride;
 	return gemm(ctx, g, stream);
 }
 
@@ -370,22 +431,28 @@ static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv)
 	if (n <= LEAF) {
 		const int row_end = base_end + (inv ? c0 + LEAF : 0);
 		ProfScope ps(ctx, GPEMU_PROF_LEAF, 0.0, 0.0);
-		return launch_leaf(ctx->stream, ctx->dT, ld, c0, row_end - (c0 + LEAF), ctx->dInfo);
+		unsigned long long *trf = trace_slot(ctx, "leaf_factor c0=%d", c0);
+		unsigned long long *trs = trace_slot(ctx, "leaf_solve c0=%d m=%d", c0, row_end - (c0 + LEAF));
+		return launch_leaf(ctx->stream, ctx->dT, ld, c0, row_end - (c0 + LEAF), ctx->dInfo, trf, trs, ctx->nb,
+		                   (long)ctx->T_stride);
 	}
-	if (n == 2 * LEAF && g_leaf128) {
+	if (n == 2 * LEAF && g_leaf128 && ctx->nb == 1) {
 		const int row_end = base_end + (inv ? c0 + 2 * LEAF : 0);
 		ProfScope ps(ctx, GPEMU_PROF_LEAF, 0.0, 0.0);
 		return launch_leaf128(ctx->stream, ctx->dT, ld, c0, row_end - (c0 + 2 * LEAF), ctx->dInfo, ctx->dDiagInv);
 	}
-	if (n > g_nb_top) {
-		// right-looking over panels of g_nb_top columns: the trailing update touches the whole remaining
+	// automatic outer panel width: a batch has enough tiles per launch to afford the longer panel chain of a wider
+	// panel and gains from the larger K of its trailing updates (measured: 3.77 -> 3.55 ms per evaluation at 2x16)
+	const int nb_top = g_nb_top > 0 ? g_nb_top : (ctx->nb >= 2 ? 1024 : 512);
+	if (n > nb_top) {
+		// right-looking over panels of nb_top columns: the trailing update touches the whole remaining
 		// matrix (thousands of tiles, K = panel width), which fills the chip far better than the few huge-K
 		// tiles a pure recursion would produce at the top levels
 		const bool profiling = ctx->prof.cls != GPEMU_PROF_NONE && ctx->prof.cls != GPEMU_PROF_POTRF;
 		const bool ahead = g_lookahead && ctx->stream2 && !profiling && c0 == 0 && n == ctx->Np;
 		hipEvent_t ev_bulk_prev = nullptr;
-		for (int c = c0; c < c0 + n; c += g_nb_top) {
-			const int nb = std::min(g_nb_top, c0 + n - c);
+		for (int c = c0; c < c0 + n; c += nb_top) {
+			const int nb = std::min(nb_top, c0 + n - c);
 			hipError_t e = potrf_rec(ctx, c, nb, inv);
 			if (e != hipSuccess) return e;
 			const int rest = c0 + n - (c + nb);
@@ -399,7 +466,7 @@ static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv)
 			// factorisation (a chain of small latency-bound kernels) can start at once, while the bulk of the
 			// update runs beside it on the second stream.  Both pieces touch disjoint column ranges; the piece
 			// of step j on the critical stream waits for the bulk of step j-1, which updated the same columns.
-			const int nb_next = std::min(g_nb_top, rest);
+			const int nb_next = std::min(nb_top, rest);
 			hipEvent_t ev_panel = next_event(ctx);
 			e = hipEventRecord(ev_panel, ctx->stream);
 			if (e != hipSuccess) return e;
@@ -438,16 +505,21 @@ static int run_potrf(gpemu_ctx *ctx, int inv)
 {
 	ctx->ev_next = 0;
 	const bool profiling = ctx->prof.cls == GPEMU_PROF_GEMM || ctx->prof.cls == GPEMU_PROF_LEAF;
-	double fl = (double)ctx->Np * ctx->Np * ctx->Np / 3.0;
+	if (ctx->dTrace) {
+		HIPCHK(ctx, hipMemsetAsync(ctx->dTrace, 0, (size_t)ctx->trace_cap * 64, ctx->stream));   // fresh slots
+	}
+	double fl = (double)ctx->nb * ctx->Np * ctx->Np * ctx->Np / 3.0;
 	ProfScope ps(ctx, GPEMU_PROF_POTRF, fl, 0.0);
 	if (!ctx->use_graph || profiling) {
+		ctx->trace_next = 0; ctx->trace_tag.clear();
 		HIPCHK(ctx, potrf_rec(ctx, 0, ctx->Np, inv));
 		return GPEMU_OK;
 	}
-	gpemu_ctx::GraphKey key{ctx->Np, ctx->Rp, inv};
+	gpemu_ctx::GraphKey key{ctx->Np, ctx->Rp, inv, ctx->nb};
 	auto it = ctx->graphs.find(key);
 	if (it == ctx->graphs.end()) {
 		hipGraph_t graph = nullptr;
+		ctx->trace_next = 0; ctx->trace_tag.clear();
 		HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
 		hipError_t e = potrf_rec(ctx, 0, ctx->Np, inv);
 		hipError_t e2 = hipStreamEndCapture(ctx->stream, &graph);
@@ -465,34 +537,43 @@ static int run_potrf(gpemu_ctx *ctx, int inv)
 	return GPEMU_OK;
 }
 
-// fill C(theta) into T (lower tiles only), load the RHS rows, reset info
-static int stage_matrix(gpemu_ctx *ctx, const CovParams &p, int inv)
+// fill C(theta_b) into matrix b of T (lower tiles only), load the RHS rows, reset the info words
+static int stage_matrices(gpemu_ctx *ctx, const CovParams *ps, int nb, int inv)
 {
 	const int Np = ctx->Np, Rp = ctx->Rp;
-	int rc = ensure_T(ctx, (size_t)Np + Rp + (inv ? Np : 0));
+	int rc = ensure_batch_slots(ctx, nb);
 	if (rc) return rc;
-	{
-		const double nlow = 0.5 * (double)Np * Np;
-		ProfScope ps(ctx, GPEMU_PROF_FILL, 0.0, 8.0 * nlow);
-		HIPCHK(ctx, launch_cov_fill(ctx->stream, ctx->dT, Np, ctx->dX, ctx->N, Np, ctx->dX, ctx->N, Np, ctx->d, p,
-		                            FILL_LOWER | FILL_IDENT_PAD));
+	rc = ensure_T(ctx, (size_t)Np + Rp + (inv ? Np : 0), nb);
+	if (rc) return rc;
+	for (int b = 0; b < nb; b++) {
+		double *Tb = ctx->dT + (size_t)b * ctx->T_stride;
+		{
+			const double nlow = 0.5 * (double)Np * Np;
+			ProfScope ps_(ctx, GPEMU_PROF_FILL, 0.0, 8.0 * nlow);
+			HIPCHK(ctx, launch_cov_fill(ctx->stream, Tb, Np, ctx->dX, ctx->N, Np, ctx->dX, ctx->N, Np, ctx->d, ps[b],
+			                            FILL_LOWER | FILL_IDENT_PAD));
+		}
+		HIPCHK(ctx, hipMemcpyAsync(Tb + (size_t)Np * Np, ctx->dRrows, (size_t)Rp * Np * sizeof(double),
+		                           hipMemcpyDeviceToDevice, ctx->stream));
+		if (inv)
+			HIPCHK(ctx, launch_set_identity_rows(ctx->stream, Tb + (size_t)(Np + Rp) * Np, Np, Np));
 	}
-	HIPCHK(ctx, hipMemcpyAsync(ctx->dT + (size_t)Np * Np, ctx->dRrows, (size_t)Rp * Np * sizeof(double),
-	                           hipMemcpyDeviceToDevice, ctx->stream));
-	if (inv)
-		HIPCHK(ctx, launch_set_identity_rows(ctx->stream, ctx->dT + (size_t)(Np + Rp) * Np, Np, Np));
-	HIPCHK(ctx, hipMemsetAsync(ctx->dInfo, 0x7f, sizeof(int), ctx->stream));
+	HIPCHK(ctx, hipMemsetAsync(ctx->dInfo, 0x7f, (size_t)nb * sizeof(int), ctx->stream));
 	return GPEMU_OK;
 }
 
+static int stage_matrix(gpemu_ctx *ctx, const CovParams &p, int inv) { return stage_matrices(ctx, &p, 1, inv); }
+
 static int enqueue_results(gpemu_ctx *ctx)
 {
-	const int Np = ctx->Np, Rp = ctx->Rp;
-	HIPCHK(ctx, launch_gram_partials(ctx->stream, ctx->dT + (size_t)Np * Np, Np, Np, ctx->nrhs, Rp, ctx->dGramPart));
-	HIPCHK(ctx, launch_finish(ctx->stream, ctx->dGramPart, Np / 64, Rp, ctx->nrhs, ctx->dT, Np, ctx->N, ctx->dRes));
-	HIPCHK(ctx, hipMemcpyAsync(ctx->hRes, ctx->dRes, ((size_t)Rp * Rp + 1) * sizeof(double), hipMemcpyDeviceToHost,
-	                           ctx->stream));
-	HIPCHK(ctx, hipMemcpyAsync(ctx->hInfo, ctx->dInfo, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+	const int Np = ctx->Np, Rp = ctx->Rp, nb = ctx->nb;
+	HIPCHK(ctx, launch_gram_partials(ctx->stream, ctx->dT + (size_t)Np * Np, Np, Np, ctx->nrhs, Rp, ctx->dGramPart, nb,
+	                                 (long)ctx->T_stride));
+	HIPCHK(ctx, launch_finish(ctx->stream, ctx->dGramPart, Np / 64, Rp, ctx->nrhs, ctx->dT, Np, ctx->N, ctx->dRes, nb,
+	                          (long)ctx->T_stride, (long)ctx->res_len));
+	HIPCHK(ctx, hipMemcpyAsync(ctx->hRes, ctx->dRes, ((size_t)(nb - 1) * ctx->res_len + (size_t)Rp * Rp + 1) * sizeof(double),
+	                           hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(ctx, hipMemcpyAsync(ctx->hInfo, ctx->dInfo, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
 	return GPEMU_OK;
 }
 
@@ -531,11 +612,11 @@ static bool small_chol_inverse(std::vector<double> &A, int n)
 
 struct HostLik { double yy, quad, sigma2, logdet; std::vector<double> beta, Q, Hy; int status; };
 
-static HostLik host_likelihood(gpemu_ctx *ctx)
+static HostLik host_likelihood(gpemu_ctx *ctx, int b = 0)
 {
 	HostLik r;
 	const int Rp = ctx->Rp, nreg = ctx->nreg;
-	const double *G = ctx->hRes;
+	const double *G = ctx->hRes + (size_t)b * ctx->res_len;
 	r.logdet = G[Rp * Rp];
 	r.yy = G[0];
 	r.Hy.resize(nreg);
@@ -567,14 +648,22 @@ static HostLik host_likelihood(gpemu_ctx *ctx)
 	return r;
 }
 
-extern "C" int gpemu_loglik_enqueue(gpemu_ctx *ctx, const double *thetas, int nthetas)
+// A batch of nb likelihood evaluations of the same model at nb theta vectors, factored in lock-step: every
+// kernel of the factorisation handles all nb matrices (grid.y), so the latency-bound panel chain is paid once per
+// batch and the trailing updates are nb times larger launches.  This is the device form of the reference's
+// callEvalLhoodList (libRbind/rbind.c:626) and of the optimiser's independent restarts.
+extern "C" int gpemu_loglik_batch_enqueue(gpemu_ctx *ctx, int nb, const double *thetas, int nthetas)
 {
-	if (!ctx || !ctx->dX) return ctx ? fail(ctx, GPEMU_ERR_STATE, "model not set") : GPEMU_ERR_ARG;
-	CovParams p;
-	int rc = make_cov_params(ctx, thetas, nthetas, &p);
-	if (rc) return rc;
+	if (!ctx) return GPEMU_ERR_ARG;
+	if (!ctx->dX) return fail(ctx, GPEMU_ERR_STATE, "model not set");
+	if (nb < 1 || nb > GPEMU_MAX_BATCH) return fail(ctx, GPEMU_ERR_ARG, "batch size must be 1..GPEMU_MAX_BATCH");
+	std::vector<CovParams> ps((size_t)nb);
+	for (int b = 0; b < nb; b++) {
+		int rc = make_cov_params(ctx, thetas ? thetas + (size_t)b * nthetas : nullptr, nthetas, &ps[b]);
+		if (rc) return rc;
+	}
 	HIPCHK(ctx, hipSetDevice(ctx->device));
-	rc = stage_matrix(ctx, p, 0);
+	int rc = stage_matrices(ctx, ps.data(), nb, 0);
 	if (rc) return rc;
 	rc = run_potrf(ctx, 0);
 	if (rc) return rc;
@@ -582,12 +671,11 @@ extern "C" int gpemu_loglik_enqueue(gpemu_ctx *ctx, const double *thetas, int nt
 	return enqueue_results(ctx);
 }
 
-extern "C" int gpemu_loglik_collect(gpemu_ctx *ctx, double *neg_loglik, double *sigma2, double *beta, double *logdet,
-                                    double *quad, int *info)
+// results of element b of the last enqueued batch (after the stream has been synchronised)
+static int collect_one(gpemu_ctx *ctx, int b, double *neg_loglik, double *sigma2, double *beta, double *logdet,
+                       double *quad, int *info)
 {
-	if (!ctx) return GPEMU_ERR_ARG;
-	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-	const int inf = (*ctx->hInfo >= INFO_NONE) ? 0 : *ctx->hInfo;
+	const int inf = (ctx->hInfo[b] >= INFO_NONE) ? 0 : ctx->hInfo[b];
 	if (info) *info = inf;
 	if (inf != 0) {
 		if (neg_loglik) *neg_loglik = NAN;
@@ -597,7 +685,7 @@ extern "C" int gpemu_loglik_collect(gpemu_ctx *ctx, double *neg_loglik, double *
 		if (beta) for (int a = 0; a < ctx->nreg; a++) beta[a] = NAN;
 		return fail(ctx, GPEMU_ERR_NOT_PD, "covariance matrix is not positive definite");
 	}
-	HostLik r = host_likelihood(ctx);
+	HostLik r = host_likelihood(ctx, b);
 	if (beta) for (int a = 0; a < ctx->nreg; a++) beta[a] = r.beta[a];
 	if (sigma2) *sigma2 = r.sigma2;
 	if (logdet) *logdet = r.logdet;
@@ -609,6 +697,44 @@ extern "C" int gpemu_loglik_collect(gpemu_ctx *ctx, double *neg_loglik, double *
 	}
 	if (r.status) return fail(ctx, r.status, "H^T C^-1 H is not positive definite");
 	return GPEMU_OK;
+}
+
+extern "C" int gpemu_loglik_batch_collect(gpemu_ctx *ctx, int nb, double *neg_loglik, double *sigma2, double *beta,
+                                          double *logdet, double *quad, int *info, int *status)
+{
+	if (!ctx) return GPEMU_ERR_ARG;
+	if (nb < 1 || nb != ctx->nb) return fail(ctx, GPEMU_ERR_STATE, "batch size differs from the enqueued batch");
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	for (int b = 0; b < nb; b++) {
+		const int rc = collect_one(ctx, b, neg_loglik ? neg_loglik + b : nullptr, sigma2 ? sigma2 + b : nullptr,
+		                           beta ? beta + (size_t)b * ctx->nreg : nullptr, logdet ? logdet + b : nullptr,
+		                           quad ? quad + b : nullptr, info ? info + b : nullptr);
+		if (status) status[b] = rc;
+	}
+	return GPEMU_OK;
+}
+
+extern "C" int gpemu_loglik_batch(gpemu_ctx *ctx, int nb, const double *thetas, int nthetas, double *neg_loglik,
+                                  double *sigma2, double *beta, double *logdet, double *quad, int *info, int *status)
+{
+	int rc = gpemu_loglik_batch_enqueue(ctx, nb, thetas, nthetas);
+	if (rc) return rc;
+	return gpemu_loglik_batch_collect(ctx, nb, neg_loglik, sigma2, beta, logdet, quad, info, status);
+}
+
+extern "C" int gpemu_loglik_enqueue(gpemu_ctx *ctx, const double *thetas, int nthetas)
+{
+	if (!ctx) return GPEMU_ERR_ARG;
+	return gpemu_loglik_batch_enqueue(ctx, 1, thetas, nthetas);
+}
+
+extern "C" int gpemu_loglik_collect(gpemu_ctx *ctx, double *neg_loglik, double *sigma2, double *beta, double *logdet,
+                                    double *quad, int *info)
+{
+	if (!ctx) return GPEMU_ERR_ARG;
+	if (ctx->nb != 1) return fail(ctx, GPEMU_ERR_STATE, "the enqueued work is a batch: use gpemu_loglik_batch_collect");
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	return collect_one(ctx, 0, neg_loglik, sigma2, beta, logdet, quad, info);
 }
 
 extern "C" int gpemu_loglik(gpemu_ctx *ctx, const double *thetas, int nthetas, double *neg_loglik, double *sigma2,
@@ -966,6 +1092,7 @@ extern "C" int gpemu_prof_begin(gpemu_ctx *ctx, int cls)
 	for (auto e : ctx->prof.ev) hipEventDestroy(e);
 	ctx->prof.ev.clear();
 	ctx->prof.cls = cls; ctx->prof.flops = ctx->prof.bytes = 0; ctx->prof.n = 0;
+	ctx->prof.tag.clear();
 	return GPEMU_OK;
 }
 
@@ -974,11 +1101,14 @@ extern "C" int gpemu_prof_end(gpemu_ctx *ctx, int *nlaunches, double *total_ms, 
 	if (!ctx) return GPEMU_ERR_ARG;
 	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 	double ms = 0.0;
+	const bool dump = getenv("GPEMU_PROF_DUMP") != nullptr;
 	for (size_t i = 0; i + 1 < ctx->prof.ev.size(); i += 2) {
 		float t = 0.f;
 		hipEventElapsedTime(&t, ctx->prof.ev[i], ctx->prof.ev[i + 1]);
 		ms += t;
+		if (dump && i / 2 < ctx->prof.tag.size()) fprintf(stderr, "[gpemu prof] %s ms=%.4f\n", ctx->prof.tag[i / 2].c_str(), t);
 	}
+	ctx->prof.tag.clear();
 	if (nlaunches) *nlaunches = ctx->prof.n;
 	if (total_ms) *total_ms = ms;
 	if (flops) *flops = ctx->prof.flops;
@@ -986,6 +1116,28 @@ extern "C" int gpemu_prof_end(gpemu_ctx *ctx, int *nlaunches, double *total_ms, 
 	for (auto e : ctx->prof.ev) hipEventDestroy(e);
 	ctx->prof.ev.clear();
 	ctx->prof.cls = GPEMU_PROF_NONE;
+	return GPEMU_OK;
+}
+
+// GPEMU_TRACE=1: write "tag start_ns end_ns" per kernel launch of the last factorisation (device wall clock,
+// 100 MHz ticks converted to ns; the same clock for every context of a GPU) to a text file
+extern "C" int gpemu_trace_dump(gpemu_ctx *ctx, const char *path)
+{
+	if (!ctx || !path) return GPEMU_ERR_ARG;
+	if (!ctx->dTrace) { ctx->err = "tracing is off (set GPEMU_TRACE=1 before gpemu_ctx_create)"; return GPEMU_ERR_STATE; }
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	std::vector<unsigned long long> h(8 * (size_t)ctx->trace_next);
+	if (!h.empty()) HIPCHK(ctx, hipMemcpy(h.data(), ctx->dTrace, h.size() * 8, hipMemcpyDeviceToHost));
+	FILE *f = fopen(path, "w");
+	if (!f) { ctx->err = "cannot open trace file"; return GPEMU_ERR_ARG; }
+	for (int i = 0; i < ctx->trace_next; i++) {
+		const unsigned long long *q = &h[8 * (size_t)i];
+		if (q[3] == 0) continue;
+		fprintf(f, "%s | %llu %llu %llu %llu %llu\n", ctx->trace_tag[i].c_str(), ~q[0] * 10ull, q[1] * 10ull, q[2] * 10ull,
+		        q[3], q[4]);
+	}
+	fclose(f);
 	return GPEMU_OK;
 }
 
@@ -1030,6 +1182,10 @@ extern "C" int gpemu_test_gemm_bench(gpemu_ctx *ctx, int m, int n, int k, int ld
 	HIPCHK(ctx, hipMalloc(&dc, (size_t)m * ld * 8));
 	HIPCHK(ctx, launch_fill_random(ctx->stream, da, rows * ld, 1u));
 	HIPCHK(ctx, launch_fill_random(ctx->stream, dc, (size_t)m * ld, 2u));
+	if (getenv("GPEMU_BENCH_ZERO")) {      // zero operands: the clock-limited ceiling (no data-dependent switching power)
+		HIPCHK(ctx, hipMemsetAsync(da, 0, rows * ld * 8, ctx->stream));
+		HIPCHK(ctx, hipMemsetAsync(dc, 0, (size_t)m * ld * 8, ctx->stream));
+	}
 	GemmArgs g;
 	memset(&g, 0, sizeof g);
 	g.C = dc; g.A = da; g.B = da; g.ldc = ld; g.lda = ld; g.ldb = ld; g.m = m; g.n = n; g.k0 = 0; g.k1 = k;

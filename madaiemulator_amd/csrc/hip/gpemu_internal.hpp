@@ -50,6 +50,9 @@ struct GemmArgs {
 	int kstart_off;
 	int kend_mode;       // 1: k ends at min(k1, ceil_BK(tn*BN + BN - kend_off))   (lower-triangular B rows)
 	int kend_off;
+	long bsC, bsA, bsB;  // element strides between the matrices of a batch (grid.y = nbatch)
+	int nbatch;          // 0/1: single problem
+	unsigned long long *trace;   // optional {first start, last end} device timestamps of this launch (GPEMU_TRACE)
 };
 
 struct ProfState {
@@ -57,6 +60,7 @@ struct ProfState {
 	std::vector<hipEvent_t> ev;   // pairs
 	double flops = 0, bytes = 0;
 	int n = 0;
+	std::vector<std::string> tag;  // one label per launch (GPEMU_PROF_DUMP=1 prints them with their times)
 };
 
 } // namespace gpemu
@@ -79,7 +83,10 @@ struct gpemu_ctx {
 
 	// factorisation workspace: tall matrix T (rows x Np)
 	double *dT = nullptr;
-	size_t T_rows = 0;           // allocated rows
+	size_t T_rows = 0;           // allocated rows (all matrices of a batch together)
+	int nb = 1;                  // matrices factored in lock-step by the current / last factorisation
+	size_t T_stride = 0;         // elements between consecutive matrices of the batch
+	int batch_cap = 0;           // allocated per-matrix result slots (dInfo, dGramPart, dRes, hRes, hInfo)
 	int *dInfo = nullptr;
 	double *dDiagInv = nullptr;  // eight inverted 16x16 diagonal blocks of the current 128-column leaf
 	double *dGramPart = nullptr; // [Np/128][Rp*Rp]
@@ -89,8 +96,9 @@ struct gpemu_ctx {
 	size_t res_len = 0;
 
 	// cached launch graphs for potrf, keyed by (Np, rows_total, with_inverse)
-	struct GraphKey { int Np; int aug_fixed; int inv; bool operator<(const GraphKey &o) const {
-		if (Np != o.Np) return Np < o.Np; if (aug_fixed != o.aug_fixed) return aug_fixed < o.aug_fixed; return inv < o.inv; } };
+	struct GraphKey { int Np; int aug_fixed; int inv; int nb; bool operator<(const GraphKey &o) const {
+		if (Np != o.Np) return Np < o.Np; if (aug_fixed != o.aug_fixed) return aug_fixed < o.aug_fixed;
+		if (inv != o.inv) return inv < o.inv; return nb < o.nb; } };
 	std::map<GraphKey, hipGraphExec_t> graphs;
 	bool use_graph = true;
 
@@ -114,6 +122,11 @@ struct gpemu_ctx {
 	size_t gradpart_len = 0;
 
 	gpemu::ProfState prof;
+	// GPEMU_TRACE=1: per-launch device timestamps (wall_clock64) written by the kernels themselves, so that the
+	// concurrent timeline of several contexts can be read (rocprofv3 serialises kernels)
+	unsigned long long *dTrace = nullptr;
+	int trace_cap = 0, trace_next = 0;
+	std::vector<std::string> trace_tag;
 	std::vector<double> last_thetas;
 };
 
@@ -134,10 +147,14 @@ hipError_t launch_grad_partials(hipStream_t s, const double *S, long lds, int so
 
 // ---- kernels_linalg.hip
 hipError_t launch_gemm(hipStream_t s, const GemmArgs &a);
-hipError_t launch_leaf(hipStream_t s, double *T, long ld, int c0, int m_below, int *info);
+extern int g_gemm_lds_pad, g_leaf_prio, g_gemm_big_tiles, g_gemm_big_cfg;
+hipError_t launch_leaf(hipStream_t s, double *T, long ld, int c0, int m_below, int *info,
+                       unsigned long long *trace_factor = nullptr, unsigned long long *trace_solve = nullptr,
+                       int nbatch = 1, long bstride = 0);
 hipError_t launch_leaf128(hipStream_t s, double *T, long ld, int c0, int m_below, int *info, double *dinv);
-hipError_t launch_gram_partials(hipStream_t s, const double *Z, long ld, int Np, int nrhs, int Rp, double *part);
+hipError_t launch_gram_partials(hipStream_t s, const double *Z, long ld, int Np, int nrhs, int Rp, double *part,
+                                int nbatch = 1, long zstride = 0);
 hipError_t launch_finish(hipStream_t s, const double *part, int nparts, int Rp, int nrhs, const double *T, long ld,
-                         int N, double *res);
+                         int N, double *res, int nbatch = 1, long tstride = 0, long rstride = 0);
 
 } // namespace gpemu

@@ -36,6 +36,30 @@ constexpr int LDS_S = GEMM_BK + 4;
 // (A persistent variant -- grid = resident workgroups, tile loop with the next tile's first chunk and the C
 // tile prefetched under the epilogue -- was measured 5-10 % slower on the big updates (register pressure,
 // imbalance of the static tile stride in triangular mode) and only ~10 % faster on the narrow ones; not kept.)
+// GPEMU_TRACE slot = 8 x u64, zero-initialised: [0] max(~start) i.e. earliest workgroup start, [1] latest end,
+// [2] sum of workgroup lifetimes, [3] workgroups (device wall clock, 100 MHz), [4] sum of workgroup lifetimes in
+// shader clocks (s_memtime): [4]/[2] = the shader clock the kernel really ran at
+struct TraceT0 { unsigned long long wall, clk; };
+__device__ __forceinline__ TraceT0 trace_begin(unsigned long long *t)
+{
+	TraceT0 r = {0, 0};
+	if (!t || threadIdx.x != 0) return r;
+	r.wall = wall_clock64();
+	r.clk = clock64();
+	atomicMax(t, ~r.wall);
+	return r;
+}
+__device__ __forceinline__ void trace_end(unsigned long long *t, TraceT0 t0)
+{
+	if (!t || threadIdx.x != 0) return;
+	const unsigned long long now = wall_clock64();
+	const unsigned long long clk = clock64();
+	atomicMax(t + 1, now);
+	atomicAdd(t + 2, now - t0.wall);
+	atomicAdd(t + 3, 1ull);
+	atomicAdd(t + 4, clk - t0.clk);
+}
+
 template <int BM, int BN, int MINW, int WGM = 2, int WGN = 2>
 __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs g)
 {
@@ -46,6 +70,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 	__shared__ double As[2][BM * LDS_S];
 	__shared__ double Bs[2][BN * LDS_S];
 
+	// batch of independent problems (lock-step factorisations): blockIdx.y selects the matrix
+	g.C += (long)blockIdx.y * g.bsC;
+	g.A += (long)blockIdx.y * g.bsA;
+	g.B += (long)blockIdx.y * g.bsB;
 	const int tiles_m = (g.m + BM - 1) / BM;
 	// natural order: consecutive blocks (which the dispatcher deals round-robin over the 8 XCDs) walk down a
 	// tile column, so one XCD keeps re-using 1/8 of the A panels and every B panel; measured equal to grouped /
@@ -53,6 +81,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 	const int tm = blockIdx.x % tiles_m;
 	const int tn = blockIdx.x / tiles_m;
 	if (g.tri && tn * BN > tm * BM + BM - 1 + g.diag_off) return;
+	const TraceT0 tr0 = trace_begin(g.trace);
 
 	int kb = g.k0, ke = g.k1;
 	if (g.kstart_mode) {
@@ -167,6 +196,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 				crow[col] = v;
 			}
 		}
+	trace_end(g.trace, tr0);
 }
 
 // active-tile count for a tile shape (tri skips the tiles strictly above the diagonal)
@@ -190,28 +220,38 @@ int g_gemm_force_cfg = -1;   // test/bench hook: 0 = 128x128, 1 = 128x64, 2 = 64
 // the big shape wins (less LDS/L2 traffic per flop: 60-62 vs 52 TF/s on the prediction GEMM); below that the
 // 64x64 shape is never slower (more workgroups for 256 CUs, 4 resident per CU) and up to 3x faster on the
 // narrow K<=256 updates of the factorisation.
+int g_gemm_big_cfg = 3;        // tile configuration of the big launches (3: 128x128 8 waves, 0: 128x128 4 waves)
+int g_gemm_big_tiles = 2048;   // 128x128 tiles (8 waves) once a launch has this many of them, else 64x64
+
 int choose_gemm_cfg(const GemmArgs &a)
 {
 	if (g_gemm_force_cfg >= 0) return g_gemm_force_cfg;
-	return count_tiles(a, 128, 128) >= 2048 ? 3 : 2;
+	return count_tiles(a, 128, 128) * (a.nbatch > 1 ? a.nbatch : 1) >= g_gemm_big_tiles ? g_gemm_big_cfg : 2;
 }
+
+int g_leaf_prio = 0;
+int g_gemm_lds_pad = 0;    // extra dynamic LDS per 64x64-tile workgroup (> 0: three instead of four per CU)
 
 hipError_t launch_gemm(hipStream_t s, const GemmArgs &a)
 {
 	if (a.m <= 0 || a.n <= 0) return hipSuccess;
+	const int nbatch = a.nbatch > 1 ? a.nbatch : 1;
 	const int cfg = choose_gemm_cfg(a);
 	if (cfg == 0) {
 		const int T = ((a.m + 127) / 128) * ((a.n + 127) / 128);
-		hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 2>), dim3(T), dim3(256), 0, s, a);
+		hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 2>), dim3(T, nbatch), dim3(256), 0, s, a);
 	} else if (cfg == 1) {
 		const int T = ((a.m + 127) / 128) * ((a.n + 63) / 64);
-		hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 2>), dim3(T), dim3(256), 0, s, a);
+		hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 2>), dim3(T, nbatch), dim3(256), 0, s, a);
 	} else if (cfg == 3) {
 		const int T = ((a.m + 127) / 128) * ((a.n + 127) / 128);
-		hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 4, 4, 2>), dim3(T), dim3(512), 0, s, a);
+		hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 4, 4, 2>), dim3(T, nbatch), dim3(512), 0, s, a);
 	} else {
 		const int T = ((a.m + 63) / 64) * ((a.n + 63) / 64);
-		hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4>), dim3(T), dim3(256), 0, s, a);
+		// a launch that fills every CU leaves one of the four workgroup slots' worth of LDS free (pad > 0), so that the
+		// latency-bound panel kernels of OTHER contexts are dispatched at once instead of waiting for a tile to retire
+		const int pad = (count_tiles(a, 64, 64) * nbatch >= 1024) ? g_gemm_lds_pad : 0;
+		hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4>), dim3(T, nbatch), dim3(256), pad, s, a);
 	}
 	return hipGetLastError();
 }
@@ -303,11 +343,15 @@ __device__ __forceinline__ void panel_update(double *A, int wave, int lane)
 		}
 }
 
-__global__ __launch_bounds__(256) void leaf_factor_kernel(double *T, long ld, int c0, int *info)
+__global__ __launch_bounds__(256) void leaf_factor_kernel(double *T, long ld, int c0, int *info, int prio, unsigned long long *trace, long bstride)
 {
+	T += (long)blockIdx.y * bstride;     // lock-step batch: one diagonal block per matrix
+	info += blockIdx.y;
 	__shared__ double A[LEAF * LP];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	double *D = T + (long)c0 * ld + c0;
+	if (prio) __builtin_amdgcn_s_setprio(3);   // critical-path kernel: win issue arbitration against co-resident GEMM waves
+	const TraceT0 tr0 = trace_begin(trace);
 	{
 		double v[16];
 #pragma unroll
@@ -337,6 +381,7 @@ __global__ __launch_bounds__(256) void leaf_factor_kernel(double *T, long ld, in
 		const int r = wave + 4 * u;
 		if (lane <= r) D[(long)r * ld + lane] = A[r * LP + lane];
 	}
+	trace_end(trace, tr0);
 }
 
 // 1/x: hardware estimate + two Newton steps (an fp64 divide costs ~10 dependent VALU ops at 16 cycles each)
@@ -353,7 +398,7 @@ __device__ __forceinline__ double fast_rcp(double x)
 // L = D (I + N), N strictly lower => (I+N)^-1 = (I - N)(I + N^2)(I + N^4)(I + N^8) exactly (N^16 = 0):
 // five 16x16x16 products on the MFMA; the D registers of a product are the B operand of the next one,
 // the A operand goes through a private 16x17 LDS tile.
-template <int LD>
+template <int LD, int TS = 17>
 __device__ __forceinline__ void tri_inverse16_to(const double *M, int o, double *tile, int lane, double *dst, int dst_ld)
 {
 	const int g = lane >> 4, q = lane & 15;
@@ -389,16 +434,16 @@ __device__ __forceinline__ void tri_inverse16_to(const double *M, int o, double 
 	for (int it = 0; it < 2; it++) {
 		double sA[4], qA[4];
 #pragma unroll
-		for (int r = 0; r < 4; r++) tile[(g + 4 * r) * 17 + q] = S[r];
+		for (int r = 0; r < 4; r++) tile[(g + 4 * r) * TS + q] = S[r];
 #pragma unroll
-		for (int r = 0; r < 4; r++) sA[r] = tile[q * 17 + g + 4 * r];
+		for (int r = 0; r < 4; r++) sA[r] = tile[q * TS + g + 4 * r];
 		d4_t S2 = {0, 0, 0, 0};
 #pragma unroll
 		for (int r = 0; r < 4; r++) S2 = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[r], S[r], S2, 0, 0, 0);
 #pragma unroll
-		for (int r = 0; r < 4; r++) tile[(g + 4 * r) * 17 + q] = Q[r];
+		for (int r = 0; r < 4; r++) tile[(g + 4 * r) * TS + q] = Q[r];
 #pragma unroll
-		for (int r = 0; r < 4; r++) qA[r] = tile[q * 17 + g + 4 * r];
+		for (int r = 0; r < 4; r++) qA[r] = tile[q * TS + g + 4 * r];
 		d4_t B2, Q2 = {0, 0, 0, 0};
 #pragma unroll
 		for (int r = 0; r < 4; r++) B2[r] = S2[r] + ((g + 4 * r == q) ? 1.0 : 0.0);
@@ -413,17 +458,21 @@ __device__ __forceinline__ void tri_inverse16_to(const double *M, int o, double 
 }
 
 
+// in place over the diagonal block; the scratch tile is a 16x16 block of M itself (row stride LP) that the solve never
+// reads: keeps the kernel at 33 KB of LDS so that it fits beside three resident GEMM workgroups
 __device__ __forceinline__ void tri_inverse16(double *M, int o, double *tile, int lane)
 {
-	tri_inverse16_to<LP>(M, o, tile, lane, M + o * LP + o, LP);     // in place over the diagonal block
+	tri_inverse16_to<LP, LP>(M, o, tile, lane, M + o * LP + o, LP);
 }
 
-__global__ __launch_bounds__(256) void leaf_solve_kernel(double *T, long ld, int c0, int m_below)
+__global__ __launch_bounds__(256) void leaf_solve_kernel(double *T, long ld, int c0, int m_below, int prio, unsigned long long *trace, long bstride)
 {
+	T += (long)blockIdx.y * bstride;
 	__shared__ double M[LEAF * LP];        // L; diagonal 16x16 blocks replaced by their inverses
-	__shared__ double Xs[4][16 * 17];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int g = lane >> 4, q = lane & 15;
+	if (prio) __builtin_amdgcn_s_setprio(3);
+	const TraceT0 tr0 = trace_begin(trace);
 	// this wave's 16 panel rows: all 16 values per lane requested up front (one memory latency, overlapped
 	// with staging L and inverting the diagonal blocks)
 	const int prow0 = (blockIdx.x * 4 + wave) * 16;
@@ -445,7 +494,11 @@ __global__ __launch_bounds__(256) void leaf_solve_kernel(double *T, long ld, int
 		for (int u = 0; u < 16; u++) M[(wave + 4 * u) * LP + lane] = v[u];
 	}
 	__syncthreads();
-	tri_inverse16(M, 16 * wave, Xs[wave], lane);      // wave w inverts diagonal block w
+	{
+		// wave w inverts diagonal block w; scratch = an upper block of M: (0,1) (1,2) (2,3) (0,3)
+		const int sr = (wave == 3) ? 0 : wave, sc = (wave == 3) ? 3 : wave + 1;
+		tri_inverse16(M, 16 * wave, M + 16 * sr * LP + 16 * sc, lane);
+	}
 	__syncthreads();
 	if (prow0 >= m_below) return;
 	d4_t X[4];
@@ -471,6 +524,7 @@ __global__ __launch_bounds__(256) void leaf_solve_kernel(double *T, long ld, int
 			for (int r = 0; r < 4; r++) bp[16 * j + g + 4 * r] = xj[r];
 		}
 	}
+	trace_end(trace, tr0);
 }
 
 // ---------------------------------------------------------------------------
@@ -695,11 +749,14 @@ hipError_t launch_leaf128(hipStream_t s, double *T, long ld, int c0, int m_below
 	return hipGetLastError();
 }
 
-hipError_t launch_leaf(hipStream_t s, double *T, long ld, int c0, int m_below, int *info)
+hipError_t launch_leaf(hipStream_t s, double *T, long ld, int c0, int m_below, int *info, unsigned long long *trf,
+                       unsigned long long *trs, int nbatch, long bstride)
 {
-	hipLaunchKernelGGL(leaf_factor_kernel, dim3(1), dim3(256), 0, s, T, ld, c0, info);
+	if (nbatch < 1) nbatch = 1;
+	hipLaunchKernelGGL(leaf_factor_kernel, dim3(1, nbatch), dim3(256), 0, s, T, ld, c0, info, g_leaf_prio, trf, bstride);
 	if (m_below > 0)
-		hipLaunchKernelGGL(leaf_solve_kernel, dim3((m_below + 63) / 64), dim3(256), 0, s, T, ld, c0, m_below);
+		hipLaunchKernelGGL(leaf_solve_kernel, dim3((m_below + 63) / 64, nbatch), dim3(256), 0, s, T, ld, c0, m_below,
+		                   g_leaf_prio, trs, bstride);
 	return hipGetLastError();
 }
 
@@ -707,8 +764,11 @@ hipError_t launch_leaf(hipStream_t s, double *T, long ld, int c0, int m_below, i
 // Gram partials: part[blk][a][b] = sum_{j in 64-column chunk blk} Z[a][j] Z[b][j]
 // Z rows are the solved right-hand sides (rows Np.. of T): Z = L^-1 [y|H].
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gram_part_kernel(const double *Z, long ld, int nrhs, int Rp, double *part)
+__global__ __launch_bounds__(256) void gram_part_kernel(const double *Z, long ld, int nrhs, int Rp, double *part,
+                                                        long zstride, long pstride)
 {
+	Z += (long)blockIdx.y * zstride;
+	part += (long)blockIdx.y * pstride;
 	__shared__ double zs[64 * 65];
 	const int tid = threadIdx.x;
 	const int c0 = blockIdx.x * 64;
@@ -726,17 +786,24 @@ __global__ __launch_bounds__(256) void gram_part_kernel(const double *Z, long ld
 	}
 }
 
-hipError_t launch_gram_partials(hipStream_t s, const double *Z, long ld, int Np, int nrhs, int Rp, double *part)
+hipError_t launch_gram_partials(hipStream_t s, const double *Z, long ld, int Np, int nrhs, int Rp, double *part,
+                                int nbatch, long zstride)
 {
-	hipLaunchKernelGGL(gram_part_kernel, dim3(Np / 64), dim3(256), 0, s, Z, ld, nrhs, Rp, part);
+	if (nbatch < 1) nbatch = 1;
+	hipLaunchKernelGGL(gram_part_kernel, dim3(Np / 64, nbatch), dim3(256), 0, s, Z, ld, nrhs, Rp, part, zstride,
+	                   (long)(Np / 64) * Rp * Rp);
 	return hipGetLastError();
 }
 
 // finish: fixed-order reduction of the Gram partials and 2*sum(log L_ii)
 // (replaces det = (prod L_ii)^2 of maxmultimin.c:355-358, which under/overflows)
 __global__ __launch_bounds__(256) void finish_kernel(const double *part, int nparts, int Rp, int nrhs,
-                                                     const double *T, long ld, int N, double *res)
+                                                     const double *T, long ld, int N, double *res, long tstride,
+                                                     long rstride)
 {
+	part += (long)blockIdx.x * nparts * Rp * Rp;
+	T += (long)blockIdx.x * tstride;
+	res += (long)blockIdx.x * rstride;
 	__shared__ double red[256];
 	const int tid = threadIdx.x;
 	for (int p = tid; p < nrhs * nrhs; p += 256) {
@@ -757,9 +824,11 @@ __global__ __launch_bounds__(256) void finish_kernel(const double *part, int npa
 }
 
 hipError_t launch_finish(hipStream_t s, const double *part, int nparts, int Rp, int nrhs, const double *T, long ld,
-                         int N, double *res)
+                         int N, double *res, int nbatch, long tstride, long rstride)
 {
-	hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, s, part, nparts, Rp, nrhs, T, ld, N, res);
+	if (nbatch < 1) nbatch = 1;
+	hipLaunchKernelGGL(finish_kernel, dim3(nbatch), dim3(256), 0, s, part, nparts, Rp, nrhs, T, ld, N, res, tstride,
+	                   rstride);
 	return hipGetLastError();
 }
 

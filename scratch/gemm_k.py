@@ -1,0 +1,9 @@
+import sys
+sys.path.insert(0,'.')
+from madaiemulator_amd import abi
+c=abi.Context(0)
+for cfg in (2,3):
+    for k in (512,2048):
+        ms,fl=c.gemm_bench(m=7744,n=7680,k=k,ld=8192,cfg=cfg,tri=1,beta=1,reps=20)
+        ms,fl=c.gemm_bench(m=7744,n=7680,k=k,ld=8192,cfg=cfg,tri=1,beta=1,reps=40)
+        print("cfg",cfg,"k",k,"ms %.4f TF/s %.1f"%(ms,fl/ms/1e9),flush=True)

@@ -193,6 +193,64 @@ def test_loglik_enqueue_collect_pipeline(gpu_ctx):
     assert last["value"] == single[-1]
 
 
+
+# ------------------------------------------------------------------ a11 over a theta list (lock-step batch)
+@pytest.mark.parametrize("kind,N,d,order,nb", [(1, 512, 8, 1, 5), (3, 1100, 8, 1, 3), (1, 2200, 4, 0, 4), (2, 300, 4, 2, 7)])
+def test_loglik_batch_vs_oracle_and_single(gpu_ctx, kind, N, d, order, nb):
+    """gpemu_loglik_batch: nb evaluations of one model factored in lock-step -- every element equals the oracle
+    to 1e-8 and equals the single-evaluation entry to rounding (same kernels; the outer panel width of a batch
+    differs above N = 512, so the summation order may)."""
+    X, y = synth.design(N, d, 20261003 + N + nb)
+    gpu_ctx.set_model(kind, order, X, y)
+    ths = np.array([synth.perturbed_thetas(kind, d, 31, i) for i in range(nb)])
+    got = gpu_ctx.loglik_batch(ths)
+    assert np.all(got["status"] == 0) and np.all(got["info"] == 0)
+    for b in range(nb):
+        one = gpu_ctx.loglik(ths[b])
+        for key in ("value", "sigma2", "logdet", "quad"):
+            assert got[key][b] == pytest.approx(one[key], rel=1e-12), (key, b)
+            if N <= 512:
+                assert got[key][b] == one[key], (key, b)
+        assert relerr(got["beta"][b], one["beta"]) < 1e-11
+    for b in (0, nb - 1):
+        e = O.Emulator(kind, order, X, y, ths[b])
+        r = y - e.H @ e.beta
+        quad = r @ e.cinverse @ r
+        ref = -(-0.5 * e.logdet - N / 2.0 * 1.83788 - 0.5 * quad)
+        assert got["value"][b] == pytest.approx(ref, rel=RTOL)
+        assert got["sigma2"][b] == pytest.approx(y @ e.cinverse @ r / N, rel=RTOL)
+        assert relerr(got["beta"][b], e.beta) < RTOL
+
+
+def test_loglik_batch_reports_not_pd_per_element(gpu_ctx, ref_inputs):
+    """one theta of the list gives a non-PD matrix (Matern, amp 0, nugget < 0): only that element fails"""
+    X, y = ref_inputs["uni"]
+    gpu_ctx.set_model(2, 0, X, y)
+    good = np.array([1.0, 0.01, -0.5])
+    bad = np.array([0.0, -3.0, 0.0])
+    got = gpu_ctx.loglik_batch(np.array([good, bad, good]))
+    assert list(got["status"]) == [0, abi.ERR_NOT_PD, 0] and list(got["info"]) == [0, 1, 0]
+    assert np.isnan(got["value"][1]) and np.all(np.isnan(got["beta"][1]))
+    one = gpu_ctx.loglik(good)
+    assert got["value"][0] == one["value"] and got["value"][2] == one["value"]
+
+
+def test_loglik_batch_pipeline_and_size_change(gpu_ctx):
+    """batches of different sizes back to back on one context (workspace regrows, graphs are per size)"""
+    X, y = synth.design(640, 8, 9)
+    gpu_ctx.set_model(1, 1, X, y)
+    ths = np.array([synth.perturbed_thetas(1, 8, 5, i) for i in range(6)])
+    single = np.array([gpu_ctx.loglik(t)["value"] for t in ths])
+    for nb in (2, 6, 3, 1):
+        gpu_ctx.loglik_batch_enqueue(ths[:nb])
+        gpu_ctx.loglik_batch_enqueue(ths[6 - nb:])
+        got = gpu_ctx.loglik_batch_collect()
+        assert relerr(got["value"], single[6 - nb:]) < 1e-12     # N > 512: the batch uses a wider outer panel
+    # a prediction set-up after a batch uses matrix 0 of the workspace again
+    beta, rc = gpu_ctx.predict_setup(ths[0])
+    assert rc == 0 and relerr(beta, gpu_ctx.loglik(ths[0])["beta"]) < 1e-12
+
+
 def test_set_training_swaps_outputs(gpu_ctx):
     # multi_modelstruct: one design, nr training vectors
     X, y = synth.design(300, 3, 6)
