@@ -150,7 +150,7 @@ int gpemu_prof_end(gpemu_ctx *ctx, int *nlaunches, double *total_ms, double *flo
 
 /* Diagnostics: with GPEMU_TRACE=1 in the environment at gpemu_ctx_create, every GEMM / leaf kernel of a
  * factorisation records its first-workgroup start and last-workgroup end on the device wall clock; this writes
- * "tag | start_ns end_ns sum_of_workgroup_ns workgroups sum_of_workgroup_shader_clocks" lines for the last factorisation.  Contexts of one GPU share the clock, so the files
+ * "tag | start_ns end_ns sum_of_workgroup_ns workgroups sum_of_workgroup_shader_clocks prologue_clocks epilogue_clocks" lines for the last factorisation.  Contexts of one GPU share the clock, so the files
  * of concurrent contexts merge into one timeline (tools/trace_timeline.py). */
 int gpemu_trace_dump(gpemu_ctx *ctx, const char *path);
 

@@ -151,6 +151,7 @@ extern "C" int gpemu_ctx_create(gpemu_ctx **out, int device)
 		{ const char *lp = getenv("GPEMU_GEMM_LDS_PAD"); if (lp) gpemu::g_gemm_lds_pad = atoi(lp); }
 		{ const char *lp = getenv("GPEMU_GEMM_BIG_TILES"); if (lp && atoi(lp) > 0) gpemu::g_gemm_big_tiles = atoi(lp); }
 		{ const char *lp = getenv("GPEMU_GEMM_BIG_CFG"); if (lp) gpemu::g_gemm_big_cfg = atoi(lp); }
+		{ const char *lp = getenv("GPEMU_GEMM_PRIO"); if (lp) gpemu::g_gemm_prio_mode = atoi(lp); }
 		{ const char *lp = getenv("GPEMU_LEAF_PRIO"); if (lp) gpemu::g_leaf_prio = atoi(lp); }
 		const char *la0 = getenv("GPEMU_LOOKAHEAD");
 		const bool want_second = la0 ? atoi(la0) != 0 : g_lookahead != 0;   // only the look-ahead schedule uses it
@@ -1134,8 +1135,8 @@ extern "C" int gpemu_trace_dump(gpemu_ctx *ctx, const char *path)
 	for (int i = 0; i < ctx->trace_next; i++) {
 		const unsigned long long *q = &h[8 * (size_t)i];
 		if (q[3] == 0) continue;
-		fprintf(f, "%s | %llu %llu %llu %llu %llu\n", ctx->trace_tag[i].c_str(), ~q[0] * 10ull, q[1] * 10ull, q[2] * 10ull,
-		        q[3], q[4]);
+		fprintf(f, "%s | %llu %llu %llu %llu %llu %llu %llu\n", ctx->trace_tag[i].c_str(), ~q[0] * 10ull, q[1] * 10ull,
+		        q[2] * 10ull, q[3], q[4], q[5], q[6]);
 	}
 	fclose(f);
 	return GPEMU_OK;
@@ -1190,6 +1191,11 @@ extern "C" int gpemu_test_gemm_bench(gpemu_ctx *ctx, int m, int n, int k, int ld
 	memset(&g, 0, sizeof g);
 	g.C = dc; g.A = da; g.B = da; g.ldc = ld; g.lda = ld; g.ldb = ld; g.m = m; g.n = n; g.k0 = 0; g.k1 = k;
 	g.alpha = -1.0; g.beta = beta; g.tri = tri;
+	if (ctx->dTrace) {
+		ctx->trace_next = 0; ctx->trace_tag.clear();
+		HIPCHK(ctx, hipMemsetAsync(ctx->dTrace, 0, (size_t)ctx->trace_cap * 64, ctx->stream));
+		g.trace = trace_slot(ctx, "gemm_bench m=%d n=%d k=%d", m, n, k);
+	}
 	const int saved = g_gemm_force_cfg;
 	g_gemm_force_cfg = cfg;
 	hipEvent_t e0, e1;

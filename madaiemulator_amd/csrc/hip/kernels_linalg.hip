@@ -43,7 +43,9 @@ struct TraceT0 { unsigned long long wall, clk; };
 __device__ __forceinline__ TraceT0 trace_begin(unsigned long long *t)
 {
 	TraceT0 r = {0, 0};
-	if (!t || threadIdx.x != 0) return r;
+	// one workgroup in 16 reports (same-address atomics cost ~12 ns each: every workgroup reporting inflated the
+	// many-small-workgroup kernels several times over)
+	if (!t || threadIdx.x != 0 || ((blockIdx.x + 5 * blockIdx.y) & 15) != 0) return r;
 	r.wall = wall_clock64();
 	r.clk = clock64();
 	atomicMax(t, ~r.wall);
@@ -51,7 +53,7 @@ __device__ __forceinline__ TraceT0 trace_begin(unsigned long long *t)
 }
 __device__ __forceinline__ void trace_end(unsigned long long *t, TraceT0 t0)
 {
-	if (!t || threadIdx.x != 0) return;
+	if (!t || threadIdx.x != 0 || t0.wall == 0) return;
 	const unsigned long long now = wall_clock64();
 	const unsigned long long clk = clock64();
 	atomicMax(t + 1, now);
@@ -82,6 +84,23 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 	const int tn = blockIdx.x / tiles_m;
 	if (g.tri && tn * BN > tm * BM + BM - 1 + g.diag_off) return;
 	const TraceT0 tr0 = trace_begin(g.trace);
+	if (g.prio_mode == 1) {
+		// experiment: distinct issue priorities for the workgroups that share a CU (breaks lock-step convoys?)
+		switch ((blockIdx.x >> 3) & 3) {
+		case 1: __builtin_amdgcn_s_setprio(1); break;
+		case 2: __builtin_amdgcn_s_setprio(2); break;
+		case 3: __builtin_amdgcn_s_setprio(3); break;
+		default: break;
+		}
+	} else if (g.prio_mode >= 2) {
+		// experiment: stagger the first round of workgroups over about one tile time so that the C read-modify-write
+		// bursts of the rounds do not all hit HBM at once
+		const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+		if (lin < 2048) {
+			const int ph = (lin >> 3) & 15;
+			for (int i = 0; i < ph * (g.prio_mode - 1); i++) __builtin_amdgcn_s_sleep(127);
+		}
+	}
 
 	int kb = g.k0, ke = g.k1;
 	if (g.kstart_mode) {
@@ -119,11 +138,44 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 		lofs_b[it] = row * LDS_S + 2 * seg;
 	}
 
+	// The accumulators start from the C tile itself (scaled by beta/alpha, alpha = +-1 when beta is set: exact), so
+	// the read half of the read-modify-write overlaps the operand prologue and the epilogue is stores only.  (Read
+	// in the epilogue, load and store of one element serialise: 11 us per 128x128 tile, 38 us under load.)
+	const int row0 = tm * BM + wm * WM + (lane >> 4);
+	const int col0 = tn * BN + wn * WN + (lane & 15);
+	const bool full_tile = (tm * BM + BM <= g.m) && (tn * BN + BN <= g.n);
 	d4_t acc[TM][TN];
+	if (g.beta) {
+		const double cs = g.alpha;       // 1/alpha for alpha = +-1
+		if (full_tile) {
 #pragma unroll
-	for (int i = 0; i < TM; i++)
+			for (int i = 0; i < TM; i++)
 #pragma unroll
-		for (int j = 0; j < TN; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+				for (int r = 0; r < 4; r++) {
+					const double *crow = g.C + (long)(row0 + i * 16 + 4 * r) * g.ldc + col0;
+#pragma unroll
+					for (int j = 0; j < TN; j++) acc[i][j][r] = cs * crow[j * 16];
+				}
+		} else {
+#pragma unroll
+			for (int i = 0; i < TM; i++)
+#pragma unroll
+				for (int r = 0; r < 4; r++) {
+					const int row = row0 + i * 16 + 4 * r;
+					const double *crow = g.C + (long)(row < g.m ? row : g.m - 1) * g.ldc;
+#pragma unroll
+					for (int j = 0; j < TN; j++) {
+						const int col = col0 + j * 16;
+						acc[i][j][r] = cs * crow[col < g.n ? col : g.n - 1];
+					}
+				}
+		}
+	} else {
+#pragma unroll
+		for (int i = 0; i < TM; i++)
+#pragma unroll
+			for (int j = 0; j < TN; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+	}
 
 	const int a_base = (wm * WM + (lane & 15)) * LDS_S + 2 * (lane >> 4);
 	const int b_base = (wn * WN + (lane & 15)) * LDS_S + 2 * (lane >> 4);
@@ -139,6 +191,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 #pragma unroll
 		for (int it = 0; it < BIT; it++) *reinterpret_cast<d2_t *>(&Bs[0][lofs_b[it]]) = rb[it];
 		__syncthreads();
+		if (g.trace && tr0.wall) atomicAdd(g.trace + 5, (unsigned long long)clock64() - tr0.clk);   // prologue
 
 		int cur = 0;
 		for (int k = kb; k < ke; k += GEMM_BK) {
@@ -178,24 +231,37 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 	}
 
 	// epilogue
-	const int row0 = tm * BM + wm * WM + (lane >> 4);
-	const int col0 = tn * BN + wn * WN + (lane & 15);
+	unsigned long long clk_loop_end = 0;
+	if (g.trace && tr0.wall) clk_loop_end = clock64();
+	if (full_tile) {
 #pragma unroll
-	for (int i = 0; i < TM; i++)
+		for (int i = 0; i < TM; i++)
 #pragma unroll
-		for (int r = 0; r < 4; r++) {
-			const int row = row0 + i * 16 + 4 * r;
-			if (row >= g.m) continue;
-			double *crow = g.C + (long)row * g.ldc;
+			for (int r = 0; r < 4; r++) {
+				double *crow = g.C + (long)(row0 + i * 16 + 4 * r) * g.ldc + col0;
 #pragma unroll
-			for (int j = 0; j < TN; j++) {
-				const int col = col0 + j * 16;
-				if (col >= g.n) continue;
-				double v = g.alpha * acc[i][j][r];
-				if (g.beta) v += crow[col];
-				crow[col] = v;
+				for (int j = 0; j < TN; j++) crow[j * 16] = g.alpha * acc[i][j][r];
 			}
-		}
+	} else {
+#pragma unroll
+		for (int i = 0; i < TM; i++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) {
+				const int row = row0 + i * 16 + 4 * r;
+				if (row >= g.m) continue;
+				double *crow = g.C + (long)row * g.ldc;
+#pragma unroll
+				for (int j = 0; j < TN; j++) {
+					const int col = col0 + j * 16;
+					if (col >= g.n) continue;
+					crow[col] = g.alpha * acc[i][j][r];
+				}
+			}
+	}
+	if (g.trace && tr0.wall) {
+		__builtin_amdgcn_s_waitcnt(0);     // stores issued, loads returned
+		atomicAdd(g.trace + 6, (unsigned long long)clock64() - clk_loop_end);                            // epilogue
+	}
 	trace_end(g.trace, tr0);
 }
 
@@ -230,11 +296,15 @@ int choose_gemm_cfg(const GemmArgs &a)
 }
 
 int g_leaf_prio = 0;
+int g_gemm_prio_mode = 0;
 int g_gemm_lds_pad = 0;    // extra dynamic LDS per 64x64-tile workgroup (> 0: three instead of four per CU)
 
-hipError_t launch_gemm(hipStream_t s, const GemmArgs &a)
+hipError_t launch_gemm(hipStream_t s, const GemmArgs &a_in)
 {
+	GemmArgs a = a_in;
+	a.prio_mode = g_gemm_prio_mode;
 	if (a.m <= 0 || a.n <= 0) return hipSuccess;
+	if (a.beta && a.alpha != 1.0 && a.alpha != -1.0) return hipErrorInvalidValue;   // accumulators start from C/alpha
 	const int nbatch = a.nbatch > 1 ? a.nbatch : 1;
 	const int cfg = choose_gemm_cfg(a);
 	if (cfg == 0) {

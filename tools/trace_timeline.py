@@ -12,11 +12,13 @@ def load(path):
     out = []
     for line in open(path):
         tag, _, times = line.rpartition("|")
-        s, e, wsum, wn, wclk = (int(x) for x in times.split())
+        s, e, wsum, wn, wclk = (int(x) for x in times.split()[:5])
         tag = tag.strip()
         m = re.search(r"k=(\d+)", tag)
         if tag.startswith("gemm"):
             cls = "gemm_k512" if m and int(m.group(1)) >= 512 else "gemm_narrow"
+            if m and int(m.group(1)) >= 1024:
+                cls = "gemm_k1024"
         else:
             cls = tag.split()[0]
         out.append((s, e, cls, tag, wsum, wn, wclk))
@@ -55,7 +57,7 @@ def main():
         ev = []
         for tr in traces:
             for s, e, cls, *_ in tr:
-                if cls != "gemm_k512" or e <= lo or s >= hi:
+                if cls not in ("gemm_k512", "gemm_k1024") or e <= lo or s >= hi:
                     continue
                 ev.append((max(s, lo), 1))
                 ev.append((min(e, hi), -1))
