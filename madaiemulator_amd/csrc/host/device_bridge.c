@@ -159,6 +159,45 @@ double evalFnMulti(const gsl_vector *theta_vec_less_amp, void *params_in)
 	return val;
 }
 
+/* evalFnMulti over a list of theta rows (npts x (nthetas-1), each {nugget, lengths...}): the rows are independent
+ * evaluations of one model (libRbind/rbind.c:626-724 callEvalLhoodList; the restarts of maxWithMultiMin), so they
+ * go to the device in lock-step batches (gpemu_loglik_batch) instead of one factorisation at a time.  answer[i] is
+ * what evalFnMulti would have returned for row i. */
+void evalFnMultiList(const gsl_matrix *theta_rows_less_amp, void *params_in, double *answer)
+{
+	struct estimate_thetas_params *params = (struct estimate_thetas_params *)params_in;
+	const int nthetas = params->options->nthetas;
+	const int npts = (int)theta_rows_less_amp->size1;
+	gpemu_ctx *ctx = bind_model(params, params->the_model, "evalFnMultiList");
+	int maxb = 16;                                         /* workspace: maxb * (N+64) * N * 8 bytes */
+	const char *e = getenv("GPEMU_HOST_BATCH");
+	if (e && atoi(e) >= 1) maxb = atoi(e) > GPEMU_MAX_BATCH ? GPEMU_MAX_BATCH : atoi(e);
+	double *th = (double *)calloc((size_t)maxb * nthetas, sizeof(double));
+	int *status = (int *)malloc(sizeof(int) * (size_t)maxb);
+	for (int p0 = 0; p0 < npts; p0 += maxb) {
+		const int nb = npts - p0 < maxb ? npts - p0 : maxb;
+		for (int b = 0; b < nb; b++) {
+			th[(size_t)b * nthetas] = 0.0;                    /* theta_local[0] = 0 (maxmultimin.c:322) */
+			for (int i = 1; i < nthetas; i++)
+				th[(size_t)b * nthetas + i] = gsl_matrix_get(theta_rows_less_amp, p0 + b, i - 1);
+		}
+		int rc = gpemu_loglik_batch(ctx, nb, th, nthetas, answer + p0, NULL, NULL, NULL, NULL, NULL, status);
+		if (rc) die(ctx, rc, "evalFnMultiList");
+		for (int b = 0; b < nb; b++) {
+			if (status[b] == GPEMU_ERR_NOT_PD) {
+				note_not_pd("evalFnMulti", th + (size_t)b * nthetas, nthetas);
+				answer[p0 + b] = GSL_NAN;
+			} else if (status[b] == GPEMU_ERR_REGRESSION) {
+				fprintf(stderr, "# err: estimateBeta\n# trying to cholesky a non postive def matrix, sorry...\n");
+				exit(1);                                      /* regression.c:134-160 */
+			} else if (status[b]) {
+				die(ctx, status[b], "evalFnMultiList");
+			}
+		}
+	}
+	free(status); free(th);
+}
+
 static void grad_failure(gpemu_ctx *ctx, int rc, const double *th, int nthetas)
 {
 	if (rc == GPEMU_ERR_NOT_PD) {

@@ -131,6 +131,9 @@ void makeHMatrix_fnptr(gsl_matrix *h_matrix, gsl_matrix *xmodel, int nmodel_poin
 
 /* ---- libEmu/maxmultimin.h ------------------------------------------------ */
 double evalFnMulti(const gsl_vector *theta_vec_less_amp, void *params_in);
+/* extension: evalFnMulti for every row of a matrix (the first nthetas-1 entries of each row are read), factored in
+ * lock-step batches on the device */
+void evalFnMultiList(const gsl_matrix *theta_rows_less_amp, void *params_in, double *answer);
 void gradFnMulti(const gsl_vector *theta_vec_less_amp, void *params_in, gsl_vector *grad_vec);
 void evalFnGradMulti(const gsl_vector *theta_vec, void *params, double *fnval, gsl_vector *grad_vec);
 double estimateSigmaFull(gsl_vector *thetas_less_amp, void *params_in);

@@ -2,7 +2,8 @@
  * rbind_compat.c -- the one libRbind entry point that is a ready-made batch of independent
  * likelihood evaluations (libRbind/rbind.c:626-724 callEvalLhoodList), without R: same flat
  * .C()-style signature (pointers to scalars, column-major arrays as R passes them).
- * Every row of pointList goes through evalFnMulti, i.e. through one GPU factorisation.
+ * The rows of pointList are independent evaluations of one model: they go through evalFnMultiList, i.e. through
+ * lock-step batches of GPU factorisations (gpemu_loglik_batch).
  */
 #include <stdlib.h>
 #include <string.h>
@@ -33,11 +34,9 @@ void callEvalLhoodList(double *xmodel_in, int *nparams_in, double *pointList_in,
 	memset(&params, 0, sizeof params);
 	params.options = model->options;
 	params.the_model = model;
-	for (int i = 0; i < npts; i++) {
-		/* evalFnMulti reads nthetas-1 entries {nugget, lengths...} from the start of the row (rbind.c:704-712) */
-		gsl_vector_view row = gsl_matrix_row(pts, i);
-		answer[i] = evalFnMulti(&row.vector, &params);
-	}
+	/* evalFnMulti reads nthetas-1 entries {nugget, lengths...} from the start of each row (rbind.c:704-712);
+	 * evalFnMultiList does the same for every row of pts (its last column is never read) */
+	evalFnMultiList(pts, &params, answer);
 	gpemu_host_release(&params);
 	gsl_matrix_free(pts);
 	gsl_matrix_free(model->xmodel);

@@ -197,14 +197,17 @@ def test_call_eval_lhood_list_without_r():
     y = Y[:, 0]
     N, d = X.shape
     nthetas = d + 2
-    rows = np.array([[-3.0, -1.0, -0.7, 0.0], [-4.0, -0.5, -0.9, 0.0], [-2.5, -1.5, -0.2, 0.0]])   # {nug, lengths..., unused}
+    rows = np.array([[-3.0, -1.0, -0.7, 0.0], [-4.0, -0.5, -0.9, 0.0], [-2.5, -1.5, -0.2, 0.0],
+                     [-3.5, -0.8, -0.4, 0.0], [-2.0, -1.2, -1.1, 0.0]])   # {nug, lengths..., unused}
     ans = np.zeros(len(rows))
+    os.environ["GPEMU_HOST_BATCH"] = "2"       # 5 rows -> lock-step batches of 2, 2, 1 (evalFnMultiList)
     dp = C.POINTER(C.c_double)
     ip = lambda v: C.byref(C.c_int(v))
     xin = np.asfortranarray(X).ravel(order="F").copy()
     pin = np.asfortranarray(rows).ravel(order="F").copy()
     lib.callEvalLhoodList(xin.ctypes.data_as(dp), ip(d), pin.ctypes.data_as(dp), ip(len(rows)), y.ctypes.data_as(dp),
                           ip(N), ip(nthetas), ans.ctypes.data_as(dp), ip(1), ip(1))
+    os.environ.pop("GPEMU_HOST_BATCH")
     for r, a in zip(rows, ans):
         assert a == pytest.approx(O.eval_fn_multi(1, 1, X, y, r[:nthetas - 1])["value"], rel=RTOL)
 
