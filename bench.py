@@ -154,22 +154,31 @@ def main():
     gate = None
     if rank == 0:
         from oracle import oracle as O
-        Xg, yg = synth.design(512, d, seed)
-        g = abi.Context(dev)
-        g.set_model(kind, order, Xg, yg)
-        thg = synth.default_thetas(kind, d)
-        got = g.loglik(thg)
-        e = O.Emulator(kind, order, Xg, yg, thg)
-        r = yg - e.H @ e.beta
-        ref = -(-0.5 * e.logdet - 512 / 2.0 * 1.83788 - 0.5 * (r @ e.cinverse @ r))
-        g.predict_setup(thg)
-        qg = synth.queries(64, d, 5)
-        m, v = g.predict(qg)
-        mo, vo, _ = e.emulate(qg)
-        gate = {"loglik_rel": abs(got["value"] - ref) / abs(ref), "mean_abs": float(np.max(np.abs(m - mo))),
-                "var_abs": float(np.max(np.abs(v - vo)))}
-        assert gate["loglik_rel"] < 1e-8 and gate["mean_abs"] < 1e-8 and gate["var_abs"] < 1e-8, gate
-        g.close()
+        gate = {}
+        # N=512 and N=2048 on the same seeds (the N=2048 oracle run is ~15 s of CPU: skipped together
+        # with the CPU baseline by --no-cpu-baseline)
+        for Ng in ([512] if args.no_cpu_baseline else [512, 2048]):
+            Xg, yg = synth.design(Ng, d, seed)
+            g = abi.Context(dev)
+            g.set_model(kind, order, Xg, yg)
+            thg = synth.default_thetas(kind, d)
+            got = g.loglik(thg)
+            gotb = g.loglik_batch(np.array([thg, synth.perturbed_thetas(kind, d, seed, 1), thg]))
+            e = O.Emulator(kind, order, Xg, yg, thg)
+            r = yg - e.H @ e.beta
+            ref = -(-0.5 * e.logdet - Ng / 2.0 * 1.83788 - 0.5 * (r @ e.cinverse @ r))
+            g.predict_setup(thg)
+            qg = synth.queries(64, d, 5)
+            m, v = g.predict(qg)
+            mo, vo, _ = e.emulate(qg)
+            gn = {"loglik_rel": abs(got["value"] - ref) / abs(ref),
+                  "loglik_batch_rel": float(max(abs(gotb["value"][0] - ref), abs(gotb["value"][2] - ref)) / abs(ref)),
+                  "sigma2_rel": abs(got["sigma2"] - yg @ e.cinverse @ r / Ng) / abs(got["sigma2"]),
+                  "beta_rel": float(np.max(np.abs(got["beta"] - e.beta)) / np.max(np.abs(e.beta))),
+                  "mean_abs": float(np.max(np.abs(m - mo))), "var_abs": float(np.max(np.abs(v - vo)))}
+            assert max(gn.values()) < 1e-8, gn
+            gate[f"N{Ng}"] = gn
+            g.close()
 
     # ---- region A: likelihood evaluations
     # the K independent evaluations (each at its own fresh theta) are cut into lock-step batches of B and the
