@@ -152,6 +152,7 @@ extern "C" int gpemu_ctx_create(gpemu_ctx **out, int device)
 		{ const char *lp = getenv("GPEMU_GEMM_BIG_TILES"); if (lp && atoi(lp) > 0) gpemu::g_gemm_big_tiles = atoi(lp); }
 		{ const char *lp = getenv("GPEMU_GEMM_BIG_CFG"); if (lp) gpemu::g_gemm_big_cfg = atoi(lp); }
 		{ const char *lp = getenv("GPEMU_GEMM_PRIO"); if (lp) gpemu::g_gemm_prio_mode = atoi(lp); }
+		{ const char *lp = getenv("GPEMU_GEMM_ORDER"); if (lp) gpemu::g_gemm_order = atoi(lp); }
 		{ const char *lp = getenv("GPEMU_LEAF_PRIO"); if (lp) gpemu::g_leaf_prio = atoi(lp); }
 		const char *la0 = getenv("GPEMU_LOOKAHEAD");
 		const bool want_second = la0 ? atoi(la0) != 0 : g_lookahead != 0;   // only the look-ahead schedule uses it

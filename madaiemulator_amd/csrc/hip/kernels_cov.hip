@@ -54,8 +54,17 @@ __device__ __forceinline__ double fast_sqrt(double a)
 __global__ __launch_bounds__(256) void cov_fill_kernel(double *out, long ld, const double *Xr, int nr,
                                                        const double *Xc, int nc, int d, CovParams p, int mode)
 {
-	const int tr = blockIdx.y, tc = blockIdx.x;
-	if ((mode & FILL_LOWER) && tc > tr) return;
+	int tr = blockIdx.y, tc = blockIdx.x;
+	if (mode & FILL_LOWER) {
+		// 1-D grid over the lower-triangular tiles only (row-major: t = tr(tr+1)/2 + tc): empty workgroups are not
+		// free, the dispatcher deals them in order like any other
+		const long t = blockIdx.x;
+		int r = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+		while ((long)r * (r + 1) / 2 > t) r--;
+		while ((long)(r + 1) * (r + 2) / 2 <= t) r++;
+		tr = r;
+		tc = (int)(t - (long)r * (r + 1) / 2);
+	}
 
 	__shared__ double xr_s[FT * (GPEMU_MAX_PARAMS + 1)];
 	__shared__ double tab[32];
@@ -135,6 +144,11 @@ hipError_t launch_cov_fill(hipStream_t s, double *out, long ld, const double *Xr
                            const double *Xc, int nc, int nc_pad, int d, const CovParams &p, int mode)
 {
 	dim3 grid(nc_pad / FT, nr_pad / FT);
+	if (mode & FILL_LOWER) {
+		if (nr_pad != nc_pad) return hipErrorInvalidValue;      // lower-triangle fill is for the square matrix
+		const long nt = nr_pad / FT;
+		grid = dim3((unsigned)(nt * (nt + 1) / 2), 1);
+	}
 	hipLaunchKernelGGL(cov_fill_kernel, grid, dim3(256), 0, s, out, ld, Xr, nr, Xc, nc, d, p, mode);
 	return hipGetLastError();
 }
