@@ -97,6 +97,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 	} else {
 		tm = blockIdx.x % tiles_m;
 		tn = blockIdx.x / tiles_m;
+		// triangular B operand: the k-range grows with the tile column; start with the long tiles so that the tail
+		// of the launch is made of short ones
+		if (g.kend_mode) tn = (g.n + BN - 1) / BN - 1 - tn;
 	}
 	if (g.tri && tn * BN > tm * BM + BM - 1 + g.diag_off) return;
 	const TraceT0 tr0 = trace_begin(g.trace);
