@@ -148,12 +148,8 @@ extern "C" int gpemu_ctx_create(gpemu_ctx **out, int device)
 				if (hipMalloc(&ctx->dTrace, (size_t)ctx->trace_cap * 64) != hipSuccess) { ctx->dTrace = nullptr; ctx->trace_cap = 0; }
 			}
 		}
-		{ const char *lp = getenv("GPEMU_GEMM_LDS_PAD"); if (lp) gpemu::g_gemm_lds_pad = atoi(lp); }
 		{ const char *lp = getenv("GPEMU_GEMM_BIG_TILES"); if (lp && atoi(lp) > 0) gpemu::g_gemm_big_tiles = atoi(lp); }
 		{ const char *lp = getenv("GPEMU_GEMM_BIG_CFG"); if (lp) gpemu::g_gemm_big_cfg = atoi(lp); }
-		{ const char *lp = getenv("GPEMU_GEMM_PRIO"); if (lp) gpemu::g_gemm_prio_mode = atoi(lp); }
-		{ const char *lp = getenv("GPEMU_GEMM_ORDER"); if (lp) gpemu::g_gemm_order = atoi(lp); }
-		{ const char *lp = getenv("GPEMU_LEAF_PRIO"); if (lp) gpemu::g_leaf_prio = atoi(lp); }
 		const char *la0 = getenv("GPEMU_LOOKAHEAD");
 		const bool want_second = la0 ? atoi(la0) != 0 : g_lookahead != 0;   // only the look-ahead schedule uses it
 		int reserve = 32;

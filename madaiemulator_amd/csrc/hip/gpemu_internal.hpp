@@ -52,7 +52,6 @@ struct GemmArgs {
 	int kend_off;
 	long bsC, bsA, bsB;  // element strides between the matrices of a batch (grid.y = nbatch)
 	int nbatch;          // 0/1: single problem
-	int prio_mode;       // experiment switch (GPEMU_GEMM_PRIO)
 	int order_mode;      // 2: dense enumeration of the lower-triangular tiles (set by launch_gemm)
 	unsigned long long *trace;   // optional {first start, last end} device timestamps of this launch (GPEMU_TRACE)
 };
@@ -149,7 +148,7 @@ hipError_t launch_grad_partials(hipStream_t s, const double *S, long lds, int so
 
 // ---- kernels_linalg.hip
 hipError_t launch_gemm(hipStream_t s, const GemmArgs &a);
-extern int g_gemm_lds_pad, g_leaf_prio, g_gemm_big_tiles, g_gemm_big_cfg, g_gemm_prio_mode, g_gemm_order;
+extern int g_gemm_big_tiles, g_gemm_big_cfg;
 hipError_t launch_leaf(hipStream_t s, double *T, long ld, int c0, int m_below, int *info,
                        unsigned long long *trace_factor = nullptr, unsigned long long *trace_solve = nullptr,
                        int nbatch = 1, long bstride = 0);

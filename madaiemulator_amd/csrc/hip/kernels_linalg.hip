@@ -103,24 +103,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 	}
 	if (g.tri && tn * BN > tm * BM + BM - 1 + g.diag_off) return;
 	const TraceT0 tr0 = trace_begin(g.trace);
-	if (g.prio_mode == 1) {
-		// experiment: distinct issue priorities for the workgroups that share a CU (breaks lock-step convoys?)
-		switch ((blockIdx.x >> 3) & 3) {
-		case 1: __builtin_amdgcn_s_setprio(1); break;
-		case 2: __builtin_amdgcn_s_setprio(2); break;
-		case 3: __builtin_amdgcn_s_setprio(3); break;
-		default: break;
-		}
-	} else if (g.prio_mode >= 2) {
-		// experiment: stagger the first round of workgroups over about one tile time so that the C read-modify-write
-		// bursts of the rounds do not all hit HBM at once
-		const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
-		if (lin < 2048) {
-			const int ph = (lin >> 3) & 15;
-			for (int i = 0; i < ph * (g.prio_mode - 1); i++) __builtin_amdgcn_s_sleep(127);
-		}
-	}
-
 	int kb = g.k0, ke = g.k1;
 	if (g.kstart_mode) {
 		int ks = (tm * BM - g.kstart_off) & ~(GEMM_BK - 1);
@@ -314,21 +296,16 @@ int choose_gemm_cfg(const GemmArgs &a)
 	return count_tiles(a, 128, 128) * (a.nbatch > 1 ? a.nbatch : 1) >= g_gemm_big_tiles ? g_gemm_big_cfg : 2;
 }
 
-int g_leaf_prio = 0;
-int g_gemm_prio_mode = 0;
-int g_gemm_order = 0;       // 3: plain 2-D tile enumeration also for triangular updates (GPEMU_GEMM_ORDER, for A/B runs)
-int g_gemm_lds_pad = 0;    // extra dynamic LDS per 64x64-tile workgroup (> 0: three instead of four per CU)
 
 hipError_t launch_gemm(hipStream_t s, const GemmArgs &a_in)
 {
 	GemmArgs a = a_in;
-	a.prio_mode = g_gemm_prio_mode;
 	if (a.m <= 0 || a.n <= 0) return hipSuccess;
 	if (a.beta && a.alpha != 1.0 && a.alpha != -1.0) return hipErrorInvalidValue;   // accumulators start from C/alpha
 	const int nbatch = a.nbatch > 1 ? a.nbatch : 1;
 	const int cfg = choose_gemm_cfg(a);
 	// lower-triangular updates with square tiles enumerate only their non-empty tiles
-	const bool dense_tri = a.tri && a.diag_off == 0 && a.m >= a.n && cfg != 1 && g_gemm_order != 3;
+	const bool dense_tri = a.tri && a.diag_off == 0 && a.m >= a.n && cfg != 1;
 	a.order_mode = dense_tri ? 2 : 0;
 	const int bt = (cfg == 2) ? 64 : 128;
 	const int T = dense_tri ? (int)count_tiles(a, bt, bt)
@@ -340,10 +317,7 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs &a_in)
 	} else if (cfg == 3) {
 		hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 4, 4, 2>), dim3(T, nbatch), dim3(512), 0, s, a);
 	} else {
-		// a launch that fills every CU leaves one of the four workgroup slots' worth of LDS free (pad > 0), so that the
-		// latency-bound panel kernels of OTHER contexts are dispatched at once instead of waiting for a tile to retire
-		const int pad = (count_tiles(a, 64, 64) * nbatch >= 1024) ? g_gemm_lds_pad : 0;
-		hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4>), dim3(T, nbatch), dim3(256), pad, s, a);
+		hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4>), dim3(T, nbatch), dim3(256), 0, s, a);
 	}
 	return hipGetLastError();
 }
@@ -435,14 +409,13 @@ __device__ __forceinline__ void panel_update(double *A, int wave, int lane)
 		}
 }
 
-__global__ __launch_bounds__(256) void leaf_factor_kernel(double *T, long ld, int c0, int *info, int prio, unsigned long long *trace, long bstride)
+__global__ __launch_bounds__(256) void leaf_factor_kernel(double *T, long ld, int c0, int *info, unsigned long long *trace, long bstride)
 {
 	T += (long)blockIdx.y * bstride;     // lock-step batch: one diagonal block per matrix
 	info += blockIdx.y;
 	__shared__ double A[LEAF * LP];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	double *D = T + (long)c0 * ld + c0;
-	if (prio) __builtin_amdgcn_s_setprio(3);   // critical-path kernel: win issue arbitration against co-resident GEMM waves
 	const TraceT0 tr0 = trace_begin(trace);
 	{
 		double v[16];
@@ -557,13 +530,12 @@ __device__ __forceinline__ void tri_inverse16(double *M, int o, double *tile, in
 	tri_inverse16_to<LP, LP>(M, o, tile, lane, M + o * LP + o, LP);
 }
 
-__global__ __launch_bounds__(256) void leaf_solve_kernel(double *T, long ld, int c0, int m_below, int prio, unsigned long long *trace, long bstride)
+__global__ __launch_bounds__(256) void leaf_solve_kernel(double *T, long ld, int c0, int m_below, unsigned long long *trace, long bstride)
 {
 	T += (long)blockIdx.y * bstride;
 	__shared__ double M[LEAF * LP];        // L; diagonal 16x16 blocks replaced by their inverses
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int g = lane >> 4, q = lane & 15;
-	if (prio) __builtin_amdgcn_s_setprio(3);
 	const TraceT0 tr0 = trace_begin(trace);
 	// this wave's 16 panel rows: all 16 values per lane requested up front (one memory latency, overlapped
 	// with staging L and inverting the diagonal blocks)
@@ -845,10 +817,10 @@ hipError_t launch_leaf(hipStream_t s, double *T, long ld, int c0, int m_below, i
                        unsigned long long *trs, int nbatch, long bstride)
 {
 	if (nbatch < 1) nbatch = 1;
-	hipLaunchKernelGGL(leaf_factor_kernel, dim3(1, nbatch), dim3(256), 0, s, T, ld, c0, info, g_leaf_prio, trf, bstride);
+	hipLaunchKernelGGL(leaf_factor_kernel, dim3(1, nbatch), dim3(256), 0, s, T, ld, c0, info, trf, bstride);
 	if (m_below > 0)
 		hipLaunchKernelGGL(leaf_solve_kernel, dim3((m_below + 63) / 64, nbatch), dim3(256), 0, s, T, ld, c0, m_below,
-		                   g_leaf_prio, trs, bstride);
+		                   trs, bstride);
 	return hipGetLastError();
 }
 
