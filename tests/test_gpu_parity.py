@@ -411,6 +411,59 @@ def test_full_size_properties(gpu_ctx, kind, N):
     assert np.all(np.isfinite(m)) and np.all(v > 0) and np.all(v < 2.0 * kappa)
 
 
+# ------------------------------------------------------------------ ragged and extreme shapes
+@pytest.mark.parametrize("N", [2, 3, 63, 64, 65, 127, 129, 513])
+@pytest.mark.parametrize("kind", [1, 3])
+def test_ragged_sizes_full_path(gpu_ctx, kind, N):
+    """N around the 64-column padding granule and the 512-column outer panel: likelihood, batch, gradient
+    (pow-exp) and predictions against the oracle"""
+    d, order = 3, (1 if N > 8 else 0)
+    X, y = synth.design(N, d, 900 + N)
+    y = y + 1.0                                  # the synthetic outputs are standardised: keep beta_0 away from 0
+    th = thetas_for(kind, d)
+    got, _ = check_loglik(gpu_ctx, kind, order, X, y, th)
+    gb = gpu_ctx.loglik_batch(np.array([th, th]))
+    assert gb["value"][0] == got["value"] and gb["value"][1] == got["value"]
+    e = O.Emulator(kind, order, X, y, th)
+    gpu_ctx.predict_setup(th)
+    Xq = np.vstack([synth.queries(5, d, N), X[:1]])
+    m, v = gpu_ctx.predict(Xq)
+    mo, vo, _ = e.emulate(Xq)
+    kappa = O.cov(kind, X[0], X[0], th)
+    assert np.max(np.abs(m - mo)) < RTOL * max(1.0, np.abs(mo).max())
+    assert np.max(np.abs(v - vo)) < RTOL * kappa
+    if kind == 1 and N > 8:
+        th0 = np.concatenate([[0.0], th[1:]])
+        g, rc = gpu_ctx.grad(th0)
+        go, _ = O.grad_fn_multi(kind, order, X, y, th0[1:])
+        assert rc == 0 and np.allclose(g, go, rtol=1e-7, atol=1e-7 * np.abs(go).max())
+
+
+def test_one_point_model(gpu_ctx):
+    """N = 1: C is the scalar amp + nugget"""
+    X, y = np.array([[0.25, 0.5]]), np.array([1.5])
+    th = thetas_for(1, 2)
+    gpu_ctx.set_model(1, 0, X, y)
+    got = gpu_ctx.loglik(th)
+    c = np.exp(th[0]) + np.exp(th[1])
+    assert got["status"] == 0 and got["logdet"] == pytest.approx(np.log(c), rel=1e-14)
+    assert got["beta"][0] == pytest.approx(1.5, rel=1e-14) and abs(got["quad"]) < 1e-20
+
+
+def test_maximum_dimensions(gpu_ctx):
+    """d = GPEMU_MAX_PARAMS = 64 coordinates, and the largest regression basis the augmented rows hold
+    (1 + nreg = 64: d = 31, quadratic)"""
+    X, y = synth.design(200, 64, 77)
+    th = thetas_for(1, 64)
+    th[2:] = np.log(3.0)                     # long length scales: 64-dimensional distances are large
+    check_loglik(gpu_ctx, 1, 0, X, y, th)
+    ref = O.cov_matrix(1, X, th)
+    assert relerr(gpu_ctx.cov_matrix(th), ref) < ELEM_RTOL
+    X, y = synth.design(400, 31, 78)
+    th = thetas_for(1, 31)
+    th[2:] = np.log(2.0)
+    check_loglik(gpu_ctx, 1, 2, X, y, th)                 # nreg = 1 + 2*31 = 63: y and H fill all 64 augmented rows
+
 # ------------------------------------------------------------------ error behaviour at the boundary
 def test_error_codes(gpu_ctx):
     X, y = synth.design(50, 2, 1)
