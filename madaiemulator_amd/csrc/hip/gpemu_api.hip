@@ -175,7 +175,7 @@ extern "C" int gpemu_ctx_create(gpemu_ctx **out, int device)
 	}
 	ctx->res_len = 64 * 64 + 8;
 	if (hipMalloc(&ctx->dInfo, sizeof(int)) != hipSuccess ||
-	    hipMalloc(&ctx->dDiagInv, 8 * 256 * sizeof(double)) != hipSuccess ||
+	    hipMalloc(&ctx->dDiagInv, (size_t)GPEMU_MAX_BATCH * 8 * 256 * sizeof(double)) != hipSuccess ||
 	    hipMalloc(&ctx->dRes, ctx->res_len * sizeof(double)) != hipSuccess ||
 	    hipHostMalloc((void **)&ctx->hRes, ctx->res_len * sizeof(double)) != hipSuccess ||
 	    hipHostMalloc((void **)&ctx->hInfo, sizeof(int)) != hipSuccess) {
@@ -434,10 +434,11 @@ static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv)
 		return launch_leaf(ctx->stream, ctx->dT, ld, c0, row_end - (c0 + LEAF), ctx->dInfo, trf, trs, ctx->nb,
 		                   (long)ctx->T_stride);
 	}
-	if (n == 2 * LEAF && g_leaf128 && ctx->nb == 1) {
+	if (n == 2 * LEAF && g_leaf128) {
 		const int row_end = base_end + (inv ? c0 + 2 * LEAF : 0);
 		ProfScope ps(ctx, GPEMU_PROF_LEAF, 0.0, 0.0);
-		return launch_leaf128(ctx->stream, ctx->dT, ld, c0, row_end - (c0 + 2 * LEAF), ctx->dInfo, ctx->dDiagInv);
+		return launch_leaf128(ctx->stream, ctx->dT, ld, c0, row_end - (c0 + 2 * LEAF), ctx->dInfo, ctx->dDiagInv, ctx->nb,
+		                      (long)ctx->T_stride);
 	}
 	// automatic outer panel width: a batch has enough tiles per launch to afford the longer panel chain of a wider
 	// panel and gains from the larger K of its trailing updates (measured: 3.77 -> 3.55 ms per evaluation at 2x16)

@@ -152,7 +152,8 @@ extern int g_gemm_big_tiles, g_gemm_big_cfg;
 hipError_t launch_leaf(hipStream_t s, double *T, long ld, int c0, int m_below, int *info,
                        unsigned long long *trace_factor = nullptr, unsigned long long *trace_solve = nullptr,
                        int nbatch = 1, long bstride = 0);
-hipError_t launch_leaf128(hipStream_t s, double *T, long ld, int c0, int m_below, int *info, double *dinv);
+hipError_t launch_leaf128(hipStream_t s, double *T, long ld, int c0, int m_below, int *info, double *dinv,
+                          int nbatch = 1, long bstride = 0);
 hipError_t launch_gram_partials(hipStream_t s, const double *Z, long ld, int Np, int nrhs, int Rp, double *part,
                                 int nbatch = 1, long zstride = 0);
 hipError_t launch_finish(hipStream_t s, const double *part, int nparts, int Rp, int nrhs, const double *T, long ld,

@@ -640,8 +640,11 @@ __device__ __forceinline__ void solve_rows_lds(double *A, int row0, const double
 		for (int r = 0; r < 4; r++) A[(row0 + q) * LD + 16 * j + g + 4 * r] = X[j - J0][r];
 }
 
-__global__ __launch_bounds__(256) void leaf128_factor_kernel(double *T, long ld, int c0, int *info, double *dinv)
+__global__ __launch_bounds__(256) void leaf128_factor_kernel(double *T, long ld, int c0, int *info, double *dinv, long bstride)
 {
+	T += (long)blockIdx.y * bstride;          // lock-step batch
+	info += blockIdx.y;
+	dinv += (long)blockIdx.y * 8 * 256;
 	__shared__ double A[L2 * LP2];
 	__shared__ double Inv[8 * 256];
 	__shared__ double Xs[4][16 * 17];
@@ -732,8 +735,10 @@ __global__ __launch_bounds__(256) void leaf128_factor_kernel(double *T, long ld,
 	for (int e = tid; e < 8 * 256; e += 256) dinv[e] = Inv[e];
 }
 
-__global__ __launch_bounds__(256) void leaf128_solve_kernel(double *T, long ld, int c0, int m_below, const double *dinv)
+__global__ __launch_bounds__(256) void leaf128_solve_kernel(double *T, long ld, int c0, int m_below, const double *dinv, long bstride)
 {
+	T += (long)blockIdx.y * bstride;
+	dinv += (long)blockIdx.y * 8 * 256;
 	__shared__ double M[L2 * LP2];
 	__shared__ double Inv[8 * 256];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -805,11 +810,14 @@ __global__ __launch_bounds__(256) void leaf128_solve_kernel(double *T, long ld, 
 	}
 }
 
-hipError_t launch_leaf128(hipStream_t s, double *T, long ld, int c0, int m_below, int *info, double *dinv)
+hipError_t launch_leaf128(hipStream_t s, double *T, long ld, int c0, int m_below, int *info, double *dinv, int nbatch,
+                          long bstride)
 {
-	hipLaunchKernelGGL(leaf128_factor_kernel, dim3(1), dim3(256), 0, s, T, ld, c0, info, dinv);
+	if (nbatch < 1) nbatch = 1;
+	hipLaunchKernelGGL(leaf128_factor_kernel, dim3(1, nbatch), dim3(256), 0, s, T, ld, c0, info, dinv, bstride);
 	if (m_below > 0)
-		hipLaunchKernelGGL(leaf128_solve_kernel, dim3((m_below + 63) / 64), dim3(256), 0, s, T, ld, c0, m_below, dinv);
+		hipLaunchKernelGGL(leaf128_solve_kernel, dim3((m_below + 63) / 64, nbatch), dim3(256), 0, s, T, ld, c0, m_below,
+		                   dinv, bstride);
 	return hipGetLastError();
 }
 
