@@ -113,6 +113,13 @@ int gpemu_grad(gpemu_ctx *ctx, const double *thetas, int nthetas, double *grad, 
  * fills and factors twice).  neg_loglik is the evalFnMulti value (theta[0] taken as 0). */
 int gpemu_loglik_grad(gpemu_ctx *ctx, const double *thetas, int nthetas, double *neg_loglik, double *sigma2,
                       double *beta, double *grad, int *info);
+/* a13 over a list of thetas: the value+gradient pairs the independent restarts of maxWithMultiMin
+ * (libEmu/maxmultimin.c:82-119) ask for at the same time.  The nb factorisations (with their inverse
+ * rows) run in lock-step; outputs as gpemu_loglik_grad per element (grad: nb rows of nthetas-1),
+ * status[b] = GPEMU_OK / GPEMU_ERR_NOT_PD / GPEMU_ERR_REGRESSION.  Workspace nb*(2N+64)*N*8 bytes. */
+int gpemu_loglik_grad_batch(gpemu_ctx *ctx, int nb, const double *thetas, int nthetas,
+                            double *neg_loglik, double *sigma2, double *beta, double *grad,
+                            int *info, int *status);
 
 /* ---- a14/a15: chol_inverse_cov_matrix + alloc_emulator_struct -------
  * (libEmu/emulate-fns.c:275-299, emulator_struct.c:13-37)

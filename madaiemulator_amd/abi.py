@@ -38,6 +38,7 @@ SYMBOLS = {
     "gpemu_loglik_batch_collect": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _ip]),
     "gpemu_grad": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _ip]),
     "gpemu_loglik_grad": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _dp, _dp, _dp, _ip]),
+    "gpemu_loglik_grad_batch": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, _dp, _dp, _dp, _dp, _ip, _ip]),
     "gpemu_predict_setup": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _ip]),
     "gpemu_get_cinverse": (C.c_int, [C.c_void_p, _dp]),
     "gpemu_predict_batch": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
@@ -196,6 +197,19 @@ class Context:
         """nb evaluations in lock-step (thetas: nb x nthetas) -> dict of arrays, as loglik() per element"""
         self.loglik_batch_enqueue(thetas)
         return self.loglik_batch_collect()
+
+    def loglik_grad_batch(self, thetas):
+        """value + gradient at nb thetas in lock-step -> dict(value, sigma2, beta, grad (nb x nthetas-1), info, status)"""
+        th = _a(thetas).reshape(-1, np.shape(thetas)[-1])
+        nb, nt = th.shape
+        v, s2 = np.full(nb, np.nan), np.full(nb, np.nan)
+        beta = np.full((nb, self.nreg), np.nan)
+        g = np.full((nb, nt - 1), np.nan)
+        info = np.zeros(nb, dtype=np.int32)
+        status = np.zeros(nb, dtype=np.int32)
+        self._chk(self.L.gpemu_loglik_grad_batch(self.h, nb, _p(th), nt, _p(v), _p(s2), _p(beta), _p(g),
+                                                 info.ctypes.data_as(_ip), status.ctypes.data_as(_ip)))
+        return dict(value=v, sigma2=s2, beta=beta, grad=g, info=info, status=status)
 
     # -- a12 ---------------------------------------------------------------
     def grad(self, thetas):

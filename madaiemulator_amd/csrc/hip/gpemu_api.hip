@@ -205,7 +205,7 @@ static void free_model(gpemu_ctx *ctx)
 {
 	free_graphs(ctx);
 	double **ptrs[] = {&ctx->dX, &ctx->dY, &ctx->dRrows, &ctx->dT, &ctx->dGramPart, &ctx->dLinvAug, &ctx->dBetaQ,
-	                   &ctx->dKq, &ctx->dV, &ctx->dXq, &ctx->dMean, &ctx->dVar, &ctx->dS, &ctx->dGradPart};
+	                   &ctx->dKq, &ctx->dV, &ctx->dXq, &ctx->dMean, &ctx->dVar, &ctx->dS, &ctx->dGradPart, &ctx->dAlpha};
 	for (auto p : ptrs) { if (*p) hipFree(*p); *p = nullptr; }
 	ctx->T_rows = 0; ctx->pred_ready = false; ctx->cinv_ready = false; ctx->pred_batch = 0; ctx->stage_cap = 0;
 	ctx->S_dim = 0; ctx->gradpart_len = 0;
@@ -943,7 +943,7 @@ extern "C" int gpemu_predict_batch(gpemu_ctx *ctx, int M, const double *xq, doub
 // explicit inverse: S = Aug Aug^T with Aug = [Z^T ; U]  ->  S[Rp+i][Rp+j] = (C^-1)_ij,
 // S[Rp+i][a] = (C^-1 [y|H])_ia   (lower triangle only)
 // ---------------------------------------------------------------------------
-static int build_corner(gpemu_ctx *ctx)
+static int build_corner(gpemu_ctx *ctx, int b = 0)
 {
 	const int Np = ctx->Np, Rp = ctx->Rp;
 	const size_t dim = (size_t)Np + Rp;
@@ -955,7 +955,7 @@ static int build_corner(gpemu_ctx *ctx)
 	GemmArgs g;
 	memset(&g, 0, sizeof g);
 	g.C = ctx->dS; g.ldc = (long)dim;
-	g.A = ctx->dT + (size_t)Np * Np; g.lda = Np;
+	g.A = ctx->dT + (size_t)b * ctx->T_stride + (size_t)Np * Np; g.lda = Np;
 	g.B = g.A; g.ldb = Np;
 	g.m = (int)dim; g.n = (int)dim; g.k0 = 0; g.k1 = Np; g.alpha = 1.0; g.beta = 0;
 	g.tri = 1; g.diag_off = 0;
@@ -1016,37 +1016,24 @@ extern "C" int gpemu_loglik_grad(gpemu_ctx *ctx, const double *thetas, int nthet
 	return GPEMU_OK;
 }
 
-static int grad_impl(gpemu_ctx *ctx, const double *thetas, int nthetas, double *grad, int *info, HostLik *lik_out)
+// second half of a gradient evaluation: matrix b of the workspace holds the factorisation with its inverse rows
+// (U = L^-T); builds C^-1 = U U^T and reduces tr(C^-1 dC_k), alpha^T dC_k alpha over its tiles
+static int grad_finish(gpemu_ctx *ctx, int b, const double *th /* full thetas, th[0] = 0 */, const HostLik &r, double *grad)
 {
-	if (!ctx || !grad) return GPEMU_ERR_ARG;
-	if (!ctx->dX) return fail(ctx, GPEMU_ERR_STATE, "model not set");
-	if (ctx->kind != GPEMU_POWEREXP)
-		return fail(ctx, GPEMU_ERR_ARG,
-		            "gradient only for the power-exponential kernel: the reference's Matern derivative matrices "
-		            "carry an accumulator across elements (emulator.c:410-425) and cannot be reproduced in parallel");
-	if (nthetas < ctx->d + 2) return fail(ctx, GPEMU_ERR_ARG, "nthetas too small");
-	std::vector<double> th(thetas, thetas + nthetas);
-	th[0] = 0.0;                                      // maxmultimin.c:441
-	ctx->pred_ready = false; ctx->cinv_ready = false;
-	CovParams p;
-	int rc = factor_with_inverse(ctx, th.data(), nthetas, &p, info);
-	if (rc) return rc;
-	HostLik r = host_likelihood(ctx);
-	if (r.status) return fail(ctx, r.status, "H^T C^-1 H is not positive definite");
-	if (lik_out) *lik_out = r;
-	rc = build_corner(ctx);
+	int rc = build_corner(ctx, b);
 	if (rc) return rc;
 	const int N = ctx->N, d = ctx->d, Rp = ctx->Rp;
 	const size_t dim = ctx->S_dim;
-	// alpha = C^-1 y  = column 0 of the [I rows x R cols] block
-	double *dAlpha = nullptr, *dGp = nullptr;
-	HIPCHK(ctx, hipMalloc(&dAlpha, (size_t)N * sizeof(double)));
-	hipError_t e = hipMalloc(&dGp, (size_t)d * sizeof(double));
+	// alpha = C^-1 y  = column 0 of the [I rows x R cols] block (scratch kept with the context: hipMalloc/hipFree per
+	// call are synchronous and cost more than the reduction kernel)
+	if (!ctx->dAlpha) HIPCHK(ctx, hipMalloc(&ctx->dAlpha, ((size_t)ctx->Np + GPEMU_MAX_PARAMS) * sizeof(double)));
+	double *dAlpha = ctx->dAlpha, *dGp = ctx->dAlpha + ctx->Np;
+	hipError_t e = hipSuccess;
 	if (e == hipSuccess)
 		e = hipMemcpy2DAsync(dAlpha, sizeof(double), ctx->dS + (size_t)Rp * dim, dim * sizeof(double), sizeof(double), N,
 		                     hipMemcpyDeviceToDevice, ctx->stream);
 	if (e == hipSuccess)
-		e = hipMemcpyAsync(dGp, th.data() + 2, (size_t)d * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+		e = hipMemcpyAsync(dGp, th + 2, (size_t)d * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
 	const int nt = (N + 63) / 64, ntiles = nt * (nt + 1) / 2;
 	const size_t need = (size_t)ntiles * (2 * d + 1);
 	if (e == hipSuccess && ctx->gradpart_len < need) {
@@ -1065,8 +1052,6 @@ static int grad_impl(gpemu_ctx *ctx, const double *thetas, int nthetas, double *
 	if (e == hipSuccess)
 		e = hipMemcpyAsync(alpha.data(), dAlpha, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-	hipFree(dAlpha);
-	if (dGp) hipFree(dGp);
 	HIPCHK(ctx, e);
 	std::vector<double> sums(2 * d + 1, 0.0);
 	for (int t = 0; t < nparts; t++)
@@ -1079,6 +1064,91 @@ static int grad_impl(gpemu_ctx *ctx, const double *thetas, int nthetas, double *
 	grad[0] = -1.0 * (-0.5 * nug * sums[2 * d] + 0.5 * nug * aa);
 	for (int k = 0; k < d; k++)
 		grad[k + 1] = -1.0 * (amp * (-0.5 * sums[2 * k] + 0.5 * sums[2 * k + 1]));
+	return GPEMU_OK;
+}
+
+static int grad_check_args(gpemu_ctx *ctx, int nthetas)
+{
+	if (!ctx->dX) return fail(ctx, GPEMU_ERR_STATE, "model not set");
+	if (ctx->kind != GPEMU_POWEREXP)
+		return fail(ctx, GPEMU_ERR_ARG,
+		            "gradient only for the power-exponential kernel: the reference's Matern derivative matrices "
+		            "carry an accumulator across elements (emulator.c:410-425) and cannot be reproduced in parallel");
+	if (nthetas < ctx->d + 2) return fail(ctx, GPEMU_ERR_ARG, "nthetas too small");
+	return GPEMU_OK;
+}
+
+static int grad_impl(gpemu_ctx *ctx, const double *thetas, int nthetas, double *grad, int *info, HostLik *lik_out)
+{
+	if (!ctx || !grad) return GPEMU_ERR_ARG;
+	int rc = grad_check_args(ctx, nthetas);
+	if (rc) return rc;
+	std::vector<double> th(thetas, thetas + nthetas);
+	th[0] = 0.0;                                      // maxmultimin.c:441
+	ctx->pred_ready = false; ctx->cinv_ready = false;
+	CovParams p;
+	rc = factor_with_inverse(ctx, th.data(), nthetas, &p, info);
+	if (rc) return rc;
+	HostLik r = host_likelihood(ctx);
+	if (r.status) return fail(ctx, r.status, "H^T C^-1 H is not positive definite");
+	if (lik_out) *lik_out = r;
+	return grad_finish(ctx, 0, th.data(), r, grad);
+}
+
+// evalFnGradMulti for a list of thetas (the line-search points of independent restarts): the nb factorisations with
+// their inverse rows run in lock-step (as gpemu_loglik_batch), then C^-1 and the gradient reductions element by
+// element (those launches fill the chip on their own).  status[b] as gpemu_loglik_grad would return for element b.
+extern "C" int gpemu_loglik_grad_batch(gpemu_ctx *ctx, int nb, const double *thetas, int nthetas, double *neg_loglik,
+                                       double *sigma2, double *beta, double *grad, int *info, int *status)
+{
+	if (!ctx || !grad || !thetas) return GPEMU_ERR_ARG;
+	int rc = grad_check_args(ctx, nthetas);
+	if (rc) return rc;
+	if (nb < 1 || nb > GPEMU_MAX_BATCH) return fail(ctx, GPEMU_ERR_ARG, "batch size must be 1..GPEMU_MAX_BATCH");
+	std::vector<double> th((size_t)nb * nthetas);
+	std::vector<CovParams> ps((size_t)nb);
+	for (int b = 0; b < nb; b++) {
+		for (int i = 0; i < nthetas; i++) th[(size_t)b * nthetas + i] = thetas[(size_t)b * nthetas + i];
+		th[(size_t)b * nthetas] = 0.0;                // maxmultimin.c:441
+		rc = make_cov_params(ctx, &th[(size_t)b * nthetas], nthetas, &ps[b]);
+		if (rc) return rc;
+	}
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	ctx->pred_ready = false; ctx->cinv_ready = false;
+	rc = stage_matrices(ctx, ps.data(), nb, 1);
+	if (rc) return rc;
+	rc = run_potrf(ctx, 1);
+	if (rc) return rc;
+	rc = enqueue_results(ctx);
+	if (rc) return rc;
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	const int ng = nthetas - 1;
+	for (int b = 0; b < nb; b++) {
+		const int inf = (ctx->hInfo[b] >= INFO_NONE) ? 0 : ctx->hInfo[b];
+		if (info) info[b] = inf;
+		int st = GPEMU_OK;
+		double val = NAN, s2 = NAN;
+		for (int i = 0; i < ng; i++) grad[(size_t)b * ng + i] = NAN;
+		if (beta) for (int a = 0; a < ctx->nreg; a++) beta[(size_t)b * ctx->nreg + a] = NAN;
+		if (inf) {
+			st = fail(ctx, GPEMU_ERR_NOT_PD, "covariance matrix is not positive definite");
+		} else {
+			HostLik r = host_likelihood(ctx, b);
+			if (r.status) {
+				st = fail(ctx, r.status, "H^T C^-1 H is not positive definite");
+			} else {
+				st = grad_finish(ctx, b, &th[(size_t)b * nthetas], r, grad + (size_t)b * ng);
+				if (st != GPEMU_OK) return st;                                   // HIP failure: give up on the batch
+				const double log_2_pi = 1.83788;
+				val = -1 * (-(1.0 / 2.0) * r.logdet - (ctx->N / 2.0) * log_2_pi + r.quad * (-1.0 / 2.0));
+				s2 = r.sigma2;
+				if (beta) for (int a = 0; a < ctx->nreg; a++) beta[(size_t)b * ctx->nreg + a] = r.beta[a];
+			}
+		}
+		if (neg_loglik) neg_loglik[b] = val;
+		if (sigma2) sigma2[b] = s2;
+		if (status) status[b] = st;
+	}
 	return GPEMU_OK;
 }
 

@@ -120,6 +120,7 @@ struct gpemu_ctx {
 
 	// gradient scratch
 	double *dGradPart = nullptr;
+	double *dAlpha = nullptr;    // Np doubles of alpha = C^-1 y, then the d length-scale thetas
 	size_t gradpart_len = 0;
 
 	gpemu::ProfState prof;

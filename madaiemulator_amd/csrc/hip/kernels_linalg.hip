@@ -87,6 +87,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 		// enumeration launches the empty upper tiles too; they exit at once, but the dispatcher deals workgroups in
 		// order and runs of hundreds of empty ones starve the CUs: 54 -> 67 TFLOP/s on a 16384^2 x 1024 update.
 		const long t = blockIdx.x;
+		if (g.kstart_mode && g.m == g.n) {
+			// rows of the operand start at k = row: tile rows are ordered by decreasing work -> row-major enumeration
+			// (t = r(r+1)/2 + c) puts the long-K tiles first and leaves the short ones for the tail of the launch
+			int r = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+			while ((long)r * (r + 1) / 2 > t) r--;
+			while ((long)(r + 1) * (r + 2) / 2 <= t) r++;
+			tm = r;
+			tn = (int)(t - (long)r * (r + 1) / 2);
+		} else {
 		const double b2 = 2.0 * tiles_m + 1.0;
 		int j = (int)((b2 - sqrt(b2 * b2 - 8.0 * (double)t)) * 0.5);
 		if (j < 0) j = 0;
@@ -94,6 +103,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 		while ((long)(j + 1) * tiles_m - (long)(j + 1) * j / 2 <= t) j++;
 		tn = j;
 		tm = j + (int)(t - ((long)j * tiles_m - (long)j * (j - 1) / 2));
+		}
 	} else {
 		tm = blockIdx.x % tiles_m;
 		tn = blockIdx.x / tiles_m;

@@ -136,16 +136,160 @@ static void note_not_pd(const char *who, const double *th, int nthetas)
 	}
 }
 
+/* ---------------------------------------------------------------- lock-step groups
+ * The restarts of a search are independent BFGS runs that each ask for one likelihood (+gradient) at a time
+ * (maxmultimin.c:82-119; one pthread each in estimate_threaded.c).  A group makes n such threads share ONE device
+ * context: a thread deposits its theta and sleeps; the last one to arrive (or to leave) sends all deposited thetas to
+ * the device as one lock-step batch (gpemu_loglik_batch / gpemu_loglik_grad_batch) and wakes the others.  The
+ * minimiser code is unchanged -- the batching happens underneath evalFnMulti / evalFnGradMulti. */
+struct group {
+	pthread_mutex_t mu;
+	pthread_cond_t cv;
+	int nlive, narrived, cap, nthetas;
+	unsigned long generation;
+	modelstruct *model;
+	const void **members;
+	int nmembers;
+	double *th, *val, *sigma2, *grad;
+	int *want_grad, *status;
+	struct group *next;
+};
+static struct group *g_groups = NULL;
+
+static struct group *find_group(const void *params)
+{
+	struct group *G;
+	pthread_mutex_lock(&g_lock);
+	for (G = g_groups; G; G = G->next) {
+		for (int i = 0; i < G->nmembers; i++)
+			if (G->members[i] == params) { pthread_mutex_unlock(&g_lock); return G; }
+	}
+	pthread_mutex_unlock(&g_lock);
+	return NULL;
+}
+
+void *gpemu_host_group_create(struct estimate_thetas_params **members, int n)
+{
+	if (n < 1 || n > GPEMU_MAX_BATCH) return NULL;
+	struct group *G = (struct group *)calloc(1, sizeof *G);
+	pthread_mutex_init(&G->mu, NULL);
+	pthread_cond_init(&G->cv, NULL);
+	G->nlive = n; G->cap = n; G->nmembers = n;
+	G->nthetas = members[0]->options->nthetas;
+	G->model = members[0]->the_model;
+	G->members = (const void **)malloc(sizeof(void *) * (size_t)n);
+	for (int i = 0; i < n; i++) G->members[i] = members[i];
+	G->th = (double *)calloc((size_t)n * G->nthetas, sizeof(double));
+	G->val = (double *)calloc((size_t)n, sizeof(double));
+	G->sigma2 = (double *)calloc((size_t)n, sizeof(double));
+	G->grad = (double *)calloc((size_t)n * G->nthetas, sizeof(double));
+	G->want_grad = (int *)calloc((size_t)n, sizeof(int));
+	G->status = (int *)calloc((size_t)n, sizeof(int));
+	pthread_mutex_lock(&g_lock);
+	G->next = g_groups;
+	g_groups = G;
+	pthread_mutex_unlock(&g_lock);
+	return G;
+}
+
+void gpemu_host_group_destroy(void *group)
+{
+	struct group *G = (struct group *)group;
+	if (!G) return;
+	pthread_mutex_lock(&g_lock);
+	for (struct group **pp = &g_groups; *pp; pp = &(*pp)->next)
+		if (*pp == G) { *pp = G->next; break; }
+	pthread_mutex_unlock(&g_lock);
+	gpemu_host_release(G);                       /* the shared device context is keyed by the group */
+	pthread_mutex_destroy(&G->mu);
+	pthread_cond_destroy(&G->cv);
+	free(G->members); free(G->th); free(G->val); free(G->sigma2); free(G->grad); free(G->want_grad); free(G->status);
+	free(G);
+}
+
+/* all live members have deposited a request: one or two device batches (value-only requests, value+gradient
+ * requests), results into the slots.  Called with G->mu held. */
+static void group_run_round(struct group *G)
+{
+	const int n = G->narrived, nt = G->nthetas;
+	gpemu_ctx *ctx = bind_model(G, G->model, "lock-step group");
+	double *th = (double *)malloc(sizeof(double) * (size_t)n * nt);
+	double *val = (double *)malloc(sizeof(double) * (size_t)n), *s2 = (double *)malloc(sizeof(double) * (size_t)n);
+	double *gr = (double *)malloc(sizeof(double) * (size_t)n * nt);
+	int *st = (int *)malloc(sizeof(int) * (size_t)n), *idx = (int *)malloc(sizeof(int) * (size_t)n);
+	for (int pass = 0; pass < 2; pass++) {       /* pass 0: value only, pass 1: value + gradient */
+		int m = 0;
+		for (int i = 0; i < n; i++)
+			if (G->want_grad[i] == pass) { memcpy(th + (size_t)m * nt, G->th + (size_t)i * nt, sizeof(double) * (size_t)nt); idx[m++] = i; }
+		if (!m) continue;
+		int rc = pass == 0 ? gpemu_loglik_batch(ctx, m, th, nt, val, s2, NULL, NULL, NULL, NULL, st)
+		                   : gpemu_loglik_grad_batch(ctx, m, th, nt, val, s2, NULL, gr, NULL, st);
+		if (rc) die(ctx, rc, "lock-step group");
+		for (int k = 0; k < m; k++) {
+			const int i = idx[k];
+			G->val[i] = val[k]; G->sigma2[i] = s2[k]; G->status[i] = st[k];
+			if (pass == 1) memcpy(G->grad + (size_t)i * nt, gr + (size_t)k * (nt - 1), sizeof(double) * (size_t)(nt - 1));
+		}
+	}
+	free(th); free(val); free(s2); free(gr); free(st); free(idx);
+}
+
+/* one member's request; returns the device status of ITS element */
+static int group_eval(struct group *G, const double *th, int want_grad, double *val, double *sigma2, double *grad)
+{
+	pthread_mutex_lock(&G->mu);
+	const int slot = G->narrived++;
+	memcpy(G->th + (size_t)slot * G->nthetas, th, sizeof(double) * (size_t)G->nthetas);
+	G->want_grad[slot] = want_grad ? 1 : 0;
+	const unsigned long gen = G->generation;
+	if (G->narrived == G->nlive) {
+		group_run_round(G);
+		G->narrived = 0;
+		G->generation++;
+		pthread_cond_broadcast(&G->cv);
+	} else {
+		while (G->generation == gen) pthread_cond_wait(&G->cv, &G->mu);
+	}
+	if (val) *val = G->val[slot];
+	if (sigma2) *sigma2 = G->sigma2[slot];
+	if (grad) memcpy(grad, G->grad + (size_t)slot * G->nthetas, sizeof(double) * (size_t)(G->nthetas - 1));
+	const int st = G->status[slot];
+	pthread_mutex_unlock(&G->mu);
+	return st;
+}
+
+/* a member's thread has finished its restarts: the others no longer wait for it */
+void gpemu_host_group_leave(void *params)
+{
+	struct group *G = find_group(params);
+	if (!G) return;
+	pthread_mutex_lock(&G->mu);
+	G->nlive--;
+	if (G->nlive > 0 && G->narrived == G->nlive) {
+		group_run_round(G);
+		G->narrived = 0;
+		G->generation++;
+		pthread_cond_broadcast(&G->cv);
+	}
+	pthread_mutex_unlock(&G->mu);
+	pthread_mutex_lock(&g_lock);
+	for (int i = 0; i < G->nmembers; i++)
+		if (G->members[i] == params) G->members[i] = NULL;
+	pthread_mutex_unlock(&g_lock);
+}
+
 /* libEmu/maxmultimin.c:288-394 */
 double evalFnMulti(const gsl_vector *theta_vec_less_amp, void *params_in)
 {
 	struct estimate_thetas_params *params = (struct estimate_thetas_params *)params_in;
 	const int nthetas = params->options->nthetas;
-	gpemu_ctx *ctx = bind_model(params, params->the_model, "evalFnMulti");
+	struct group *G = find_group(params);
+	gpemu_ctx *ctx = G ? NULL : bind_model(params, params->the_model, "evalFnMulti");
 	double *th = full_thetas(theta_vec_less_amp, nthetas);
 	double val = GSL_NAN;
 	int info = 0;
-	int rc = gpemu_loglik(ctx, th, nthetas, &val, NULL, NULL, NULL, NULL, &info);
+	int rc = G ? group_eval(G, th, 0, &val, NULL, NULL)
+	           : gpemu_loglik(ctx, th, nthetas, &val, NULL, NULL, NULL, NULL, &info);
 	if (rc == GPEMU_ERR_NOT_PD) {
 		note_not_pd("evalFnMulti", th, nthetas);
 		val = GSL_NAN;
@@ -212,11 +356,12 @@ void gradFnMulti(const gsl_vector *theta_vec_less_amp, void *params_in, gsl_vect
 {
 	struct estimate_thetas_params *params = (struct estimate_thetas_params *)params_in;
 	const int nthetas = params->options->nthetas;
-	gpemu_ctx *ctx = bind_model(params, params->the_model, "gradFnMulti");
+	struct group *G = find_group(params);
+	gpemu_ctx *ctx = G ? NULL : bind_model(params, params->the_model, "gradFnMulti");
 	double *th = full_thetas(theta_vec_less_amp, nthetas);
 	double *g = (double *)malloc(sizeof(double) * (size_t)(nthetas - 1));
 	int info = 0;
-	int rc = gpemu_grad(ctx, th, nthetas, g, &info);
+	int rc = G ? group_eval(G, th, 1, NULL, NULL, g) : gpemu_grad(ctx, th, nthetas, g, &info);
 	if (rc) grad_failure(ctx, rc, th, nthetas);
 	for (int i = 0; i < nthetas - 1; i++) gsl_vector_set(grad_vec, i, g[i]);
 	free(g); free(th);
@@ -227,11 +372,12 @@ void evalFnGradMulti(const gsl_vector *theta_vec, void *params_in, double *fnval
 {
 	struct estimate_thetas_params *params = (struct estimate_thetas_params *)params_in;
 	const int nthetas = params->options->nthetas;
-	gpemu_ctx *ctx = bind_model(params, params->the_model, "evalFnGradMulti");
+	struct group *G = find_group(params);
+	gpemu_ctx *ctx = G ? NULL : bind_model(params, params->the_model, "evalFnGradMulti");
 	double *th = full_thetas(theta_vec, nthetas);
 	double *g = (double *)malloc(sizeof(double) * (size_t)(nthetas - 1));
 	int info = 0;
-	int rc = gpemu_loglik_grad(ctx, th, nthetas, fnval, NULL, NULL, g, &info);
+	int rc = G ? group_eval(G, th, 1, fnval, NULL, g) : gpemu_loglik_grad(ctx, th, nthetas, fnval, NULL, NULL, g, &info);
 	if (rc == GPEMU_ERR_NOT_PD) {
 		/* The reference would return GSL_NAN from evalFnMulti and then exit(EXIT_FAILURE) inside gradFnMulti
 		 * (maxmultimin.c:349,495) -- a line-search trial point that is numerically not positive definite kills
@@ -252,11 +398,12 @@ double estimateSigmaFull(gsl_vector *thetas_less_amp, void *params_in)
 {
 	struct estimate_thetas_params *params = (struct estimate_thetas_params *)params_in;
 	const int nthetas = params->options->nthetas;
-	gpemu_ctx *ctx = bind_model(params, params->the_model, "estimateSigmaFull");
+	struct group *G = find_group(params);
+	gpemu_ctx *ctx = G ? NULL : bind_model(params, params->the_model, "estimateSigmaFull");
 	double *th = full_thetas(thetas_less_amp, nthetas);
 	double s2 = GSL_NAN;
 	int info = 0;
-	int rc = gpemu_loglik(ctx, th, nthetas, NULL, &s2, NULL, NULL, NULL, &info);
+	int rc = G ? group_eval(G, th, 0, NULL, &s2, NULL) : gpemu_loglik(ctx, th, nthetas, NULL, &s2, NULL, NULL, NULL, &info);
 	if (rc == GPEMU_ERR_NOT_PD) { note_not_pd("estSigmaFull", th, nthetas); s2 = GSL_NAN; }
 	else if (rc) die(ctx, rc, "estimateSigmaFull");
 	free(th);

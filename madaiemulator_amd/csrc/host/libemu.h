@@ -191,6 +191,12 @@ void gpemu_host_set_device(int device);          /* HIP device used by contexts 
 void gpemu_host_set_seed(unsigned long seed);    /* 0 = /dev/urandom as the reference (estimate_threaded.c:159) */
 void gpemu_host_set_search(int nthreads, int restarts_per_job);   /* defaults: 1 thread (1 GPU stream), 50 restarts */
 void gpemu_host_release(void *params_or_emulator); /* drop the device context cached for a params / emulator pointer */
+/* lock-step group: n restart threads (one struct estimate_thetas_params each, same model) share one device context;
+ * their concurrent evalFnMulti / gradFnMulti / evalFnGradMulti / estimateSigmaFull calls are gathered into device
+ * batches.  A member's thread calls gpemu_host_group_leave(params) when it will make no further calls. */
+void *gpemu_host_group_create(struct estimate_thetas_params **members, int n);
+void gpemu_host_group_leave(void *params);
+void gpemu_host_group_destroy(void *group);
 
 #ifdef __cplusplus
 }

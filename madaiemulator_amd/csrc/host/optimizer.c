@@ -251,14 +251,15 @@ struct pool {
 	double best_likelyhood_val;
 };
 
-struct worker { struct pool *pool; struct estimate_thetas_params params; int id; };
+struct worker { struct pool *pool; struct estimate_thetas_params params; int id; int in_group; };
 
 static void *worker_main(void *arg)
 {
 	struct worker *w = (struct worker *)arg;
 	struct pool *P = w->pool;
-	for (;;) {
+	for (int round = 0;; round++) {
 		int job;
+		if (w->in_group && round > 0) break;      /* lock-step group: exactly one job per member thread */
 		pthread_mutex_lock(&P->job_lock);
 		job = (P->jobnumber == P->ntries) ? -1 : P->jobnumber++;
 		pthread_mutex_unlock(&P->job_lock);
@@ -275,13 +276,16 @@ static void *worker_main(void *arg)
 		}
 		pthread_mutex_unlock(&P->result_lock);
 	}
+	if (w->in_group) gpemu_host_group_leave(&w->params);
 	return NULL;
 }
 
 /* libEmu/estimate_threaded.c:78-237.  The reference starts one pthread per CPU, each running jobs of 50 restarts
- * on its own copy of the model.  Here a worker is a host thread with its own device context (HIP stream + HBM
- * workspace); the default is one worker (the GPU serialises the N^3 work anyway), GPEMU_NTHREADS / GPEMU_JOBS /
- * gpemu_host_set_search change it; jobs default to the worker count as in the reference (:101-103). */
+ * on its own copy of the model.  Here the restarts run as a LOCK-STEP GROUP (default, pow-exp models): up to 16
+ * host threads, each an ordinary sequential BFGS run, share one device context; whenever all of them have asked for
+ * a likelihood (+gradient) the requests go to the GPU as one batch (device_bridge.c).  The restarts of a job
+ * (GPEMU_RESTARTS, default 50, times GPEMU_JOBS) are dealt evenly to the group's threads.  GPEMU_LOCKSTEP=1 (or a
+ * Matern model) gives the older scheme: GPEMU_NTHREADS workers with one device context each, one job at a time. */
 void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 {
 	int nthreads = g_nthreads > 0 ? g_nthreads : 1;
@@ -294,6 +298,19 @@ void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 	int restarts = g_restarts;
 	env = getenv("GPEMU_RESTARTS");
 	if (env && atoi(env) > 0) restarts = atoi(env);
+	int lockstep = 16;
+	env = getenv("GPEMU_LOCKSTEP");
+	if (env && atoi(env) > 0) lockstep = atoi(env);
+	if (lockstep > 64) lockstep = 64;
+	if (options->cov_fn_index != POWEREXPCOVFN) lockstep = 1;      /* the batched gradient is pow-exp only */
+	if (lockstep > 1) {
+		/* njobs * restarts BFGS runs in total, spread over the group's threads, one job each */
+		const int total = njobs * restarts;
+		if (lockstep > total) lockstep = total;
+		nthreads = lockstep;
+		njobs = lockstep;
+		restarts = (total + lockstep - 1) / lockstep;
+	}
 	unsigned long seed = g_seed;
 	env = getenv("GPEMU_SEED");
 	if (env && atol(env) > 0) seed = (unsigned long)atol(env);
@@ -321,6 +338,14 @@ void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 		W[i].params.random_number = gsl_rng_alloc(gsl_rng_default);
 		gsl_rng_set(W[i].params.random_number, seed ? seed + 7919UL * (unsigned long)i : seed_noblock());
 	}
+	void *group = NULL;
+	if (lockstep > 1) {
+		struct estimate_thetas_params **members = (struct estimate_thetas_params **)malloc(sizeof(void *) * (size_t)nthreads);
+		for (int i = 0; i < nthreads; i++) { members[i] = &W[i].params; W[i].in_group = 1; }
+		group = gpemu_host_group_create(members, nthreads);
+		free(members);
+		if (!group) { fprintf(stderr, "estimate_thetas_threaded: cannot create the lock-step group\n"); exit(EXIT_FAILURE); }
+	}
 	for (int i = 0; i < nthreads; i++)
 		if (pthread_create(&tid[i], NULL, worker_main, &W[i])) { perror("pthread_create"); exit(EXIT_FAILURE); }
 	for (int i = 0; i < nthreads; i++)
@@ -333,6 +358,7 @@ void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 		printf("\n");
 	}
 	printf("-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=\n");
+	if (group) gpemu_host_group_destroy(group);
 	for (int i = 0; i < nthreads; i++) {
 		gpemu_host_release(&W[i].params);
 		gsl_rng_free(W[i].params.random_number);

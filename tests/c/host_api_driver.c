@@ -100,6 +100,21 @@ int main(int argc, char **argv)
 			printf("\n");
 		}
 		gpemu_host_release(&params);
+	} else if (!strcmp(argv[1], "train")) {
+		/* estimate_thetas_threaded on the model, then the best thetas and -logL at them (evalFnMulti) */
+		setup_optimization_ranges(model->options, model);
+		estimate_thetas_threaded(model, model->options);
+		printf("thetas");
+		for (int i = 0; i < nthetas; i++) printf(" %.17g", gsl_vector_get(model->thetas, i));
+		printf("\n");
+		struct estimate_thetas_params params;
+		memset(&params, 0, sizeof params);
+		params.options = model->options;
+		params.the_model = model;
+		gsl_vector *th = gsl_vector_alloc(nthetas - 1);
+		for (int i = 0; i < nthetas - 1; i++) gsl_vector_set(th, i, gsl_vector_get(model->thetas, i + 1));
+		printf("neglogl %.17g\n", evalFnMulti(th, &params));
+		gpemu_host_release(&params);
 	} else if (!strcmp(argv[1], "emu")) {
 		gsl_matrix *q = read_queries(argv[5], (int)x->size2);
 		for (int i = 0; i < nthetas; i++) gsl_vector_set(model->thetas, i, atof(argv[6 + i]));

@@ -287,6 +287,33 @@ def test_grad_golden(gpu_ctx, ref_inputs, golden):
     assert np.allclose(g, golden["g4_multi"], rtol=1e-7, atol=1e-7 * np.abs(golden["g4_multi"]).max())
 
 
+@pytest.mark.parametrize("N,d,order,nb", [(300, 3, 1, 4), (700, 8, 0, 3)])
+def test_loglik_grad_batch_vs_oracle_and_single(gpu_ctx, N, d, order, nb):
+    """gpemu_loglik_grad_batch: value + gradient of nb independent thetas, factorisations in lock-step"""
+    X, y = synth.design(N, d, 4242 + N)
+    gpu_ctx.set_model(1, order, X, y)
+    ths = np.array([synth.perturbed_thetas(1, d, 17, i) for i in range(nb)])
+    ths[:, 0] = 0.0
+    got = gpu_ctx.loglik_grad_batch(ths)
+    assert np.all(got["status"] == 0) and np.all(got["info"] == 0)
+    for b in range(nb):
+        one = gpu_ctx.loglik_grad(ths[b])
+        assert got["value"][b] == pytest.approx(one["value"], rel=1e-12)
+        assert np.allclose(got["grad"][b], one["grad"], rtol=1e-9, atol=1e-9 * np.abs(one["grad"]).max())
+        go, _ = O.grad_fn_multi(1, order, X, y, ths[b][1:])
+        assert np.allclose(got["grad"][b], go, rtol=1e-7, atol=1e-7 * np.abs(go).max())
+        ref = O.eval_fn_multi(1, order, X, y, ths[b][1:])
+        assert got["value"][b] == pytest.approx(ref["value"], rel=RTOL)
+
+
+def test_loglik_grad_batch_matern_is_refused(gpu_ctx, ref_inputs):
+    X, y = ref_inputs["uni"]
+    gpu_ctx.set_model(3, 0, X, y)
+    with pytest.raises(abi.GpemuError) as e:
+        gpu_ctx.loglik_grad_batch(np.array([[1.0, 0.01, -0.5], [1.0, 0.02, -0.4]]))
+    assert e.value.code == abi.ERR_ARG
+
+
 def test_grad_matern_is_refused(gpu_ctx, ref_inputs):
     X, y = ref_inputs["uni"]
     gpu_ctx.set_model(3, 0, X, y)

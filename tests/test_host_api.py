@@ -156,6 +156,33 @@ def test_cli_train_snapshot_predict_end_to_end(driver, tmp_path):
 
 
 @pytest.mark.gpu
+def test_training_in_lockstep_group_matches_per_thread_scheme(driver, tmp_path):
+    """estimate_thetas_threaded: the restarts as a lock-step group (their likelihood/gradient requests batched on the
+    device) find the same optimum as one sequential BFGS run after the other, and its value agrees with the oracle.
+    Noisy synthetic outputs, so that the optimum is interior (the reference's toy models are noise-free: their
+    likelihood grows without bound as the nugget vanishes)."""
+    N, d = 150, 2
+    X, y = synth.design(N, d, 31337)
+    y = y + 0.15 * synth.normal(99, N)
+    f = tmp_path / "noisy.dat"
+    f.write_text(f"1\n{d}\n{N}\n" + "\n".join(" ".join(repr(float(v)) for v in row) for row in X) + "\n" +
+                 "\n".join(repr(float(v)) for v in y) + "\n")
+    best = {}
+    for mode in ("8", "1"):
+        env = dict(os.environ, GPEMU_SEED="4711", GPEMU_RESTARTS="16", GPEMU_LOCKSTEP=mode)
+        res = parse(run([driver, "train", str(f), "1", "1"], env=env))
+        th = np.array(res["thetas"][0])
+        val = res["neglogl"][0][0]
+        assert np.all(np.isfinite(th)) and np.isfinite(val)
+        assert val == pytest.approx(O.eval_fn_multi(1, 1, X, y, th[1:])["value"], rel=1e-6)
+        best[mode] = (val, th)
+    # 16 random restarts each: both searches end at the same optimum, to the minimiser's own stopping tolerance
+    # (|gradient| < 0.1 as in the reference, maxmultimin.c:725)
+    assert abs(best["8"][0] - best["1"][0]) < 0.5, best
+    assert np.max(np.abs(best["8"][1] - best["1"][1])) < 0.2, best
+
+
+@pytest.mark.gpu
 def test_multi_output_pca_snapshot_and_backprojection(driver, tmp_path):
     """test/multi-simple (N=100, d=3, t=6): PCA keeps nr <= t-1 components; predictions at the training points
     come back in the observable space close to the training outputs."""
