@@ -18,8 +18,13 @@
 #include <sys/time.h>
 #include "libemu.h"
 
-#define SCREWUPVALUE -2000
-#define SCREWUPVALUE_T -20000
+/* The reference starts its arg-max over restarts at -2000 (maxmultimin.c:38,60,110) and over threads at -20000
+ * (estimate_threaded.c:5,34): a model whose log-likelihood never exceeds that (any N of a few thousand: logL scales
+ * with N) cannot be trained there -- it ends with "maximisation didn't work at all" and thetas = 0.  The floors are
+ * scale-dependent constants, not semantics: here the arg-max starts at -infinity, which gives the reference's
+ * result whenever the reference produced one. */
+#define SCREWUPVALUE (-HUGE_VAL)
+#define SCREWUPVALUE_T (-HUGE_VAL)
 
 static unsigned long g_seed = 0;
 static int g_nthreads = 0, g_restarts = 50;
@@ -58,7 +63,9 @@ static double phi(struct fdf *F, const double *x, const double *p, double alpha,
 	F->nevals++;
 	for (int i = 0; i < F->n; i++) gout[i] = gsl_vector_get(gt, i);
 	*dphi = dot(gout, p, F->n);
-	if (isnan(f) || isinf(f)) { f = INFINITY; *dphi = INFINITY; }
+	/* a trial point is unusable when the value OR the slope is not finite (the literal derivative formula overflows
+	 * to inf * 0 for extreme length scales while the likelihood itself is still finite) */
+	if (isnan(f) || isinf(f) || isnan(*dphi) || isinf(*dphi)) { f = INFINITY; *dphi = INFINITY; }
 	return f;
 }
 
@@ -87,38 +94,54 @@ static int line_search(struct fdf *F, const double *x, double f0, const double *
 	double lo = 0, flo = f0, dlo = d0, hi = 0, fhi = 0, dhi = 0;
 	int bracketed = 0;
 	double *g = (double *)malloc(sizeof(double) * (size_t)n);
+	/* lowest trial value seen, in case no point passes the Armijo/Wolfe tests: the reference's gradient is the
+	 * literal one-coordinate formula (emulator.c:173-209), which for nparams > 1 is NOT the derivative of the
+	 * likelihood -- its slope d0 overstates the decrease by orders of magnitude and the sufficient-decrease test can
+	 * then reject every step that does lower f.  Such a step is taken rather than ending the run. */
+	double best_a = 0.0, best_f = f0;
+	double *best_g = (double *)malloc(sizeof(double) * (size_t)n);
+#define NOTE_TRIAL() do { if (fa < best_f) { best_f = fa; best_a = a; memcpy(best_g, g, sizeof(double) * (size_t)n); } } while (0)
+#define LS_RETURN(code) do { free(g); free(best_g); return (code); } while (0)
+	const int debug = getenv("GPEMU_OPT_DEBUG") != NULL;
+	if (debug) fprintf(stderr, "#   ls f0 %.10g d0 %.4g alpha1 %.4g\n", f0, d0, alpha1);
 	for (int it = 0; it < 12 && !bracketed; it++) {
 		fa = phi(F, x, p, a, g, &da, xt, gt);
+		if (debug) fprintf(stderr, "#   ls expand a %.4g fa %.10g da %.4g\n", a, fa, da);
+		NOTE_TRIAL();
 		if (fa > f0 + rho * a * d0 || (it > 0 && fa >= f_prev)) {
 			lo = a_prev; flo = f_prev; dlo = d_prev; hi = a; fhi = fa; dhi = da; bracketed = 1; break;
 		}
-		if (fabs(da) <= -sigma * d0) { *alpha_out = a; *f_out = fa; memcpy(g_out, g, sizeof(double) * (size_t)n); free(g); return 0; }
+		if (fabs(da) <= -sigma * d0) { *alpha_out = a; *f_out = fa; memcpy(g_out, g, sizeof(double) * (size_t)n); LS_RETURN(0); }
 		if (da >= 0.0) { lo = a; flo = fa; dlo = da; hi = a_prev; fhi = f_prev; dhi = d_prev; bracketed = 1; break; }
 		a_prev = a; f_prev = fa; d_prev = da;
 		a *= 2.5;
 	}
-	if (!bracketed) { free(g); return 1; }
+	if (!bracketed) goto fallback;
 	for (int it = 0; it < 16; it++) {
 		a = cubic_min(lo, flo, dlo, hi, fhi, dhi);
 		fa = phi(F, x, p, a, g, &da, xt, gt);
+		if (debug) fprintf(stderr, "#   ls zoom [%.4g,%.4g] a %.4g fa %.10g da %.4g\n", lo, hi, a, fa, da);
+		NOTE_TRIAL();
 		if (fa > f0 + rho * a * d0 || fa >= flo) {
 			hi = a; fhi = fa; dhi = da;
 		} else {
-			if (fabs(da) <= -sigma * d0) { *alpha_out = a; *f_out = fa; memcpy(g_out, g, sizeof(double) * (size_t)n); free(g); return 0; }
+			if (fabs(da) <= -sigma * d0) { *alpha_out = a; *f_out = fa; memcpy(g_out, g, sizeof(double) * (size_t)n); LS_RETURN(0); }
 			if (da * (hi - lo) >= 0.0) { hi = lo; fhi = flo; dhi = dlo; }
 			lo = a; flo = fa; dlo = da;
 		}
 		if (fabs(hi - lo) < 1e-10 * fmax(1.0, fabs(lo))) break;
+		if (best_f < f0 && it >= 5) break;         /* six sections without an acceptable point: take the best decrease */
 	}
 	/* accept the best sufficient-decrease point seen, if any */
-	if (lo > 0.0 && flo < f0) {
-		fa = phi(F, x, p, lo, g, &da, xt, gt);
-		*alpha_out = lo; *f_out = fa; memcpy(g_out, g, sizeof(double) * (size_t)n);
-		free(g);
-		return (fa < f0) ? 0 : 1;
+fallback:
+	if (best_f < f0) {
+		if (debug) fprintf(stderr, "#   ls no Wolfe point: taking the lowest trial a %.4g f %.10g\n", best_a, best_f);
+		*alpha_out = best_a; *f_out = best_f; memcpy(g_out, best_g, sizeof(double) * (size_t)n);
+		LS_RETURN(0);
 	}
-	free(g);
-	return 1;
+	LS_RETURN(1);
+#undef NOTE_TRIAL
+#undef LS_RETURN
 }
 
 /* libEmu/maxmultimin.c:633-778 */
@@ -151,9 +174,11 @@ int doOptimizeMultiMin(double (*fn)(const gsl_vector *, void *),
 		f = phi(&F, x, zp, 0.0, g, &dd, xt, gt);
 		if (zp != zero_p) free(zp);
 	}
+	const int debug = getenv("GPEMU_OPT_DEBUG") != NULL;
 	if (isinf(f)) status = GSL_ENOPROG;
 	while (status == GSL_CONTINUE && stepcount < stepmax) {
 		const double gnorm = sqrt(dot(g, g, n));
+		if (debug) fprintf(stderr, "# bfgs it %d f %.10g |g| %.4g evals %d\n", stepcount, f, gnorm, F.nevals);
 		if (gnorm < epsAbs) { status = GSL_SUCCESS; break; }
 		for (int i = 0; i < n; i++) { double t = 0; for (int j = 0; j < n; j++) t -= H[i * n + j] * g[j]; p[i] = t; }
 		double alpha1 = 1.0;
@@ -166,6 +191,7 @@ int doOptimizeMultiMin(double (*fn)(const gsl_vector *, void *),
 		double alpha, fnew;
 		if (line_search(&F, x, f, g, p, alpha1, 0.01, tolerance, &alpha, &fnew, gn, xt, gt)) {
 			status = GSL_ENOPROG;               /* maxmultimin.c:703-707: no progress ends the run */
+			if (debug) fprintf(stderr, "# bfgs line search failed at it %d (alpha1 %.4g, %d evals)\n", stepcount, alpha1, F.nevals);
 			break;
 		}
 		for (int i = 0; i < n; i++) { s[i] = alpha * p[i]; yv[i] = gn[i] - g[i]; x[i] += s[i]; g[i] = gn[i]; }
