@@ -2,8 +2,9 @@ import sys
 sys.path.insert(0,'.')
 from madaiemulator_amd import abi
 c=abi.Context(0)
-for cfg in (2,3):
-    for k in (512,2048):
+cfgs=[int(x) for x in sys.argv[1:]] or [3,4]
+for cfg in cfgs:
+    for k in (512,1024,2048):
         ms,fl=c.gemm_bench(m=15488,n=15360,k=k,ld=15360,cfg=cfg,tri=1,beta=1,reps=5)
         ms,fl=c.gemm_bench(m=15488,n=15360,k=k,ld=15360,cfg=cfg,tri=1,beta=1,reps=10)
         print("cfg",cfg,"k",k,"ms %.4f TF/s %.1f"%(ms,fl/ms/1e9),flush=True)
