@@ -65,7 +65,7 @@ def cpu_baseline(kind, order, N, d, seed):
     from oracle import oracle as O
     O.build()
     cores = min(os.cpu_count() or 1, 16)
-    Ns = 1280
+    Ns = 2048
     t0 = time.perf_counter()
     with mp.get_context("spawn").Pool(cores) as pool:
         times = pool.map(_cpu_eval_worker, [(kind, order, Ns, d, seed, i) for i in range(cores)])

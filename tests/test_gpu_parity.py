@@ -491,6 +491,40 @@ def test_maximum_dimensions(gpu_ctx):
     th[2:] = np.log(2.0)
     check_loglik(gpu_ctx, 1, 2, X, y, th)                 # nreg = 1 + 2*31 = 63: y and H fill all 64 augmented rows
 
+def test_model_switching_soak_is_deterministic():
+    """two contexts, a random sequence of model changes (size, dimension, kernel, order) with evaluations, batches,
+    gradients and predictions in between: workspaces and launch graphs are re-used / rebuilt correctly, and the
+    same inputs always give bit-identical outputs"""
+    rng = np.random.default_rng(1)
+    ctxs = [abi.Context(0), abi.Context(0)]
+    seen = {}
+    for it in range(60):
+        c = ctxs[it % 2]
+        N = int(rng.choice([100, 257, 640, 1500])); d = int(rng.choice([1, 3, 8]))
+        kind = int(rng.choice([1, 1, 3])); order = int(rng.choice([0, 1]))
+        X, y = synth.design(N, d, N + d)
+        c.set_model(kind, order, X, y)
+        th = thetas_for(kind, d)
+        v = c.loglik(th)["value"]
+        ths = np.array([synth.perturbed_thetas(kind, d, 3, i) for i in range(int(rng.integers(1, 7)))])
+        ths[0] = th
+        vb = c.loglik_batch(ths)["value"]
+        assert vb[0] == pytest.approx(v, rel=1e-11)
+        g0 = None
+        if kind == 1:
+            th0 = np.concatenate([[0.0], th[1:]])
+            g0 = c.loglik_grad(th0)["grad"]
+            gb = c.loglik_grad_batch(np.array([th0, th0]))["grad"]
+            assert np.allclose(gb[0], g0, rtol=1e-9, atol=1e-12) and np.array_equal(gb[0], gb[1])
+        c.predict_setup(th)
+        m, var = c.predict(synth.queries(int(rng.integers(1, 300)), d, 7))
+        sig = (v, float(m[0]), float(var[0]), None if g0 is None else tuple(g0))
+        key = (N, d, kind, order)
+        assert seen.setdefault(key, sig) == sig, key
+    for c in ctxs:
+        c.close()
+
+
 # ------------------------------------------------------------------ error behaviour at the boundary
 def test_error_codes(gpu_ctx):
     X, y = synth.design(50, 2, 1)
