@@ -868,6 +868,8 @@ extern "C" int gpemu_predict_setup(gpemu_ctx *ctx, const double *thetas, int nth
 	return GPEMU_OK;
 }
 
+constexpr int PRED_SPLIT_MAX = 16;
+
 static int ensure_pred_batch(gpemu_ctx *ctx, int mb)
 {
 	if (ctx->pred_batch >= mb) return GPEMU_OK;
@@ -876,7 +878,8 @@ static int ensure_pred_batch(gpemu_ctx *ctx, int mb)
 	if (ctx->dV) hipFree(ctx->dV);
 	ctx->dKq = ctx->dV = nullptr; ctx->pred_batch = 0;
 	HIPCHK(ctx, hipMalloc(&ctx->dKq, (size_t)mb * ctx->Np * sizeof(double)));
-	HIPCHK(ctx, hipMalloc(&ctx->dV, (size_t)mb * (ctx->Np + ctx->Rp) * sizeof(double)));
+	// V also holds the split-K partial products of small batches: PRED_SPLIT_MAX slices of up to 128 query rows
+	HIPCHK(ctx, hipMalloc(&ctx->dV, (size_t)std::max(mb, 128 * PRED_SPLIT_MAX) * (ctx->Np + ctx->Rp) * sizeof(double)));
 	ctx->pred_batch = mb;
 	return GPEMU_OK;
 }
@@ -907,9 +910,19 @@ extern "C" int gpemu_predict_batch_dev(gpemu_ctx *ctx, int M, const double *xq_d
 		g.B = ctx->dLinvAug; g.ldb = Np;
 		g.m = mb; g.n = Np + Rp; g.k0 = 0; g.k1 = Np; g.alpha = 1.0; g.beta = 0;
 		g.kend_mode = 1; g.kend_off = 0;
+		// a few queries (emulate_point: ONE) give one or two tile rows with K = N each: split K over the chip
+		// (0.46 -> 0.1 ms per call at N=8192); the slices are summed in order by the finishing kernel
+		int nslice = 1;
+		{
+			const long tiles = (long)(mbp / 64) * ((Np + Rp + 63) / 64);      // 64x64 tiles of the unsplit product
+			if (tiles < 1024) nslice = (int)std::max(1L, std::min((long)std::min(PRED_SPLIT_MAX, Np / 512), 2048 / tiles));
+			if ((long)nslice * mbp > 128L * PRED_SPLIT_MAX) nslice = 1;       // capacity of dV for the partial products
+		}
+		if (nslice > 1) { g.ksplit = nslice; g.bsC = (long)mbp * (Np + Rp); }
 		HIPCHK(ctx, gemm(ctx, g));
 		HIPCHK(ctx, launch_predict_finish(ctx->stream, ctx->dV, Np + Rp, mb, Np, ctx->nreg, ctx->order, d,
-		                                  xq_dev + (size_t)q0 * d, ctx->dBetaQ, ctx->kappa, mean_dev + q0, var_dev + q0));
+		                                  xq_dev + (size_t)q0 * d, ctx->dBetaQ, ctx->kappa, mean_dev + q0, var_dev + q0,
+		                                  nslice, (long)mbp * (Np + Rp)));
 	}
 	return GPEMU_OK;
 }

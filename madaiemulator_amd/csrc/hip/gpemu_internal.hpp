@@ -52,6 +52,8 @@ struct GemmArgs {
 	int kend_off;
 	long bsC, bsA, bsB;  // element strides between the matrices of a batch (grid.y = nbatch)
 	int nbatch;          // 0/1: single problem
+	int ksplit;          // > 1: grid.y = k-slices of ONE problem; slice s takes k in [k0 + s*klen, k0 + (s+1)*klen) and
+	                     // writes its partial product to C + s*bsC (beta = 0); the consumer sums the slices in order
 	int order_mode;      // 2: dense enumeration of the lower-triangular tiles (set by launch_gemm)
 	unsigned long long *trace;   // optional {first start, last end} device timestamps of this launch (GPEMU_TRACE)
 };
@@ -143,7 +145,8 @@ hipError_t launch_build_rrows(hipStream_t s, double *R, int Np, int Rp, const do
 hipError_t launch_set_identity_rows(hipStream_t s, double *T, long ld, int n);
 hipError_t launch_transpose(hipStream_t s, double *dst, long ldd, const double *src, long lds, int n);
 hipError_t launch_predict_finish(hipStream_t s, const double *V, long ldv, int M, int Np, int nreg, int order, int d,
-                                 const double *Xq, const double *betaQ, double kappa, double *mean, double *var);
+                                 const double *Xq, const double *betaQ, double kappa, double *mean, double *var,
+                                 int nslice = 1, long sstride = 0);
 hipError_t launch_grad_partials(hipStream_t s, const double *S, long lds, int soff, const double *X, int N, int d,
                                 const double *alpha, int kind, const double *gp /* d+2 scalars */, double *part, int *nparts);
 

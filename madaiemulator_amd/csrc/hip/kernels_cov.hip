@@ -286,10 +286,30 @@ __global__ __launch_bounds__(256) void predict_finish_kernel(const double *V, lo
 	}
 }
 
+// split-K partial products -> V (slice 0), summed in slice order: V[e] = sum_s V[s*sstride + e]
+__global__ __launch_bounds__(256) void sum_slices_kernel(double *V, long n, int nslice, long sstride)
+{
+	const long e = 2 * ((long)blockIdx.x * 256 + threadIdx.x);
+	if (e >= n) return;
+	double2 t = *reinterpret_cast<const double2 *>(V + e);
+	for (int s = 1; s < nslice; s++) {
+		const double2 u = *reinterpret_cast<const double2 *>(V + (long)s * sstride + e);
+		t.x += u.x;
+		t.y += u.y;
+	}
+	*reinterpret_cast<double2 *>(V + e) = t;
+}
+
 hipError_t launch_predict_finish(hipStream_t s, const double *V, long ldv, int M, int Np, int nreg, int order, int d,
-                                 const double *Xq, const double *betaQ, double kappa, double *mean, double *var)
+                                 const double *Xq, const double *betaQ, double kappa, double *mean, double *var,
+                                 int nslice, long sstride)
 {
 	(void)order;
+	if (nslice > 1) {
+		const long n = (long)M * ldv;          // rows are contiguous (ldv = row length), an even number of doubles
+		hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, s, const_cast<double *>(V), n,
+		                   nslice, sstride);
+	}
 	hipLaunchKernelGGL(predict_finish_kernel, dim3((M + 3) / 4), dim3(256), 0, s, V, ldv, M, Np, nreg, d, Xq, betaQ,
 	                   kappa, mean, var);
 	return hipGetLastError();

@@ -122,6 +122,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 		int kx = (tn * BN + BN - g.kend_off + GEMM_BK - 1) & ~(GEMM_BK - 1);
 		if (kx < ke) ke = kx;
 	}
+	if (g.ksplit > 1) {
+		// split-K for updates with few tiles and a long K (a handful of prediction queries against L^-1): grid.y
+		// enumerates k-slices, each writes its own partial tile (C was offset by blockIdx.y * bsC above)
+		const int klen = (((g.k1 - g.k0) + g.ksplit - 1) / g.ksplit + GEMM_BK - 1) & ~(GEMM_BK - 1);
+		const int lo = g.k0 + (int)blockIdx.y * klen;
+		if (lo > kb) kb = lo;
+		if (lo + klen < ke) ke = lo + klen;
+	}
 
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;
@@ -312,6 +320,10 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs &a_in)
 	GemmArgs a = a_in;
 	if (a.m <= 0 || a.n <= 0) return hipSuccess;
 	if (a.beta && a.alpha != 1.0 && a.alpha != -1.0) return hipErrorInvalidValue;   // accumulators start from C/alpha
+	if (a.ksplit > 1) {
+		if (a.beta || a.nbatch > 1) return hipErrorInvalidValue;      // slices write fresh partials of one problem
+		a.nbatch = a.ksplit; a.bsA = 0; a.bsB = 0;                      // bsC = stride between the partial outputs
+	}
 	const int nbatch = a.nbatch > 1 ? a.nbatch : 1;
 	const int cfg = choose_gemm_cfg(a);
 	// lower-triangular updates with square tiles enumerate only their non-empty tiles
