@@ -86,6 +86,7 @@ def cpu_baseline(kind, order, N, d, seed):
         "sample": (f"{cores} concurrent oracle evaluations (one per core) at N={Ns}, d={d}: {per_eval:.2f} s each "
                    f"({wall:.1f} s wall); extrapolated to N={N} by (N/{Ns})^3; predictions: 4 oracle emulate_point "
                    f"calls at N={Ns} ({per_q*1e3:.1f} ms each) scaled by (N/{Ns})^2"),
+        "value_1core": 1.0 / (per_eval * scale), "predictions_per_s_1core": 1.0 / (per_q * (N / Ns) ** 2),
         "predictions_per_s": preds_per_s,
         "seconds_per_eval_at_sample": per_eval,
     }
