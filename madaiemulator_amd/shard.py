@@ -75,6 +75,28 @@ def farm_evaluations(eval_fn, thetas, rank=None, world_size=None):
     return vals
 
 
+def farm_evaluations_batched(batch_fn, thetas, batch=16, rank=None, world_size=None):
+    """As farm_evaluations, but a rank sends its share to the device in lock-step batches:
+    batch_fn(theta_rows) -> array of -logL, one per row (Context.loglik_batch(rows)["value"]; NaN where the
+    evaluation failed).  Same partition (restart r -> rank r mod W), same single all-gather."""
+    r0, w0, _ = world()
+    rank = r0 if rank is None else rank
+    world_size = w0 if world_size is None else world_size
+    thetas = np.asarray(thetas, dtype=np.float64)
+    mine = cyclic_share(len(thetas), rank, world_size)
+    rows = []
+    for s0 in range(0, len(mine), max(1, batch)):
+        idx = mine[s0:s0 + max(1, batch)]
+        vals = np.asarray(batch_fn(thetas[idx]), dtype=np.float64).reshape(-1)
+        rows += [[i, v] for i, v in zip(idx, vals)]
+    rows = np.array(rows, dtype=np.float64).reshape(-1, 2)
+    out = np.full(len(thetas), np.nan)
+    for part in all_gather_rows(rows, 2):
+        for i, v in part:
+            out[int(i)] = v
+    return out
+
+
 def best_of(values, thetas):
     """the reference's arg-max under results_mutex (estimate_threaded.c:308-313): NaN/inf are skipped
     (maxmultimin.c:110); values are -logL so the best is the smallest"""

@@ -27,6 +27,8 @@ def ev(th):
     calls.append(1)
     return O.eval_fn_multi(1, 0, X, y, th[1:])["value"]
 vals = shard.farm_evaluations(ev, thetas)
+valsb = shard.farm_evaluations_batched(lambda rows: [O.eval_fn_multi(1, 0, X, y, th[1:])["value"] for th in rows], thetas, batch=2)
+assert np.array_equal(vals, valsb)
 Y = synth.multi_outputs(X, y, 5)
 comp = shard.farm_components(lambda c: [O.eval_fn_multi(1, 0, X, Y[:, c], thetas[0][1:])["value"], float(c)], 5, 2)
 e = O.Emulator(1, 0, X, y, thetas[0])
