@@ -102,9 +102,10 @@ def main():
     ap.add_argument("--streams", type=int, default=2,
                     help="concurrent evaluation contexts (HIP streams) per GPU: the panel chain of one context's batch "
                          "overlaps the trailing updates of the other's")
-    ap.add_argument("--batch", type=int, default=16,
+    ap.add_argument("--batch", type=int, default=None,
                     help="independent evaluations factored in lock-step per context (gpemu_loglik_batch: the device "
-                         "form of the reference's restart threads / callEvalLhoodList); 1 = one matrix per launch")
+                         "form of the reference's restart threads / callEvalLhoodList); 1 = one matrix per launch; "
+                         "default 16 at N >= 8192, up to 64 for smaller models (the panel chain weighs more there)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-predict", action="store_true")
     args = ap.parse_args()
@@ -185,7 +186,8 @@ def main():
     # the K independent evaluations (each at its own fresh theta) are cut into lock-step batches of B and the
     # batches dealt round-robin to the contexts: every kernel of a factorisation handles its B matrices at once,
     # and the latency-bound panel chain of one context overlaps the big GEMMs of the other
-    B = max(1, min(args.batch, -(-K // nstreams)))
+    want = args.batch if args.batch else int(min(64, max(16, 16 * (8192 / N) ** 2)))
+    B = max(1, min(want, -(-K // nstreams)))
     chunks = [list(range(s0, min(s0 + B, K))) for s0 in range(0, K, B)]
     for size in sorted({len(c) for c in chunks}):           # warm-up: captures the launch graph of every batch size used
         for j in range(max(1, -(-W // (size * nstreams)))):
