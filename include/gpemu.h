@@ -132,6 +132,12 @@ int gpemu_get_cinverse(gpemu_ctx *ctx, double *cinv_out);
 /* ---- a19: emulate_point, batched (emulator_struct.c:124-143) --------
  * mean[q], var[q] for M query rows xq[M*d].  Host buffers. */
 int gpemu_predict_batch(gpemu_ctx *ctx, int npoints, const double *xq, double *mean, double *var);
+/* the same in two halves: enqueue stages the queries through pinned memory and returns at once (the device work
+ * runs on the context's stream), collect waits and copies the M means/variances out.  One batch per context at a
+ * time; different contexts -- the PCA components of a multi-output emulator (multivar_support.c:103-157) --
+ * work on their batches concurrently. */
+int gpemu_predict_batch_enqueue(gpemu_ctx *ctx, int npoints, const double *xq /* M*d host */);
+int gpemu_predict_batch_collect(gpemu_ctx *ctx, int npoints, double *mean, double *var);
 /* same with query / result buffers already resident in HBM (device pointers) */
 int gpemu_predict_batch_dev(gpemu_ctx *ctx, int npoints, const double *xq_dev,
                             double *mean_dev, double *var_dev);

@@ -42,6 +42,8 @@ SYMBOLS = {
     "gpemu_predict_setup": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _ip]),
     "gpemu_get_cinverse": (C.c_int, [C.c_void_p, _dp]),
     "gpemu_predict_batch": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
+    "gpemu_predict_batch_enqueue": (C.c_int, [C.c_void_p, C.c_int, _dp]),
+    "gpemu_predict_batch_collect": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp]),
     "gpemu_predict_batch_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpemu_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "gpemu_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -237,6 +239,16 @@ class Context:
         rc = self._chk(self.L.gpemu_predict_setup(self.h, _p(th), th.size, _p(beta), C.byref(info)),
                        allow=(ERR_NOT_PD, ERR_REGRESSION))
         return beta, rc
+
+    def predict_enqueue(self, Xq):
+        Xq = _a(Xq).reshape(-1, self.d)
+        self._npred = Xq.shape[0]
+        self._chk(self.L.gpemu_predict_batch_enqueue(self.h, Xq.shape[0], _p(Xq)))
+
+    def predict_collect(self):
+        m, v = np.empty(self._npred), np.empty(self._npred)
+        self._chk(self.L.gpemu_predict_batch_collect(self.h, self._npred, _p(m), _p(v)))
+        return m, v
 
     def cinverse(self):
         out = np.empty((self.N, self.N))

@@ -208,6 +208,7 @@ static void free_model(gpemu_ctx *ctx)
 	                   &ctx->dKq, &ctx->dV, &ctx->dXq, &ctx->dMean, &ctx->dVar, &ctx->dS, &ctx->dGradPart, &ctx->dAlpha};
 	for (auto p : ptrs) { if (*p) hipFree(*p); *p = nullptr; }
 	ctx->T_rows = 0; ctx->pred_ready = false; ctx->cinv_ready = false; ctx->pred_batch = 0; ctx->stage_cap = 0;
+	ctx->pred_pending = 0;
 	ctx->S_dim = 0; ctx->gradpart_len = 0;
 }
 
@@ -225,6 +226,7 @@ extern "C" void gpemu_ctx_destroy(gpemu_ctx *ctx)
 	if (ctx->dRes) hipFree(ctx->dRes);
 	if (ctx->hRes) hipHostFree(ctx->hRes);
 	if (ctx->hInfo) hipHostFree(ctx->hInfo);
+	if (ctx->hStage) hipHostFree(ctx->hStage);
 	for (auto e : ctx->ev_pool) hipEventDestroy(e);
 	if (ctx->stream2) hipStreamDestroy(ctx->stream2);
 	if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -927,29 +929,59 @@ extern "C" int gpemu_predict_batch_dev(gpemu_ctx *ctx, int M, const double *xq_d
 	return GPEMU_OK;
 }
 
-extern "C" int gpemu_predict_batch(gpemu_ctx *ctx, int M, const double *xq, double *mean, double *var)
+// host-buffer entry, asynchronous form: the queries are staged through pinned memory, the batch runs on the context's
+// stream and the results come back into pinned memory; nothing blocks until gpemu_predict_batch_collect.  Several
+// contexts (the PCA components of a multi-output emulator) can so work on one query at the same time.
+extern "C" int gpemu_predict_batch_enqueue(gpemu_ctx *ctx, int M, const double *xq)
 {
-	if (!ctx || M < 1 || !xq || !mean || !var) return GPEMU_ERR_ARG;
+	if (!ctx || M < 1 || !xq) return GPEMU_ERR_ARG;
 	if (!ctx->pred_ready) return fail(ctx, GPEMU_ERR_STATE, "gpemu_predict_setup has not been called");
+	if (ctx->pred_pending) return fail(ctx, GPEMU_ERR_STATE, "a prediction batch is already enqueued: collect it first");
 	HIPCHK(ctx, hipSetDevice(ctx->device));
+	const int d = ctx->d;
 	if (ctx->stage_cap < M) {
 		HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 		if (ctx->dXq) hipFree(ctx->dXq);
 		if (ctx->dMean) hipFree(ctx->dMean);
 		if (ctx->dVar) hipFree(ctx->dVar);
-		ctx->dXq = ctx->dMean = ctx->dVar = nullptr; ctx->stage_cap = 0;
-		HIPCHK(ctx, hipMalloc(&ctx->dXq, (size_t)M * ctx->d * sizeof(double)));
-		HIPCHK(ctx, hipMalloc(&ctx->dMean, (size_t)M * sizeof(double)));
-		HIPCHK(ctx, hipMalloc(&ctx->dVar, (size_t)M * sizeof(double)));
-		ctx->stage_cap = M;
+		if (ctx->hStage) hipHostFree(ctx->hStage);
+		ctx->dXq = ctx->dMean = ctx->dVar = nullptr; ctx->hStage = nullptr; ctx->stage_cap = 0;
+		const int cap = std::max(M, 64);
+		HIPCHK(ctx, hipMalloc(&ctx->dXq, (size_t)cap * d * sizeof(double)));
+		HIPCHK(ctx, hipMalloc(&ctx->dMean, (size_t)cap * sizeof(double)));
+		HIPCHK(ctx, hipMalloc(&ctx->dVar, (size_t)cap * sizeof(double)));
+		HIPCHK(ctx, hipHostMalloc((void **)&ctx->hStage, (size_t)cap * (d + 2) * sizeof(double)));
+		ctx->stage_cap = cap;
 	}
-	HIPCHK(ctx, hipMemcpyAsync(ctx->dXq, xq, (size_t)M * ctx->d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+	double *hx = ctx->hStage, *hm = ctx->hStage + (size_t)ctx->stage_cap * d, *hv = hm + ctx->stage_cap;
+	memcpy(hx, xq, (size_t)M * d * sizeof(double));
+	HIPCHK(ctx, hipMemcpyAsync(ctx->dXq, hx, (size_t)M * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
 	int rc = gpemu_predict_batch_dev(ctx, M, ctx->dXq, ctx->dMean, ctx->dVar);
 	if (rc) return rc;
-	HIPCHK(ctx, hipMemcpyAsync(mean, ctx->dMean, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-	HIPCHK(ctx, hipMemcpyAsync(var, ctx->dVar, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	HIPCHK(ctx, hipMemcpyAsync(hm, ctx->dMean, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(ctx, hipMemcpyAsync(hv, ctx->dVar, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+	ctx->pred_pending = M;
 	return GPEMU_OK;
+}
+
+extern "C" int gpemu_predict_batch_collect(gpemu_ctx *ctx, int M, double *mean, double *var)
+{
+	if (!ctx || !mean || !var) return GPEMU_ERR_ARG;
+	if (!ctx->pred_pending || M != ctx->pred_pending) return fail(ctx, GPEMU_ERR_STATE, "no enqueued prediction batch of this size");
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	const double *hm = ctx->hStage + (size_t)ctx->stage_cap * ctx->d, *hv = hm + ctx->stage_cap;
+	memcpy(mean, hm, (size_t)M * sizeof(double));
+	memcpy(var, hv, (size_t)M * sizeof(double));
+	ctx->pred_pending = 0;
+	return GPEMU_OK;
+}
+
+extern "C" int gpemu_predict_batch(gpemu_ctx *ctx, int M, const double *xq, double *mean, double *var)
+{
+	if (!ctx || M < 1 || !xq || !mean || !var) return GPEMU_ERR_ARG;
+	int rc = gpemu_predict_batch_enqueue(ctx, M, xq);
+	if (rc) return rc;
+	return gpemu_predict_batch_collect(ctx, M, mean, var);
 }
 
 // ---------------------------------------------------------------------------

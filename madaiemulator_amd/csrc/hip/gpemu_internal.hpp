@@ -116,6 +116,8 @@ struct gpemu_ctx {
 	int pred_batch = 0;
 	double *dXq = nullptr, *dMean = nullptr, *dVar = nullptr; // staging for host-buffer entry
 	int stage_cap = 0;
+	double *hStage = nullptr;    // pinned: stage_cap*d query coordinates, then stage_cap means, then stage_cap variances
+	int pred_pending = 0;        // queries of an enqueued, not yet collected prediction batch
 	bool cinv_ready = false;
 	double *dS = nullptr;        // (Rp+Np)^2 corner for explicit inverse / gradient
 	size_t S_dim = 0;

@@ -466,6 +466,25 @@ void emulate_points(emulator_struct *e, gsl_matrix *points, double *mean, double
 	if (rc) die(en->ctx, rc, "emulate_point");
 }
 
+/* the two halves of emulate_points: all components of a multi-output emulator enqueue, then all collect */
+void emulate_points_enqueue(emulator_struct *e, gsl_matrix *points)
+{
+	struct entry *en = lookup(e, 0);
+	if (!en) { fprintf(stderr, "emulate_point: emulator_struct was not made by alloc_emulator_struct\n"); exit(EXIT_FAILURE); }
+	double *q = pack_matrix(points);
+	int rc = gpemu_predict_batch_enqueue(en->ctx, (int)points->size1, q);
+	free(q);
+	if (rc) die(en->ctx, rc, "emulate_point");
+}
+
+void emulate_points_collect(emulator_struct *e, int npoints, double *mean, double *variance)
+{
+	struct entry *en = lookup(e, 0);
+	if (!en) { fprintf(stderr, "emulate_point: emulator_struct was not made by alloc_emulator_struct\n"); exit(EXIT_FAILURE); }
+	int rc = gpemu_predict_batch_collect(en->ctx, npoints, mean, variance);
+	if (rc) die(en->ctx, rc, "emulate_point");
+}
+
 /* emulator_struct.c:124-143 */
 void emulate_point(emulator_struct *e, gsl_vector *point, double *mean, double *variance)
 {

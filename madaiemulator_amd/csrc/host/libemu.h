@@ -163,6 +163,9 @@ void free_emulator_struct(emulator_struct *e);
 void emulate_point(emulator_struct *e, gsl_vector *point, double *mean, double *variance);
 /* extension: npoints query rows (npoints x nparams), mean/variance arrays of npoints */
 void emulate_points(emulator_struct *e, gsl_matrix *points, double *mean, double *variance);
+/* emulate_points in two halves (device work runs in between): used to query all PCA components at the same time */
+void emulate_points_enqueue(emulator_struct *e, gsl_matrix *points);
+void emulate_points_collect(emulator_struct *e, int npoints, double *mean, double *variance);
 
 /* ---- multi_modelstruct.h / multivar_support.h ---------------------------------- */
 multi_modelstruct *alloc_multimodelstruct(gsl_matrix *xmodel_in, gsl_matrix *training_matrix_in, int cov_fn_index,

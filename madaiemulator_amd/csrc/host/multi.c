@@ -291,8 +291,11 @@ void emulate_points_multi(multi_emulator *emu, gsl_matrix *points, int pca_space
 	const int np = (int)points->size1, nr = emu->nr;
 	double *mp = (double *)malloc(sizeof(double) * (size_t)np * nr), *vp = (double *)malloc(sizeof(double) * (size_t)np * nr);
 	double *mc = (double *)malloc(sizeof(double) * (size_t)np), *vc = (double *)malloc(sizeof(double) * (size_t)np);
+	/* the nr scalar emulators are independent (multivar_support.c:116 loops over them): each has its own device
+	 * context, so all of them are started before the first result is waited for */
+	for (int c = 0; c < nr; c++) emulate_points_enqueue(emu->emu_struct_array[c], points);
 	for (int c = 0; c < nr; c++) {
-		emulate_points(emu->emu_struct_array[c], points, mc, vc);
+		emulate_points_collect(emu->emu_struct_array[c], np, mc, vc);
 		for (int q = 0; q < np; q++) { mp[(size_t)q * nr + c] = mc[q]; vp[(size_t)q * nr + c] = vc[q]; }
 	}
 	if (pca_space) {
