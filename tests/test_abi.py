@@ -47,3 +47,23 @@ def test_product_package_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in text.lower(), \
                     f"{f} mentions the oracle: the product path must not depend on test infrastructure"
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/gpemu.h is what a C host (the reference is C99) includes: it must compile as C99 and as C++, with no
+    HIP or torch headers, and a program that only uses it must link against the library"""
+    import subprocess
+    build.build_hip()
+    src = tmp_path / "use_header.c"
+    src.write_text(
+        '#include "gpemu.h"\n#include <stdio.h>\n'
+        'int main(void) { gpemu_ctx *c = 0; int rc = gpemu_ctx_create(&c, 0);\n'
+        '  printf("%s devices=%d rc=%d max_batch=%d\\n", gpemu_version(), gpemu_device_count(), rc, GPEMU_MAX_BATCH);\n'
+        '  if (c) { gpemu_ctx_destroy(c); }\n  return 0; }\n')
+    exe = tmp_path / "use_header"
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", inc, "-o", str(exe), str(src),
+                           "-L", build.LIBDIR, "-lgpemu_hip", f"-Wl,-rpath,{build.LIBDIR}"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "gfx950" in out.stdout, out.stderr
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-I", inc, "-x", "c++", "-fsyntax-only", str(src)])
