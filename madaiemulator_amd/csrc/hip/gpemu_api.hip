@@ -921,6 +921,14 @@ extern "C" int gpemu_predict_batch_dev(gpemu_ctx *ctx, int M, const double *xq_d
 			if ((long)nslice * mbp > 128L * PRED_SPLIT_MAX) nslice = 1;       // capacity of dV for the partial products
 		}
 		if (nslice > 1) { g.ksplit = nslice; g.bsC = (long)mbp * (Np + Rp); }
+		if (mb <= 16 && nslice > 1) {
+			// up to 16 queries (emulate_point: one): the skinny kernel, one 16-row query tile, instead of 64-row GEMM
+			// tiles (97 vs 115 us at N=8192; from 17 queries on the split-K GEMM is as fast)
+			const int klen = (((Np + nslice - 1) / nslice) + 15) & ~15;
+			ProfScope ps(ctx, GPEMU_PROF_GEMM, gemm_flops(g), 0.0);
+			HIPCHK(ctx, launch_skinny_nt(ctx->stream, ctx->dKq, Np, ctx->dLinvAug, Np, ctx->dV, Np + Rp, (long)mbp * (Np + Rp),
+			                             1, Np + Rp, Np, Np, nslice, klen));
+		} else
 		HIPCHK(ctx, gemm(ctx, g));
 		HIPCHK(ctx, launch_predict_finish(ctx->stream, ctx->dV, Np + Rp, mb, Np, ctx->nreg, ctx->order, d,
 		                                  xq_dev + (size_t)q0 * d, ctx->dBetaQ, ctx->kappa, mean_dev + q0, var_dev + q0,

@@ -154,6 +154,8 @@ hipError_t launch_grad_partials(hipStream_t s, const double *S, long lds, int so
 
 // ---- kernels_linalg.hip
 hipError_t launch_gemm(hipStream_t s, const GemmArgs &a);
+hipError_t launch_skinny_nt(hipStream_t s, const double *Kq, long ldk, const double *L, long ldl, double *Vp, long ldv,
+                            long sstride, int tq, int ntot, int K, int ntri, int nslice, int klen);
 extern int g_gemm_big_tiles, g_gemm_big_cfg;
 hipError_t launch_leaf(hipStream_t s, double *T, long ld, int c0, int m_below, int *info,
                        unsigned long long *trace_factor = nullptr, unsigned long long *trace_solve = nullptr,

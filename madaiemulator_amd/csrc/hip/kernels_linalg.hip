@@ -284,6 +284,79 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 	trace_end(g.trace, tr0);
 }
 
+// ---------------------------------------------------------------------------
+// Skinny product for a handful of prediction queries (emulate_point: ONE): Vp[s][q][n] = sum over the k-slice s of
+// Kq[q][k] * L[n][k], q < 16*TQ.  A 64x64 GEMM tile would spend 63/64 of its MFMA work on padding rows; here a wave
+// owns 16 columns n and TQ query tiles, streams its 16 rows of L once (32 contiguous bytes per lane and 16-k chunk,
+// 128-byte segments per row) and keeps four independent accumulators per query tile so that the MFMAs pipeline.
+// Rows n < ntri of L are lower triangular (L^-1): k beyond the block's last column is skipped.
+// grid (ntot/64, nslice), 256 threads.
+// ---------------------------------------------------------------------------
+template <int TQ>
+__global__ __launch_bounds__(256) void skinny_nt_kernel(const double *Kq, long ldk, const double *L, long ldl, double *Vp,
+                                                        long ldv, long sstride, int K, int ntri, int klen)
+{
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int q = lane & 15, g = lane >> 4;
+	const int n0 = blockIdx.x * 64 + 16 * wave;
+	const int kb = blockIdx.y * klen;
+	int ke = kb + klen < K ? kb + klen : K;
+	if (n0 < ntri) {
+		const int kx = (n0 + 16 + 15) & ~15;        // columns <= n0+15 of the triangular rows
+		if (kx < ke) ke = kx;
+	}
+	d4_t acc[TQ][4];
+#pragma unroll
+	for (int t = 0; t < TQ; t++)
+#pragma unroll
+		for (int u = 0; u < 4; u++) acc[t][u] = (d4_t){0.0, 0.0, 0.0, 0.0};
+	const double *lp = L + (long)(n0 + q) * ldl + 4 * g;
+	const double *ap = Kq + (long)q * ldk + 4 * g;
+	// memory-bound stream: four 16-k chunks (128 bytes per lane and operand) are requested before they are consumed
+	int k = kb;
+	for (; k + 64 <= ke; k += 64) {
+		d4_t b[4], a[TQ][4];
+#pragma unroll
+		for (int c = 0; c < 4; c++) b[c] = *reinterpret_cast<const d4_t *>(lp + k + 16 * c);
+#pragma unroll
+		for (int t = 0; t < TQ; t++)
+#pragma unroll
+			for (int c = 0; c < 4; c++) a[t][c] = *reinterpret_cast<const d4_t *>(ap + (long)t * 16 * ldk + k + 16 * c);
+#pragma unroll
+		for (int c = 0; c < 4; c++)
+#pragma unroll
+			for (int t = 0; t < TQ; t++)
+#pragma unroll
+				for (int u = 0; u < 4; u++)
+					acc[t][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t][c][u], b[c][u], acc[t][u], 0, 0, 0);
+	}
+	for (; k < ke; k += 16) {
+		const d4_t b = *reinterpret_cast<const d4_t *>(lp + k);
+#pragma unroll
+		for (int t = 0; t < TQ; t++) {
+			const d4_t a = *reinterpret_cast<const d4_t *>(ap + (long)t * 16 * ldk + k);
+#pragma unroll
+			for (int u = 0; u < 4; u++) acc[t][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc[t][u], 0, 0, 0);
+		}
+	}
+	double *vp = Vp + (long)blockIdx.y * sstride + n0 + q;
+#pragma unroll
+	for (int t = 0; t < TQ; t++)
+#pragma unroll
+		for (int r = 0; r < 4; r++)
+			vp[(long)(16 * t + g + 4 * r) * ldv] = (acc[t][0][r] + acc[t][1][r]) + (acc[t][2][r] + acc[t][3][r]);
+}
+
+// Vp[s][q][n] for q < 16*tq (tq = 1..4), n < ntot (multiple of 64), slices of klen (multiple of 16) over [0, K)
+hipError_t launch_skinny_nt(hipStream_t s, const double *Kq, long ldk, const double *L, long ldl, double *Vp, long ldv,
+                            long sstride, int tq, int ntot, int K, int ntri, int nslice, int klen)
+{
+	const dim3 grid(ntot / 64, nslice);
+	if (tq != 1) return hipErrorInvalidValue;       // more query tiles measured slower than the split-K GEMM
+	hipLaunchKernelGGL(skinny_nt_kernel<1>, grid, dim3(256), 0, s, Kq, ldk, L, ldl, Vp, ldv, sstride, K, ntri, klen);
+	return hipGetLastError();
+}
+
 // active-tile count for a tile shape (tri skips the tiles strictly above the diagonal)
 static long count_tiles(const GemmArgs &a, int BM, int BN)
 {
