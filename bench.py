@@ -4,10 +4,11 @@ at N=8192, d=8, fp64.
 
   python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank/GPU)
 
-A step = one evalFnMulti-equivalent likelihood evaluation (covariance fill + Cholesky + solves + logL, sigma^2,
-beta) at a FRESH theta (nothing cacheable), design resident in HBM.  The K evaluations are independent (the
-reference runs them as restart threads / a theta list): they are factored in lock-step batches (--batch) on
---streams concurrent contexts.  After the K timed evaluation steps a second timed region pushes 1e6 query points
+A step = one pass of the hot path over one batch of synthetic input: a lock-step batch of B independent
+evalFnMulti-equivalent likelihood evaluations (covariance fill + Cholesky + solves + logL, sigma^2, beta), each at
+its own FRESH theta (nothing cacheable), design resident in HBM -- what the reference runs as restart threads / a
+theta list.  B = --batch (default 16 at N >= 8192); the K steps are dealt to --streams concurrent contexts.
+value = evaluations per second = K * B * n_gpus / time ("evaluations_per_step" in the line).  After the K timed evaluation steps a second timed region pushes 1e6 query points
 (resident in HBM, min(K, 20) batches) through the posterior mean+variance sweep.
 Workload = BASELINE.json configs[2]: N=8192, d=8, Matern 5/2, regression order 1, 1e6 batched predictions.
 The evaluation is at given (supplied) thetas: the reference cannot train a Matern model.
@@ -97,7 +98,7 @@ def cpu_baseline(kind, order, N, d, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=24, help="timed steps; one step = one lock-step batch of --batch evaluations")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--queries", type=int, default=None, help="total prediction points per rank (default 1e6)")
@@ -189,14 +190,13 @@ def main():
     # batches dealt round-robin to the contexts: every kernel of a factorisation handles its B matrices at once,
     # and the latency-bound panel chain of one context overlaps the big GEMMs of the other
     want = args.batch if args.batch else int(min(64, max(16, 16 * (8192 / N) ** 2)))
-    B = max(1, min(want, -(-K // nstreams)))
-    chunks = [list(range(s0, min(s0 + B, K))) for s0 in range(0, K, B)]
-    for size in sorted({len(c) for c in chunks}):           # warm-up: captures the launch graph of every batch size used
-        for j in range(max(1, -(-W // (size * nstreams)))):
-            for c in ctxs:
-                c.loglik_batch_enqueue(np.array([theta(1000 + 97 * j + i) for i in range(size)]))
-        for c in ctxs:
-            c.loglik_batch_collect()
+    B = max(1, want)
+    chunks = [list(range(j * B, (j + 1) * B)) for j in range(K)]       # step j = evaluations j*B .. (j+1)*B-1
+    for j in range(max(1, W)):                                          # W untimed warm-up steps per context at least
+        for c in ctxs:                                                  # (the first one captures the launch graph)
+            c.loglik_batch_enqueue(np.array([theta(100000 + 97 * j + i) for i in range(B)]))
+    for c in ctxs:
+        c.loglik_batch_collect()
     barrier()
     t0 = time.perf_counter()
     for j, ch in enumerate(chunks):
@@ -214,16 +214,16 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         tA = float(tt.item())
         # the single collective of the path: gather (value, thetas...) per rank, arg-max on every rank
-        rows = shard.all_gather_rows(np.concatenate([[last["value"]], theta(K - 1)])[None, :], 1 + len(theta(0)))
+        rows = shard.all_gather_rows(np.concatenate([[last["value"]], theta(K * B - 1)])[None, :], 1 + len(theta(0)))
         assert len(rows) == world_size
-    evals_per_s = ngpus * K / tA
+    evals_per_s = ngpus * K * B / tA
 
     # ---- region B: batched predictions, queries resident in HBM
     pred = None
     if not args.no_predict:
         th0 = synth.default_thetas(kind, d)
         ctx.predict_setup(th0)
-        nb = max(1, min(K, 20))
+        nb = 20
         per = -(-nq // nb)
         Xq = synth.queries(per, d, seed + 11 + rank)
         dq, dm, dv = ctx.dev_alloc(Xq.nbytes), ctx.dev_alloc(per * 8), ctx.dev_alloc(per * 8)
@@ -306,7 +306,9 @@ def main():
                                    f"regression_order={order}, {nq} prediction points per rank",
                        "parallelism": f"independent evaluations / query blocks x{ngpus} GPUs, one all-gather; per GPU "
                                       f"{nstreams} contexts x lock-step batches of {B} evaluations",
-                       "streams_per_gpu": nstreams, "batch": B},
+                       "streams_per_gpu": nstreams, "batch": B,
+                       "step": f"one lock-step batch of {B} independent likelihood evaluations"},
+            "evaluations_per_step": B, "ms_per_evaluation": tA / (K * B) * 1e3,
             "predictions": pred,
             "roofline": roof, "roofline_other": roof_other,
             "cpu_baseline": cpu,
