@@ -162,17 +162,21 @@ int gpemu_prof_begin(gpemu_ctx *ctx, int kernel_class);
 int gpemu_prof_end(gpemu_ctx *ctx, int *nlaunches, double *total_ms, double *flops, double *bytes);
 
 /* Diagnostics: with GPEMU_TRACE=1 in the environment at gpemu_ctx_create, every GEMM / leaf kernel of a
- * factorisation records its first-workgroup start and last-workgroup end on the device wall clock; this writes
- * "tag | start_ns end_ns sum_of_workgroup_ns workgroups sum_of_workgroup_shader_clocks prologue_clocks epilogue_clocks" lines for the last factorisation.  Contexts of one GPU share the clock, so the files
- * of concurrent contexts merge into one timeline (tools/trace_timeline.py). */
+ * factorisation records (one workgroup in 16) its start and end on the device wall clock; this writes one line
+ * per launch of the last factorisation:
+ *   tag | start_ns end_ns sum_of_workgroup_ns workgroups sum_of_workgroup_shader_clocks prologue_clocks epilogue_clocks
+ * Contexts of one GPU share the clock, so the files of concurrent contexts merge into one timeline
+ * (tools/trace_timeline.py). */
 int gpemu_trace_dump(gpemu_ctx *ctx, const char *path);
 
 /* ---- low-level building blocks exported for parity tests ------------ */
-/* C[m*n] = beta*C + alpha * A[m*K] * B[n*K]^T, host row-major buffers */
+/* C[m*n] = beta*C + alpha * A[m*K] * B[n*K]^T, host row-major buffers; beta is 0 or 1, and with beta = 1
+ * alpha must be +1 or -1 (the accumulators start from C/alpha) */
 int gpemu_test_gemm_nt(gpemu_ctx *ctx, int m, int n, int k, double alpha, int beta,
                        const double *a, const double *b, double *c);
-/* micro-benchmark of one GEMM shape on device-resident random operands: cfg -1 = heuristic, 0 = 128x128,
- * 1 = 128x64, 2 = 64x64 tiles; tri = lower-trapezoid update as in the factorisation; HIP-event timed. */
+/* micro-benchmark of one GEMM shape on device-resident random operands: cfg -1 = heuristic, 0 = 128x128 tiles
+ * with 4 waves, 1 = 128x64, 2 = 64x64, 3 = 128x128 with 8 waves; tri = lower-trapezoid update as in the
+ * factorisation; HIP-event timed. */
 int gpemu_test_gemm_bench(gpemu_ctx *ctx, int m, int n, int k, int ld, int cfg, int tri, int beta, int reps,
                           double *ms_avg, double *flops);
 /* in-place lower Cholesky of a host n*n matrix (both triangles read as lower);
