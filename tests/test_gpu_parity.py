@@ -491,6 +491,38 @@ def test_maximum_dimensions(gpu_ctx):
     th[2:] = np.log(2.0)
     check_loglik(gpu_ctx, 1, 2, X, y, th)                 # nreg = 1 + 2*31 = 63: y and H fill all 64 augmented rows
 
+def test_predict_enqueue_collect_on_several_contexts(gpu_ctx):
+    """the asynchronous halves of gpemu_predict_batch: three contexts (PCA components of one design) are all started
+    before the first is collected; results equal the blocking call; misuse is reported, not executed"""
+    X, y = synth.design(500, 4, 21)
+    Y = synth.multi_outputs(X, y, 3)
+    th = thetas_for(1, 4)
+    ctxs = []
+    for c in range(3):
+        k = abi.Context(0)
+        k.set_model(1, 1, X, Y[:, c])
+        k.predict_setup(th)
+        ctxs.append(k)
+    for M in (1, 9, 40, 300):
+        Xq = synth.queries(M, 4, 5 + M)
+        ref = [k.predict(Xq) for k in ctxs]
+        for k in ctxs:
+            k.predict_enqueue(Xq)
+        got = [k.predict_collect() for k in ctxs]
+        for (m0, v0), (m1, v1) in zip(ref, got):
+            assert np.array_equal(m0, m1) and np.array_equal(v0, v1)
+    ctxs[0].predict_enqueue(Xq)
+    with pytest.raises(abi.GpemuError) as e:
+        ctxs[0].predict_enqueue(Xq)                      # a batch is already pending on this context
+    assert e.value.code == abi.ERR_STATE
+    ctxs[0].predict_collect()
+    with pytest.raises(abi.GpemuError) as e:
+        ctxs[0].predict_collect()                        # nothing pending
+    assert e.value.code == abi.ERR_STATE
+    for k in ctxs:
+        k.close()
+
+
 def test_model_switching_soak_is_deterministic():
     """two contexts, a random sequence of model changes (size, dimension, kernel, order) with evaluations, batches,
     gradients and predictions in between: workspaces and launch graphs are re-used / rebuilt correctly, and the
