@@ -62,7 +62,11 @@ __device__ __forceinline__ void trace_end(unsigned long long *t, TraceT0 t0)
 	atomicAdd(t + 4, clk - t0.clk);
 }
 
-template <int BM, int BN, int MINW, int WGM = 2, int WGN = 2>
+// PF = global-load prefetch distance in k-steps.  1: the chunk for step k+1 is requested at the top of step k and
+// written to LDS at its end.  2 (two register stages, for the 64x64 tiles that have the registers to spare): requested
+// two steps ahead -- the short-K panel updates are chains of dependent HBM round trips, one per k-step, and this halves
+// the chain.
+template <int BM, int BN, int MINW, int WGM = 2, int WGN = 2, int PF = 1>
 __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs g)
 {
 	constexpr int NT = 64 * WGM * WGN;              // threads: WGM x WGN waves
@@ -199,7 +203,56 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 	const int a_base = (wm * WM + (lane & 15)) * LDS_S + 2 * (lane >> 4);
 	const int b_base = (wn * WN + (lane & 15)) * LDS_S + 2 * (lane >> 4);
 
-	if (kb < ke) {
+#define GEMM_LOAD(RA, RB, kk)                                                                                     \
+	do {                                                                                                          \
+		_Pragma("unroll") for (int it = 0; it < AIT; it++) RA[it] = *reinterpret_cast<const d2_t *>(ag[it] + (kk)); \
+		_Pragma("unroll") for (int it = 0; it < BIT; it++) RB[it] = *reinterpret_cast<const d2_t *>(bg[it] + (kk)); \
+	} while (0)
+#define GEMM_STORE(RA, RB, buf)                                                                                   \
+	do {                                                                                                          \
+		_Pragma("unroll") for (int it = 0; it < AIT; it++) *reinterpret_cast<d2_t *>(&As[buf][lofs_a[it]]) = RA[it]; \
+		_Pragma("unroll") for (int it = 0; it < BIT; it++) *reinterpret_cast<d2_t *>(&Bs[buf][lofs_b[it]]) = RB[it]; \
+	} while (0)
+#define GEMM_STEP(buf)                                                                                            \
+	do {                                                                                                          \
+		const double *as = As[buf];                                                                               \
+		const double *bs = Bs[buf];                                                                               \
+		_Pragma("unroll") for (int t = 0; t < GEMM_BK / 8; t++) {                                                  \
+			d2_t a[TM], b[TN];                                                                                    \
+			_Pragma("unroll") for (int i = 0; i < TM; i++)                                                         \
+				a[i] = *reinterpret_cast<const d2_t *>(&as[a_base + i * 16 * LDS_S + 8 * t]);                      \
+			_Pragma("unroll") for (int j = 0; j < TN; j++)                                                         \
+				b[j] = *reinterpret_cast<const d2_t *>(&bs[b_base + j * 16 * LDS_S + 8 * t]);                      \
+			_Pragma("unroll") for (int h = 0; h < 2; h++)                                                          \
+				_Pragma("unroll") for (int i = 0; i < TM; i++)                                                     \
+					_Pragma("unroll") for (int j = 0; j < TN; j++)                                                 \
+						acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][h], b[j][h], acc[i][j], 0, 0, 0);    \
+		}                                                                                                         \
+	} while (0)
+	if (PF == 2 && kb < ke) {
+		d2_t r0a[AIT], r0b[BIT], r1a[AIT], r1b[BIT];
+		GEMM_LOAD(r0a, r0b, kb);
+		if (kb + GEMM_BK < ke) GEMM_LOAD(r1a, r1b, kb + GEMM_BK);
+		GEMM_STORE(r0a, r0b, 0);
+		__syncthreads();
+		if (g.trace && tr0.wall) atomicAdd(g.trace + 5, (unsigned long long)clock64() - tr0.clk);   // prologue
+		int cur = 0;
+		for (int k = kb; k < ke; k += 2 * GEMM_BK) {
+			// even step: chunk k is in LDS[cur], chunk k+16 in r1 (requested a step ago); request chunk k+32 into r0
+			if (k + 2 * GEMM_BK < ke) GEMM_LOAD(r0a, r0b, k + 2 * GEMM_BK);
+			GEMM_STEP(cur);
+			if (k + GEMM_BK < ke) GEMM_STORE(r1a, r1b, cur ^ 1);
+			__syncthreads();
+			cur ^= 1;
+			if (k + GEMM_BK >= ke) break;
+			// odd step: chunk k+16 in LDS[cur], chunk k+32 in r0; request chunk k+48 into r1
+			if (k + 3 * GEMM_BK < ke) GEMM_LOAD(r1a, r1b, k + 3 * GEMM_BK);
+			GEMM_STEP(cur);
+			if (k + 2 * GEMM_BK < ke) GEMM_STORE(r0a, r0b, cur ^ 1);
+			__syncthreads();
+			cur ^= 1;
+		}
+	} else if (kb < ke) {
 		d2_t ra[AIT], rb[BIT];
 #pragma unroll
 		for (int it = 0; it < AIT; it++) ra[it] = *reinterpret_cast<const d2_t *>(ag[it] + kb);
@@ -248,6 +301,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 			cur ^= 1;
 		}
 	}
+#undef GEMM_LOAD
+#undef GEMM_STORE
+#undef GEMM_STEP
 
 	// epilogue
 	unsigned long long clk_loop_end = 0;
@@ -412,7 +468,7 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs &a_in)
 	} else if (cfg == 3) {
 		hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 4, 4, 2>), dim3(T, nbatch), dim3(512), 0, s, a);
 	} else {
-		hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4>), dim3(T, nbatch), dim3(256), 0, s, a);
+		hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2, 2>), dim3(T, nbatch), dim3(256), 0, s, a);
 	}
 	return hipGetLastError();
 }
