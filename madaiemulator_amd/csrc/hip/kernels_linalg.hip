@@ -513,17 +513,34 @@ __device__ __forceinline__ void panel_factor(double *A, int lane, int &bad, int 
 		d2_t v = *reinterpret_cast<const d2_t *>(&A[lane * LD + 16 * P + c]);
 		a[c] = v[0]; a[c + 1] = v[1];
 	}
+	// 1/sqrt(pivot): hardware estimate + two Newton steps -- a chain of ~10 dependent fp64 operations.  The pivot of
+	// column k+1 is final as soon as column k has updated it, so its chain is started right there and runs beside the
+	// remaining independent updates of column k instead of in front of column k+1.
+	auto refined_rsqrt = [](double p) {
+		double rs = __builtin_amdgcn_rsq(p);
+		double t = p * rs; double e = fma(-t, rs, 1.0); rs = fma(rs * 0.5, e, rs);
+		t = p * rs; e = fma(-t, rs, 1.0); rs = fma(rs * 0.5, e, rs);
+		return rs;
+	};
+	double p = bcast_lane(a[0], 16 * P);
+	if (!(p > 0.0) && bad == 0) bad = bad_off + 16 * P + 1;
+	double rs = refined_rsqrt(p);
 #pragma unroll
 	for (int k = 0; k < 16; k++) {
-		const double p = bcast_lane(a[k], 16 * P + k);
-		if (!(p > 0.0) && bad == 0) bad = bad_off + 16 * P + k + 1;
-		double rs = __builtin_amdgcn_rsq(p);
-		{ double t = p * rs; double e = fma(-t, rs, 1.0); rs = fma(rs * 0.5, e, rs); t = p * rs; e = fma(-t, rs, 1.0); rs = fma(rs * 0.5, e, rs); }
 		const double lik = (lane == 16 * P + k) ? p * rs : a[k] * rs;
 		a[k] = lik;
+		double p_next = 1.0, rs_next = 1.0;
+		if (k + 1 < 16) {
+			a[k + 1] = fma(-lik, bcast_lane(lik, 16 * P + k + 1), a[k + 1]);
+			p_next = bcast_lane(a[k + 1], 16 * P + k + 1);
+			if (!(p_next > 0.0) && bad == 0) bad = bad_off + 16 * P + k + 2;
+			rs_next = refined_rsqrt(p_next);
+		}
 #pragma unroll
-		for (int c = k + 1; c < 16; c++)
+		for (int c = k + 2; c < 16; c++)
 			a[c] = fma(-lik, bcast_lane(lik, 16 * P + c), a[c]);
+		p = p_next;
+		rs = rs_next;
 	}
 	if (lane >= 16 * P) {
 #pragma unroll
