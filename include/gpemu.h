@@ -164,7 +164,9 @@ int gpemu_prof_end(gpemu_ctx *ctx, int *nlaunches, double *total_ms, double *flo
 /* Diagnostics: with GPEMU_TRACE=1 in the environment at gpemu_ctx_create, every GEMM / leaf kernel of a
  * factorisation records (one workgroup in 16) its start and end on the device wall clock; this writes one line
  * per launch of the last factorisation:
- *   tag | start_ns end_ns sum_of_workgroup_ns workgroups sum_of_workgroup_shader_clocks prologue_clocks epilogue_clocks
+ *   tag | start_ns end_ns sum_of_workgroup_ns workgroups sum_of_workgroup_shader_clocks stamp1 stamp2 stamp3
+ * (stamps, in shader clocks since the workgroup started: GEMM prologue end / epilogue length / -; leaf factor:
+ * block staged / first 16-column panel factored / first rank-16 update done)
  * Contexts of one GPU share the clock, so the files of concurrent contexts merge into one timeline
  * (tools/trace_timeline.py). */
 int gpemu_trace_dump(gpemu_ctx *ctx, const char *path);

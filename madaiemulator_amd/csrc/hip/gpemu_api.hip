@@ -1256,8 +1256,8 @@ extern "C" int gpemu_trace_dump(gpemu_ctx *ctx, const char *path)
 	for (int i = 0; i < ctx->trace_next; i++) {
 		const unsigned long long *q = &h[8 * (size_t)i];
 		if (q[3] == 0) continue;
-		fprintf(f, "%s | %llu %llu %llu %llu %llu %llu %llu\n", ctx->trace_tag[i].c_str(), ~q[0] * 10ull, q[1] * 10ull,
-		        q[2] * 10ull, q[3], q[4], q[5], q[6]);
+		fprintf(f, "%s | %llu %llu %llu %llu %llu %llu %llu %llu\n", ctx->trace_tag[i].c_str(), ~q[0] * 10ull, q[1] * 10ull,
+		        q[2] * 10ull, q[3], q[4], q[5], q[6], q[7]);
 	}
 	fclose(f);
 	return GPEMU_OK;

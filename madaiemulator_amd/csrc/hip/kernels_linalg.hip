@@ -593,11 +593,14 @@ __global__ __launch_bounds__(256) void leaf_factor_kernel(double *T, long ld, in
 		for (int u = 0; u < 16; u++) A[(wave + 4 * u) * LP + lane] = v[u];
 	}
 	__syncthreads();
+	if (trace && tr0.wall) atomicAdd(trace + 5, (unsigned long long)clock64() - tr0.clk);          // block staged in LDS
 	int bad = 0;
 	if (wave == 0) panel_factor<0, LP>(A, lane, bad, 0);
 	__syncthreads();
+	if (trace && tr0.wall) atomicAdd(trace + 6, (unsigned long long)clock64() - tr0.clk);          // first panel factored
 	panel_update<0, LP>(A, wave, lane);
 	__syncthreads();
+	if (trace && tr0.wall) atomicAdd(trace + 7, (unsigned long long)clock64() - tr0.clk);          // first update done
 	if (wave == 0) panel_factor<1, LP>(A, lane, bad, 0);
 	__syncthreads();
 	panel_update<1, LP>(A, wave, lane);
