@@ -49,7 +49,8 @@ static const char useage[] =
 	"  (-z) --pca_output: emulator output is left in the pca space\n"
 	"general options:\n"
 	"  -h -? print this dialogue\n"
-	"environment: GPEMU_DEVICE (HIP device), GPEMU_SEED, GPEMU_NTHREADS, GPEMU_JOBS, GPEMU_RESTARTS\n";
+	"environment: GPEMU_DEVICE (HIP device), GPEMU_SEED, GPEMU_RESTARTS, GPEMU_JOBS, GPEMU_LOCKSTEP (restart threads\n"
+	"sharing one device context, default 16), GPEMU_NTHREADS (with GPEMU_LOCKSTEP=1: threads with a context each)\n";
 
 static int perr(const char *s) { fprintf(stderr, "%s\n", s); return EXIT_FAILURE; }
 
