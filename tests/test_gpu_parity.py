@@ -77,6 +77,31 @@ def test_cov_matrix_vs_oracle(gpu_ctx, kind, N, d):
     assert np.array_equal(got, got.T)
 
 
+@pytest.mark.parametrize("kind", [1, 2, 3])
+@pytest.mark.parametrize("loglen", [-6.0, -2.0, 3.0, 7.0])
+def test_cov_matrix_extreme_hyperparameters(gpu_ctx, kind, loglen):
+    """very short and very long length scales, large and tiny amplitudes / nuggets: the table-based exp and the Newton
+    sqrt of the fill kernel against glibc through the oracle (entries that underflow must underflow alike)"""
+    d, N = 5, 130
+    X, y = synth.design(N, d, 77)
+    X[7] = X[3]                                            # a duplicated design point: off-diagonal nugget
+    gpu_ctx.set_model(kind, 0, X, y)
+    if kind == 1:
+        th = np.concatenate([[8.0, -18.0], np.full(d, loglen)])
+    else:
+        th = np.array([3.0e3, 1.0e-9, loglen])
+    got = gpu_ctx.cov_matrix(th)
+    ref = O.cov_matrix(kind, X, th)
+    assert np.all(np.isfinite(got))
+    big = np.abs(ref) > 1e-290
+    # exp(-x) carries the rounding of its argument, x * 2^-53 relative: the tolerance grows with x = -log(c / amp)
+    amp = np.exp(th[0]) if kind == 1 else th[0]
+    tol = 1e-13 + 1e-15 * np.abs(np.log(np.abs(ref[big]) / amp))
+    assert np.all(np.abs(got[big] - ref[big]) / np.abs(ref[big]) < tol)
+    assert np.all(np.abs(got[~big]) < 1e-280)
+    assert got[7, 3] == got[3, 3] and got[3, 7] == got[3, 3]     # duplicates carry the nugget off the diagonal too
+
+
 def test_cov_golden_special_pairs(gpu_ctx, golden):
     # identical points, |delta| = 5e-11 / 2e-10 (pow-exp nugget threshold), 5e-17 (Matern), far points
     for x, y, kind, d, val, th in zip(golden["g1_x"], golden["g1_y"], golden["g1_kind"], golden["g1_d"],
