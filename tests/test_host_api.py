@@ -62,6 +62,43 @@ def test_host_library_exports_reference_symbols():
         assert hasattr(lib, name), name
 
 
+def test_host_logic_without_gpu(tmp_path):
+    """mt19937 known answers, regression basis, PCA decomposition (Jacobi eigen-solver) against numpy, snapshot
+    dump -> load -> dump byte identity: the parts of the host mirror that never touch the device"""
+    build.build_all()
+    exe = str(tmp_path / "host_cpu_driver")
+    subprocess.check_call(["gcc", "-std=gnu99", "-O1", "-I", os.path.join(ROOT, "include"), "-I", build.HOST_SRC,
+                           "-o", exe, os.path.join(ROOT, "tests", "c", "host_cpu_driver.c"),
+                           "-L", build.LIBDIR, "-lEmuMI", "-lgpemu_hip", f"-Wl,-rpath,{build.LIBDIR}", "-lm"])
+    s1, s2 = tmp_path / "snap1", tmp_path / "snap2"
+    out = subprocess.run([exe, MULTI, str(s1), str(s2)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = parse(out.stdout)
+    # MT19937, init_genrand(5489): Matsumoto & Nishimura's reference output
+    assert [int(v) for v in res["mt"][0]] == [3499211612, 581869302, 3890346734, 3586334585]
+    assert res["uniform"][0][0] == 3499211612 / 4294967296.0
+    X, Y = synth.read_input_model_file(MULTI)
+    d = X.shape[1]
+    x0 = X[0]
+    assert res["h0"][0] == [1.0]
+    assert np.allclose(res["h1"][0], np.concatenate([[1.0], x0]), rtol=0, atol=0)
+    assert np.allclose(res["h2"][0], np.concatenate([[1.0], x0, x0 ** 2]), rtol=1e-15)
+    assert np.allclose(res["h3"][0], np.concatenate([[1.0], x0, x0 ** 2, x0 ** 3]), rtol=1e-15)
+    # PCA: eigen-decomposition of the (1/N) covariance of the centred outputs (multi_modelstruct.c:172-338)
+    Yc = Y - Y.mean(axis=0)
+    w, V = np.linalg.eigh(Yc.T @ Yc / len(Y))
+    w, V = w[::-1], V[:, ::-1]
+    nr = int(res["nr"][0][0])
+    assert 1 <= nr <= Y.shape[1]
+    assert np.allclose(res["evals"][0], w[:nr], rtol=1e-10)
+    E = np.array(res["evec"])
+    for r in range(nr):                                   # eigenvectors up to sign
+        assert min(np.max(np.abs(E[:, r] - V[:, r])), np.max(np.abs(E[:, r] + V[:, r]))) < 1e-8
+    z0 = (Yc[0] @ E) / np.sqrt(np.array(res["evals"][0]))
+    assert np.allclose(res["z0"][0], z0, rtol=1e-9, atol=1e-12)
+    assert s1.read_bytes() == s2.read_bytes() and len(s1.read_bytes()) > 100
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("path,d,order", [(UNI, 1, 0), (UNI, 1, 1), (TWOD, 2, 1)])
 def test_evalfn_gradfn_like_gsl_multimin_would_call_them(driver, path, d, order):
