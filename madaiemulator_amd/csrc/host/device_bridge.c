@@ -33,7 +33,8 @@ static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 
 static void die(gpemu_ctx *ctx, int rc, const char *where)
 {
-	fprintf(stderr, "%s: gpemu error %d: %s\n", where, rc, ctx ? gpemu_last_error(ctx) : "no usable HIP device");
+	fprintf(stderr, "%s: gpemu error %d: %s\n", where, rc,
+	        ctx ? gpemu_last_error(ctx) : rc == GPEMU_ERR_NO_DEVICE ? "no usable HIP device" : "(reported by the lock-step group's device context)");
 	exit(EXIT_FAILURE);
 }
 
