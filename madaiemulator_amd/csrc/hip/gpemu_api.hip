@@ -121,6 +121,18 @@ extern "C" int gpemu_device_count(void)
 	return n;
 }
 
+// process-wide tunables, read from the environment when a context is created (INTEGRATION.md lists them)
+static void read_environment()
+{
+	auto geti = [](const char *name, int *out) { const char *v = getenv(name); if (v) *out = atoi(v); return v != nullptr; };
+	int v = 0;
+	if (geti("GPEMU_GEMM_BIG_TILES", &v) && v > 0) gpemu::g_gemm_big_tiles = v;
+	geti("GPEMU_GEMM_BIG_CFG", &gpemu::g_gemm_big_cfg);
+	if (geti("GPEMU_LOOKAHEAD", &v)) g_lookahead = v != 0;
+	if (geti("GPEMU_LEAF128", &v)) g_leaf128 = v != 0;
+	if (geti("GPEMU_NB_TOP", &v) && v >= LEAF) g_nb_top = (v / LEAF) * LEAF;
+}
+
 extern "C" int gpemu_ctx_create(gpemu_ctx **out, int device)
 {
 	if (!out) return GPEMU_ERR_ARG;
@@ -128,69 +140,53 @@ extern "C" int gpemu_ctx_create(gpemu_ctx **out, int device)
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return GPEMU_ERR_NO_DEVICE;
 	if (device < 0 || device >= n) return GPEMU_ERR_ARG;
+	if (hipSetDevice(device) != hipSuccess) return GPEMU_ERR_HIP;
+	read_environment();
 	gpemu_ctx *ctx = new gpemu_ctx();
 	ctx->device = device;
-	if (hipSetDevice(device) != hipSuccess) { delete ctx; return GPEMU_ERR_HIP; }
-	{
-		int least = 0, greatest = 0;
-		if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = 0; greatest = 0; }
-		if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, greatest) != hipSuccess) {
-			delete ctx;
-			return GPEMU_ERR_HIP;
-		}
-		// The look-ahead stream is kept off a slice of the chip (GPEMU_RESERVE_CUS, default 32 of 256 CUs) so
-		// that the latency-bound panel kernels of the critical stream do not share MFMA pipes with the bulk
-		// trailing update (measured: sharing slows the 64x64 factor kernel 5x and cancels the overlap).
-		{
-			const char *tr = getenv("GPEMU_TRACE");
-			if (tr && atoi(tr) > 0) {
-				ctx->trace_cap = 4096;
-				if (hipMalloc(&ctx->dTrace, (size_t)ctx->trace_cap * 64) != hipSuccess) { ctx->dTrace = nullptr; ctx->trace_cap = 0; }
-			}
-		}
-		{ const char *lp = getenv("GPEMU_GEMM_BIG_TILES"); if (lp && atoi(lp) > 0) gpemu::g_gemm_big_tiles = atoi(lp); }
-		{ const char *lp = getenv("GPEMU_GEMM_BIG_CFG"); if (lp) gpemu::g_gemm_big_cfg = atoi(lp); }
-		const char *la0 = getenv("GPEMU_LOOKAHEAD");
-		const bool want_second = la0 ? atoi(la0) != 0 : g_lookahead != 0;   // only the look-ahead schedule uses it
-		int reserve = 32;
+	ctx->res_len = 64 * 64 + 8;
+	ctx->batch_cap = 1;
+	int least = 0, greatest = 0;
+	if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = 0; greatest = 0; }
+	bool ok = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, greatest) == hipSuccess;
+	if (ok && g_lookahead) {
+		// Only the look-ahead schedule uses a second stream.  It is kept off a slice of the chip (GPEMU_RESERVE_CUS,
+		// default 32 of 256 CUs) so that the latency-bound panel kernels of the critical stream do not share MFMA
+		// pipes with the bulk trailing update (measured: sharing slows the 64x64 factor kernel 5x).
+		int reserve = 32, ncu = 256;
 		const char *rs = getenv("GPEMU_RESERVE_CUS");
 		if (rs) reserve = atoi(rs);
 		hipDeviceProp_t prop;
-		int ncu = 256;
 		if (hipGetDeviceProperties(&prop, device) == hipSuccess) ncu = prop.multiProcessorCount;
-		hipError_t e2 = want_second ? hipErrorUnknown : hipSuccess;
-		if (want_second && reserve > 0 && reserve < ncu) {
+		hipError_t e2 = hipErrorUnknown;
+		if (reserve > 0 && reserve < ncu) {
 			std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
 			for (int i = 0; i < ncu - reserve; i++) mask[i / 32] |= (1u << (i % 32));
 			e2 = hipExtStreamCreateWithCUMask(&ctx->stream2, (uint32_t)mask.size(), mask.data());
 		}
-		if (want_second && e2 != hipSuccess) {
+		if (e2 != hipSuccess) {
 			(void)hipGetLastError();
 			e2 = hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, least);
 		}
-		if (e2 != hipSuccess) {
-			delete ctx;
-			return GPEMU_ERR_HIP;
-		}
+		ok = e2 == hipSuccess;
 	}
-	ctx->res_len = 64 * 64 + 8;
-	if (hipMalloc(&ctx->dInfo, sizeof(int)) != hipSuccess ||
-	    hipMalloc(&ctx->dDiagInv, (size_t)GPEMU_MAX_BATCH * 8 * 256 * sizeof(double)) != hipSuccess ||
-	    hipMalloc(&ctx->dRes, ctx->res_len * sizeof(double)) != hipSuccess ||
-	    hipHostMalloc((void **)&ctx->hRes, ctx->res_len * sizeof(double)) != hipSuccess ||
-	    hipHostMalloc((void **)&ctx->hInfo, sizeof(int)) != hipSuccess) {
+	ok = ok && hipMalloc(&ctx->dInfo, sizeof(int)) == hipSuccess &&
+	     hipMalloc(&ctx->dDiagInv, (size_t)GPEMU_MAX_BATCH * 8 * 256 * sizeof(double)) == hipSuccess &&
+	     hipMalloc(&ctx->dRes, ctx->res_len * sizeof(double)) == hipSuccess &&
+	     hipHostMalloc((void **)&ctx->hRes, ctx->res_len * sizeof(double)) == hipSuccess &&
+	     hipHostMalloc((void **)&ctx->hInfo, sizeof(int)) == hipSuccess;
+	const char *tr = getenv("GPEMU_TRACE");
+	if (ok && tr && atoi(tr) > 0) {                 // in-kernel timestamps: 4096 launch slots of 8 x u64
+		ctx->trace_cap = 4096;
+		if (hipMalloc(&ctx->dTrace, (size_t)ctx->trace_cap * 64) != hipSuccess) { ctx->dTrace = nullptr; ctx->trace_cap = 0; }
+	}
+	const char *ng = getenv("GPEMU_NO_GRAPH");
+	if (ng && ng[0] == '1') ctx->use_graph = false;
+	if (!ok) {
+		(void)hipGetLastError();
 		gpemu_ctx_destroy(ctx);
 		return GPEMU_ERR_HIP;
 	}
-	ctx->batch_cap = 1;
-	const char *ng = getenv("GPEMU_NO_GRAPH");
-	if (ng && ng[0] == '1') ctx->use_graph = false;
-	const char *la = getenv("GPEMU_LOOKAHEAD");
-	if (la) g_lookahead = atoi(la) != 0;
-	const char *l128 = getenv("GPEMU_LEAF128");
-	if (l128) g_leaf128 = atoi(l128) != 0;
-	const char *nbt = getenv("GPEMU_NB_TOP");
-	if (nbt && atoi(nbt) >= LEAF) g_nb_top = (atoi(nbt) / LEAF) * LEAF;
 	*out = ctx;
 	return GPEMU_OK;
 }
