@@ -142,6 +142,16 @@ int gpemu_predict_batch_collect(gpemu_ctx *ctx, int npoints, double *mean, doubl
 int gpemu_predict_batch_dev(gpemu_ctx *ctx, int npoints, const double *xq_dev,
                             double *mean_dev, double *var_dev);
 
+/* ---- low-level compatibility with the reference's host-matrix interface (what libRbind links against) ------
+ * a14 chol_inverse_cov_matrix (libEmu/emulate-fns.c:275-299): the n x n matrix a (row stride lda, lower triangle
+ * read) is replaced by its inverse (both triangles); *logdet = 2 sum log L_ii; *info as gpemu_loglik. */
+int gpemu_chol_inverse(gpemu_ctx *ctx, int n, double *a_inout, int lda, double *logdet, int *info);
+/* the C^-1-times-vector products of estimateBeta / getLogLikelyhood / makeEmulatedMean / makeEmulatedVariance
+ * (libEmu/regression.c:120-176, estimator-fns.c:38-103, emulator.c:672-785) with C^-1 passed in host memory:
+ * out[v*n + i] = sum_j a[i*lda + j] * v_rows[v*n + j] for nvec vectors stored as rows.  The matrix is uploaded when
+ * its (pointer, size, fingerprint) differs from the copy the context holds. */
+int gpemu_symm_apply(gpemu_ctx *ctx, int n, const double *a, int lda, int nvec, const double *v_rows, double *out_rows);
+
 /* ---- device memory helpers for callers that keep data resident ------ */
 int gpemu_dev_alloc(gpemu_ctx *ctx, size_t bytes, void **dptr);
 int gpemu_dev_free(gpemu_ctx *ctx, void *dptr);

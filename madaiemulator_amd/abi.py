@@ -45,6 +45,8 @@ SYMBOLS = {
     "gpemu_predict_batch_enqueue": (C.c_int, [C.c_void_p, C.c_int, _dp]),
     "gpemu_predict_batch_collect": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp]),
     "gpemu_predict_batch_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gpemu_chol_inverse": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, _dp, _ip]),
+    "gpemu_symm_apply": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp]),
     "gpemu_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "gpemu_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gpemu_dev_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -249,6 +251,19 @@ class Context:
         m, v = np.empty(self._npred), np.empty(self._npred)
         self._chk(self.L.gpemu_predict_batch_collect(self.h, self._npred, _p(m), _p(v)))
         return m, v
+
+    def chol_inverse(self, A):
+        A = _a(A).copy()
+        ld, info = C.c_double(np.nan), C.c_int(0)
+        rc = self._chk(self.L.gpemu_chol_inverse(self.h, A.shape[0], _p(A), A.shape[1], C.byref(ld), C.byref(info)),
+                       allow=(ERR_NOT_PD,))
+        return A, ld.value, info.value, rc
+
+    def symm_apply(self, A, V):
+        A, V = _a(A), _a(V).reshape(-1, np.shape(A)[0])
+        out = np.empty_like(V)
+        self._chk(self.L.gpemu_symm_apply(self.h, A.shape[0], _p(A), A.shape[1], V.shape[0], _p(V), _p(out)))
+        return out
 
     def cinverse(self):
         out = np.empty((self.N, self.N))

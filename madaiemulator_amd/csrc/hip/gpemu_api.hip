@@ -219,6 +219,9 @@ extern "C" void gpemu_ctx_destroy(gpemu_ctx *ctx)
 	if (ctx->dInfo) hipFree(ctx->dInfo);
 	if (ctx->dTrace) hipFree(ctx->dTrace);
 	if (ctx->dDiagInv) hipFree(ctx->dDiagInv);
+	if (ctx->dSym) hipFree(ctx->dSym);
+	if (ctx->dSymV) hipFree(ctx->dSymV);
+	if (ctx->dSymOut) hipFree(ctx->dSymOut);
 	if (ctx->dRes) hipFree(ctx->dRes);
 	if (ctx->hRes) hipHostFree(ctx->hRes);
 	if (ctx->hInfo) hipHostFree(ctx->hInfo);
@@ -1256,6 +1259,113 @@ extern "C" int gpemu_trace_dump(gpemu_ctx *ctx, const char *path)
 		        q[2] * 10ull, q[3], q[4], q[5], q[6], q[7]);
 	}
 	fclose(f);
+	return GPEMU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// low-level compatibility entries: the reference's libRbind-era interface passes N x N matrices through host
+// memory (emulate-fns.c:275-299, regression.c:120-176, emulator.c:672-785).  The O(N^2)/O(N^3) work still runs here.
+// ---------------------------------------------------------------------------
+// C -> C^-1 in place (both triangles), log det C = 2 sum log L_ii; *info = 1-based index of the first pivot <= 0
+extern "C" int gpemu_chol_inverse(gpemu_ctx *ctx, int n, double *a, int lda, double *logdet, int *info)
+{
+	if (!ctx || n < 1 || !a || lda < n) return GPEMU_ERR_ARG;
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	gpemu_ctx tmp;                       // scratch state on the caller's stream: sizes of this matrix, no model
+	tmp.device = ctx->device; tmp.stream = ctx->stream; tmp.use_graph = false;
+	tmp.Np = round_up(n, LEAF); tmp.Rp = 64; tmp.N = n; tmp.nrhs = 0; tmp.nb = 1;
+	const int Np = tmp.Np, Rp = tmp.Rp;
+	const size_t rows = (size_t)2 * Np + Rp, dim = (size_t)Np + Rp;
+	std::vector<double> h((size_t)Np * Np, 0.0), diag((size_t)n);
+	for (int i = 0; i < Np; i++)
+		for (int j = 0; j <= i; j++)
+			h[(size_t)i * Np + j] = (i < n) ? a[(size_t)i * lda + j] : (i == j ? 1.0 : 0.0);
+	int big = INFO_NONE, inf = 0;
+	hipError_t e = hipMalloc(&tmp.dT, rows * Np * sizeof(double));
+	if (e == hipSuccess) e = hipMalloc(&tmp.dInfo, sizeof(int));
+	if (e == hipSuccess) e = hipMalloc(&tmp.dS, dim * dim * sizeof(double));
+	if (e == hipSuccess) tmp.S_dim = dim;
+	tmp.dDiagInv = ctx->dDiagInv;
+	if (e == hipSuccess) e = hipMemcpyAsync(tmp.dT, h.data(), h.size() * 8, hipMemcpyHostToDevice, tmp.stream);
+	if (e == hipSuccess) e = hipMemsetAsync(tmp.dT + (size_t)Np * Np, 0, (size_t)Rp * Np * 8, tmp.stream);
+	if (e == hipSuccess) e = launch_set_identity_rows(tmp.stream, tmp.dT + (size_t)(Np + Rp) * Np, Np, Np);
+	if (e == hipSuccess) e = hipMemcpyAsync(tmp.dInfo, &big, sizeof(int), hipMemcpyHostToDevice, tmp.stream);
+	if (e == hipSuccess) e = potrf_rec(&tmp, 0, Np, 1);
+	if (e == hipSuccess) e = hipMemcpyAsync(&inf, tmp.dInfo, sizeof(int), hipMemcpyDeviceToHost, tmp.stream);
+	if (e == hipSuccess)
+		e = hipMemcpy2DAsync(diag.data(), sizeof(double), tmp.dT, ((size_t)Np + 1) * sizeof(double), sizeof(double), n,
+		                     hipMemcpyDeviceToHost, tmp.stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(tmp.stream);
+	const int bad = (inf >= INFO_NONE) ? 0 : inf;
+	if (e == hipSuccess && !bad) {
+		int rc = build_corner(&tmp);         // C^-1 = U U^T, lower triangle at (Rp, Rp) of the corner matrix
+		if (rc) e = hipErrorUnknown;
+		if (e == hipSuccess)
+			e = hipMemcpy2DAsync(a, (size_t)lda * sizeof(double), tmp.dS + (size_t)Rp * dim + Rp, dim * sizeof(double),
+			                     (size_t)n * sizeof(double), n, hipMemcpyDeviceToHost, tmp.stream);
+		if (e == hipSuccess) e = hipStreamSynchronize(tmp.stream);
+	}
+	if (tmp.dT) hipFree(tmp.dT);
+	if (tmp.dInfo) hipFree(tmp.dInfo);
+	if (tmp.dS) hipFree(tmp.dS);
+	tmp.dT = nullptr; tmp.dInfo = nullptr; tmp.dS = nullptr; tmp.stream = nullptr; tmp.dDiagInv = nullptr;
+	HIPCHK(ctx, e);
+	if (info) *info = bad;
+	if (bad) return fail(ctx, GPEMU_ERR_NOT_PD, "matrix is not positive definite");
+	double ld = 0.0;
+	for (int i = 0; i < n; i++) ld += log(diag[i]);
+	if (logdet) *logdet = 2.0 * ld;
+	for (int i = 0; i < n; i++)
+		for (int j = i + 1; j < n; j++) a[(size_t)i * lda + j] = a[(size_t)j * lda + i];
+	return GPEMU_OK;
+}
+
+// out[v][i] = sum_j A[i][j] V[v][j] for nvec vectors stored as rows; A symmetric, host-resident, N x N with row
+// stride lda.  A is uploaded when (pointer, sizes, fingerprint) differ from the cached copy.
+extern "C" int gpemu_symm_apply(gpemu_ctx *ctx, int n, const double *a, int lda, int nvec, const double *v, double *out)
+{
+	if (!ctx || n < 1 || !a || lda < n || nvec < 1 || !v || !out) return GPEMU_ERR_ARG;
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	const int Npad = round_up(n, 64);
+	const double fp = a[0] + 3.0 * a[(size_t)(n / 2) * lda + n / 3] + 7.0 * a[(size_t)(n - 1) * lda + n - 1] +
+	                  11.0 * a[(size_t)(n - 1) * lda];
+	if (ctx->sym_key != a || ctx->sym_N != n || ctx->sym_lda != lda || ctx->sym_fp != fp || !ctx->dSym) {
+		HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+		if (ctx->sym_pad != Npad || !ctx->dSym) {
+			if (ctx->dSym) hipFree(ctx->dSym);
+			ctx->dSym = nullptr;
+			HIPCHK(ctx, hipMalloc(&ctx->dSym, (size_t)Npad * Npad * sizeof(double)));
+			ctx->sym_pad = Npad;
+			ctx->sym_vcap = 0;
+		}
+		HIPCHK(ctx, hipMemsetAsync(ctx->dSym, 0, (size_t)Npad * Npad * sizeof(double), ctx->stream));
+		HIPCHK(ctx, hipMemcpy2DAsync(ctx->dSym, (size_t)Npad * sizeof(double), a, (size_t)lda * sizeof(double),
+		                             (size_t)n * sizeof(double), n, hipMemcpyHostToDevice, ctx->stream));
+		ctx->sym_key = a; ctx->sym_N = n; ctx->sym_lda = lda; ctx->sym_fp = fp;
+	}
+	if (ctx->sym_vcap < nvec) {
+		HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+		if (ctx->dSymV) hipFree(ctx->dSymV);
+		if (ctx->dSymOut) hipFree(ctx->dSymOut);
+		ctx->dSymV = ctx->dSymOut = nullptr; ctx->sym_vcap = 0;
+		const int cap = round_up(nvec, 64);
+		HIPCHK(ctx, hipMalloc(&ctx->dSymV, (size_t)cap * Npad * sizeof(double)));
+		HIPCHK(ctx, hipMalloc(&ctx->dSymOut, (size_t)cap * Npad * sizeof(double)));
+		ctx->sym_vcap = cap;
+	}
+	HIPCHK(ctx, hipMemsetAsync(ctx->dSymV, 0, (size_t)nvec * Npad * sizeof(double), ctx->stream));
+	HIPCHK(ctx, hipMemcpy2DAsync(ctx->dSymV, (size_t)Npad * sizeof(double), v, (size_t)n * sizeof(double),
+	                             (size_t)n * sizeof(double), nvec, hipMemcpyHostToDevice, ctx->stream));
+	GemmArgs g;
+	memset(&g, 0, sizeof g);
+	g.C = ctx->dSymOut; g.ldc = Npad;
+	g.A = ctx->dSymV; g.lda = Npad;
+	g.B = ctx->dSym; g.ldb = Npad;
+	g.m = nvec; g.n = Npad; g.k0 = 0; g.k1 = Npad; g.alpha = 1.0; g.beta = 0;
+	HIPCHK(ctx, gemm(ctx, g));
+	HIPCHK(ctx, hipMemcpy2DAsync(out, (size_t)n * sizeof(double), ctx->dSymOut, (size_t)Npad * sizeof(double),
+	                             (size_t)n * sizeof(double), nvec, hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 	return GPEMU_OK;
 }
 

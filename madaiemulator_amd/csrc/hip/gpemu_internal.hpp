@@ -124,6 +124,11 @@ struct gpemu_ctx {
 
 	// gradient scratch
 	double *dGradPart = nullptr;
+	// gpemu_symm_apply: a host-resident symmetric matrix kept on the device between calls
+	double *dSym = nullptr, *dSymV = nullptr, *dSymOut = nullptr;
+	const double *sym_key = nullptr;
+	int sym_N = 0, sym_lda = 0, sym_pad = 0, sym_vcap = 0;
+	double sym_fp = 0.0;
 	double *dAlpha = nullptr;    // Np doubles of alpha = C^-1 y, then the d length-scale thetas
 	size_t gradpart_len = 0;
 

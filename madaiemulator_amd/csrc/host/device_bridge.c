@@ -56,6 +56,15 @@ static struct entry *lookup(const void *key, int create)
 	return e;
 }
 
+/* one scratch device context per host thread for the model-less low-level entries (lowlevel.c) */
+gpemu_ctx *gpemu_host_scratch_ctx(const char *where)
+{
+	static __thread char tls_key;
+	struct entry *e = lookup(&tls_key, 1);
+	if (!e || !e->ctx) { fprintf(stderr, "%s: no device context\n", where); exit(EXIT_FAILURE); }
+	return e->ctx;
+}
+
 void gpemu_host_release(void *key)
 {
 	pthread_mutex_lock(&g_lock);

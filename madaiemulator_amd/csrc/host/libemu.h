@@ -129,6 +129,19 @@ void makeHVector_cubic(gsl_vector *h_vector, gsl_vector *x_location, int nparams
 void makeHMatrix_fnptr(gsl_matrix *h_matrix, gsl_matrix *xmodel, int nmodel_points, int nparams, int nregression_fns,
                        void (*makeHVector_ptr)(gsl_vector *, gsl_vector *, int));
 
+/* ---- host-matrix interface below evalFnMulti / emulate_point (what libRbind calls; lowlevel.c) ------------- */
+void chol_inverse_cov_matrix(optstruct *options, gsl_matrix *temp_matrix, gsl_matrix *result_matrix, double *final_determinant_c);
+void estimateBeta(gsl_vector *beta_vector, gsl_matrix *h_matrix, gsl_matrix *cinverse, gsl_vector *trainingvector,
+                  int nmodel_points, int nregression_fns);
+double estimateSigma(gsl_matrix *cinverse, void *params_in);
+double getLogLikelyhood(gsl_matrix *cinverse, double det_cmatrix, gsl_matrix *xmodel, gsl_vector *trainingvector,
+                        gsl_vector *thetas, gsl_matrix *h_matrix, int nmodel_points, int nthetas, int nparams,
+                        int nregression_fns, void (*makeHVector)(gsl_vector *, gsl_vector *, int));
+double makeEmulatedMean(gsl_matrix *inverse_cov_matrix, gsl_vector *training_vector, gsl_vector *kplus_vector,
+                        gsl_vector *h_vector, gsl_matrix *h_matrix, gsl_vector *beta_vector, int nmodel_points);
+double makeEmulatedVariance(gsl_matrix *inverse_cov_matrix, gsl_vector *kplus_vector, gsl_vector *h_vector,
+                            gsl_matrix *h_matrix, double kappa, int nmodel_points, int nregression_fns);
+
 /* ---- libEmu/maxmultimin.h ------------------------------------------------ */
 double evalFnMulti(const gsl_vector *theta_vec_less_amp, void *params_in);
 /* extension: evalFnMulti for every row of a matrix (the first nthetas-1 entries of each row are read), factored in

@@ -6,10 +6,12 @@
  *   host_api_driver emu   INPUT_MODEL_FILE cov_fn order QUERY_FILE theta_full...
  *   host_api_driver roundtrip SNAPSHOT_IN SNAPSHOT_OUT
  *   host_api_driver multi SNAPSHOT QUERY_FILE
+ *   host_api_driver lowlevel INPUT_MODEL_FILE cov_fn order QUERY_FILE theta_full...   (the host-matrix interface)
  */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 #include "libemu.h"
 
 static int read_model(const char *name, gsl_matrix **x, gsl_matrix **y)
@@ -115,6 +117,38 @@ int main(int argc, char **argv)
 		for (int i = 0; i < nthetas - 1; i++) gsl_vector_set(th, i, gsl_vector_get(model->thetas, i + 1));
 		printf("neglogl %.17g\n", evalFnMulti(th, &params));
 		gpemu_host_release(&params);
+	} else if (!strcmp(argv[1], "lowlevel")) {
+		/* the call sequence of the reference's R bindings (libRbind/rbind.c:121-210): N x N matrices in host memory */
+		const int N = (int)x->size1, d = (int)x->size2, nreg = model->options->nregression_fns;
+		gsl_matrix *q = read_queries(argv[5], d);
+		for (int i = 0; i < nthetas; i++) gsl_vector_set(model->thetas, i, atof(argv[6 + i]));
+		gsl_matrix *c = gsl_matrix_alloc(N, N), *cinv = gsl_matrix_alloc(N, N), *H = gsl_matrix_alloc(N, nreg);
+		makeCovMatrix_fnptr(c, model->xmodel, model->thetas, N, nthetas, d, model->covariance_fn);
+		double det = 0.0;
+		chol_inverse_cov_matrix(model->options, c, cinv, &det);
+		printf("logdet %.17g\n", log(det));
+		makeHMatrix_fnptr(H, model->xmodel, N, d, nreg, model->makeHVector);
+		gsl_vector *beta = gsl_vector_alloc(nreg);
+		estimateBeta(beta, H, cinv, model->training_vector, N, nreg);
+		printf("beta");
+		for (int a = 0; a < nreg; a++) printf(" %.17g", gsl_vector_get(beta, a));
+		printf("\n");
+		printf("loglik %.17g\n", getLogLikelyhood(cinv, det, model->xmodel, model->training_vector, model->thetas, H, N,
+		                                          nthetas, d, nreg, model->makeHVector));
+		struct estimate_thetas_params params;
+		memset(&params, 0, sizeof params);
+		params.options = model->options; params.the_model = model; params.h_matrix = H;
+		printf("sigma2 %.17g\n", estimateSigma(cinv, &params));
+		gsl_vector *k = gsl_vector_alloc(N), *h = gsl_vector_alloc(nreg), *pt = gsl_vector_alloc(d);
+		for (size_t i = 0; i < q->size1; i++) {
+			for (int kk = 0; kk < d; kk++) gsl_vector_set(pt, kk, gsl_matrix_get(q, i, kk));
+			makeKVector_fnptr(k, model->xmodel, pt, model->thetas, N, nthetas, d, model->covariance_fn);
+			model->makeHVector(h, pt, d);
+			const double kappa = model->covariance_fn(pt, pt, model->thetas, nthetas, d);
+			const double m = makeEmulatedMean(cinv, model->training_vector, k, h, H, beta, N);
+			const double v = makeEmulatedVariance(cinv, k, h, H, kappa, N, nreg);
+			printf("pred %.17g %.17g\n", m, v);
+		}
 	} else if (!strcmp(argv[1], "emu")) {
 		gsl_matrix *q = read_queries(argv[5], (int)x->size2);
 		for (int i = 0; i < nthetas; i++) gsl_vector_set(model->thetas, i, atof(argv[6 + i]));

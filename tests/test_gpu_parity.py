@@ -548,6 +548,29 @@ def test_predict_enqueue_collect_on_several_contexts(gpu_ctx):
         k.close()
 
 
+@pytest.mark.parametrize("n", [5, 64, 300, 1100])
+def test_chol_inverse_and_symm_apply_on_host_matrices(gpu_ctx, n):
+    """the host-matrix entries behind chol_inverse_cov_matrix / estimateBeta / makeEmulatedMean: inverse and log det of
+    a host matrix, and C^-1 applied to a few vectors, against LAPACK"""
+    rng = np.random.default_rng(n)
+    B = rng.standard_normal((n, n))
+    A = B @ B.T / n + np.eye(n) * 0.5
+    inv, logdet, info, rc = gpu_ctx.chol_inverse(A)
+    assert rc == 0 and info == 0
+    ref = np.linalg.inv(A)
+    assert relerr(inv, ref) < 1e-9 and np.array_equal(inv, inv.T)
+    assert logdet == pytest.approx(np.linalg.slogdet(A)[1], rel=1e-11)
+    V = rng.standard_normal((7, n))
+    out = gpu_ctx.symm_apply(ref, V)
+    assert relerr(out, V @ ref) < 1e-12
+    out2 = gpu_ctx.symm_apply(ref, V[:2])                # cached matrix, fewer vectors
+    assert np.array_equal(out2, out[:2])
+    bad = A.copy()
+    bad[n // 2, n // 2] = -1.0
+    _, _, info, rc = gpu_ctx.chol_inverse(bad)
+    assert rc == abi.ERR_NOT_PD and info == n // 2 + 1
+
+
 def test_model_switching_soak_is_deterministic():
     """two contexts, a random sequence of model changes (size, dimension, kernel, order) with evaluations, batches,
     gradients and predictions in between: workspaces and launch graphs are re-used / rebuilt correctly, and the

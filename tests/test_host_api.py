@@ -58,7 +58,9 @@ def test_host_library_exports_reference_symbols():
                  "emulate_point", "makeCovMatrix_fnptr", "makeKVector_fnptr", "makeHMatrix_fnptr", "makeHVector_linear",
                  "covariance_fn_gaussian", "covariance_fn_matern_three", "covariance_fn_matern_five",
                  "alloc_multimodelstruct", "gen_pca_decomp", "dump_multi_modelstruct", "load_multi_modelstruct",
-                 "alloc_multi_emulator", "emulate_point_multi", "emulate_point_multi_pca", "estimate_multi"):
+                 "alloc_multi_emulator", "emulate_point_multi", "emulate_point_multi_pca", "estimate_multi",
+                 "chol_inverse_cov_matrix", "estimateBeta", "estimateSigma", "getLogLikelyhood", "makeEmulatedMean",
+                 "makeEmulatedVariance", "callEvalLhoodList", "evalFnMultiList", "emulate_points"):
         assert hasattr(lib, name), name
 
 
@@ -144,6 +146,32 @@ def test_emulator_struct_and_emulate_point(driver, tmp_path, cov, order):
     assert np.max(np.abs(pred[:, 1] - v)) <= RTOL * kappa
     assert np.array_equal(pred, batch)                      # one point at a time == one batch
     assert res["cinverse00"][0][0] == pytest.approx(e.cinverse[0, 0], rel=RTOL)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cov,order", [(1, 1), (3, 0)])
+def test_lowlevel_host_matrix_interface(driver, tmp_path, cov, order):
+    """chol_inverse_cov_matrix, estimateBeta, estimateSigma, getLogLikelyhood, makeEmulatedMean / Variance with the
+    N x N matrices in host memory, called in the order the reference's R bindings call them (rbind.c:121-210)"""
+    X, Y = synth.read_input_model_file(TWOD)
+    y = Y[:, 0]
+    th = np.array([-0.2, -3.5, -1.0, -0.7]) if cov == 1 else np.array([1.3, 0.02, np.log(0.8)])
+    Q = np.vstack([synth.queries(12, 2, 3), X[:1]])
+    qf = tmp_path / "q.dat"
+    np.savetxt(qf, Q, fmt="%.17g")
+    res = parse(run([driver, "lowlevel", TWOD, str(cov), str(order), str(qf)] + [repr(float(t)) for t in th]))
+    e = O.Emulator(cov, order, X, y, th)
+    r = y - e.H @ e.beta
+    quad = r @ e.cinverse @ r
+    assert res["logdet"][0][0] == pytest.approx(e.logdet, rel=RTOL)
+    assert np.allclose(res["beta"][0], e.beta, rtol=RTOL)
+    assert res["loglik"][0][0] == pytest.approx(-0.5 * e.logdet - len(y) / 2.0 * 1.83788 - 0.5 * quad, rel=RTOL)
+    assert res["sigma2"][0][0] == pytest.approx(y @ e.cinverse @ r / len(y), rel=RTOL)
+    m, v, _ = e.emulate(Q)
+    pred = np.array(res["pred"])
+    kappa = O.cov(cov, Q[0], Q[0], th)
+    assert np.max(np.abs(pred[:, 0] - m)) <= RTOL * max(1.0, np.abs(m).max())
+    assert np.max(np.abs(pred[:, 1] - v)) <= RTOL * kappa
 
 
 @pytest.mark.gpu
