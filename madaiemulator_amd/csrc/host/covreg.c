@@ -190,3 +190,36 @@ void makeHMatrix_fnptr(gsl_matrix *h_matrix, gsl_matrix *xmodel, int nmodel_poin
 		makeHVector_ptr(&hr.vector, &xr.vector, nparams);
 	}
 }
+
+/* ---- the process-wide function pointers of the reference's headers (emulator.h:13, regression.h:32,
+ * maxmultimin.h:26) and the entry points that dispatch on them (emulator.c:548-562, 607-623; regression.c:77-91).
+ * set_global_ptrs (modelstruct.c) sets them together with the model's own pointers; as in the reference, two models
+ * with different kernels in one process make these -- and only these -- entry points ambiguous. */
+double (*covariance_fn)(gsl_vector *, gsl_vector *, gsl_vector *, int, int) = NULL;
+void (*makeHVector)(gsl_vector *h_vector, gsl_vector *x_location, int nparams) = NULL;
+void (*makeGradMatLength)(gsl_matrix *dCdTheta, gsl_matrix *xmodel, double thetaLength, int index, int nmodel_points,
+                          int nparams) = NULL;
+
+static void need_global(const void *p, const char *who)
+{
+	if (!p) { fprintf(stderr, "%s: set_global_ptrs has not been called\n", who); exit(EXIT_FAILURE); }
+}
+
+void makeCovMatrix(gsl_matrix *cov_matrix, gsl_matrix *xmodel, gsl_vector *thetas, int nmodel_points, int nthetas, int nparams)
+{
+	need_global((const void *)covariance_fn, "makeCovMatrix");
+	makeCovMatrix_fnptr(cov_matrix, xmodel, thetas, nmodel_points, nthetas, nparams, covariance_fn);
+}
+
+void makeKVector(gsl_vector *kvector, gsl_matrix *xmodel, gsl_vector *xnew, gsl_vector *thetas, int nmodel_points,
+                 int nthetas, int nparams)
+{
+	need_global((const void *)covariance_fn, "makeKVector");
+	makeKVector_fnptr(kvector, xmodel, xnew, thetas, nmodel_points, nthetas, nparams, covariance_fn);
+}
+
+void makeHMatrix(gsl_matrix *h_matrix, gsl_matrix *xmodel, int nmodel_points, int nparams, int nregression_fns)
+{
+	need_global((const void *)makeHVector, "makeHMatrix");
+	makeHMatrix_fnptr(h_matrix, xmodel, nmodel_points, nparams, nregression_fns, makeHVector);
+}

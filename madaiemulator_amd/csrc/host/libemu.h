@@ -121,6 +121,16 @@ void makeKVector_fnptr(gsl_vector *kvector, gsl_matrix *xmodel, gsl_vector *xnew
                        int nthetas, int nparams,
                        double (*covariance_fn_ptr)(gsl_vector *, gsl_vector *, gsl_vector *, int, int));
 
+/* the process-wide pointers of the reference's headers and the entry points that use them (set by set_global_ptrs) */
+extern double (*covariance_fn)(gsl_vector *, gsl_vector *, gsl_vector *, int, int);
+extern void (*makeHVector)(gsl_vector *h_vector, gsl_vector *x_location, int nparams);
+extern void (*makeGradMatLength)(gsl_matrix *dCdTheta, gsl_matrix *xmodel, double thetaLength, int index, int nmodel_points,
+                                 int nparams);
+void makeCovMatrix(gsl_matrix *cov_matrix, gsl_matrix *xmodel, gsl_vector *thetas, int nmodel_points, int nthetas, int nparams);
+void makeKVector(gsl_vector *kvector, gsl_matrix *xmodel, gsl_vector *xnew, gsl_vector *thetas, int nmodel_points, int nthetas,
+                 int nparams);
+void makeHMatrix(gsl_matrix *h_matrix, gsl_matrix *xmodel, int nmodel_points, int nparams, int nregression_fns);
+
 /* ---- libEmu/regression.h ------------------------------------------------ */
 void makeHVector_trivial(gsl_vector *h_vector, gsl_vector *x_location, int nparams);
 void makeHVector_linear(gsl_vector *h_vector, gsl_vector *x_location, int nparams);

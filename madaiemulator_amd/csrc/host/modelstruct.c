@@ -51,6 +51,10 @@ void set_global_ptrs(modelstruct *model)
 		model->covariance_fn = &covariance_fn_gaussian;
 		model->makeGradMatLength = &derivative_l_gauss;
 	}
+	/* the reference sets its process-wide pointers at the same place (modelstruct.c:222-262) */
+	covariance_fn = model->covariance_fn;
+	makeHVector = model->makeHVector;
+	makeGradMatLength = model->makeGradMatLength;
 }
 
 /* optstruct.c:142-250 */

@@ -123,11 +123,11 @@ int main(int argc, char **argv)
 		gsl_matrix *q = read_queries(argv[5], d);
 		for (int i = 0; i < nthetas; i++) gsl_vector_set(model->thetas, i, atof(argv[6 + i]));
 		gsl_matrix *c = gsl_matrix_alloc(N, N), *cinv = gsl_matrix_alloc(N, N), *H = gsl_matrix_alloc(N, nreg);
-		makeCovMatrix_fnptr(c, model->xmodel, model->thetas, N, nthetas, d, model->covariance_fn);
+		makeCovMatrix(c, model->xmodel, model->thetas, N, nthetas, d);      /* global-pointer twin (emulator.c:607) */
 		double det = 0.0;
 		chol_inverse_cov_matrix(model->options, c, cinv, &det);
 		printf("logdet %.17g\n", log(det));
-		makeHMatrix_fnptr(H, model->xmodel, N, d, nreg, model->makeHVector);
+		makeHMatrix(H, model->xmodel, N, d, nreg);                            /* regression.c:77 */
 		gsl_vector *beta = gsl_vector_alloc(nreg);
 		estimateBeta(beta, H, cinv, model->training_vector, N, nreg);
 		printf("beta");
@@ -142,9 +142,9 @@ int main(int argc, char **argv)
 		gsl_vector *k = gsl_vector_alloc(N), *h = gsl_vector_alloc(nreg), *pt = gsl_vector_alloc(d);
 		for (size_t i = 0; i < q->size1; i++) {
 			for (int kk = 0; kk < d; kk++) gsl_vector_set(pt, kk, gsl_matrix_get(q, i, kk));
-			makeKVector_fnptr(k, model->xmodel, pt, model->thetas, N, nthetas, d, model->covariance_fn);
-			model->makeHVector(h, pt, d);
-			const double kappa = model->covariance_fn(pt, pt, model->thetas, nthetas, d);
+			makeKVector(k, model->xmodel, pt, model->thetas, N, nthetas, d);    /* emulator.c:548 */
+			makeHVector(h, pt, d);
+			const double kappa = covariance_fn(pt, pt, model->thetas, nthetas, d);
 			const double m = makeEmulatedMean(cinv, model->training_vector, k, h, H, beta, N);
 			const double v = makeEmulatedVariance(cinv, k, h, H, kappa, N, nreg);
 			printf("pred %.17g %.17g\n", m, v);

@@ -60,7 +60,8 @@ def test_host_library_exports_reference_symbols():
                  "alloc_multimodelstruct", "gen_pca_decomp", "dump_multi_modelstruct", "load_multi_modelstruct",
                  "alloc_multi_emulator", "emulate_point_multi", "emulate_point_multi_pca", "estimate_multi",
                  "chol_inverse_cov_matrix", "estimateBeta", "estimateSigma", "getLogLikelyhood", "makeEmulatedMean",
-                 "makeEmulatedVariance", "callEvalLhoodList", "evalFnMultiList", "emulate_points"):
+                 "makeEmulatedVariance", "callEvalLhoodList", "evalFnMultiList", "emulate_points", "makeCovMatrix",
+                 "makeKVector", "makeHMatrix", "covariance_fn", "makeHVector", "makeGradMatLength"):
         assert hasattr(lib, name), name
 
 
