@@ -151,6 +151,9 @@ int gpemu_chol_inverse(gpemu_ctx *ctx, int n, double *a_inout, int lda, double *
  * out[v*n + i] = sum_j a[i*lda + j] * v_rows[v*n + j] for nvec vectors stored as rows.  The matrix is uploaded when
  * its (pointer, size, fingerprint) differs from the copy the context holds. */
 int gpemu_symm_apply(gpemu_ctx *ctx, int n, const double *a, int lda, int nvec, const double *v_rows, double *out_rows);
+/* getGradientCn's trace(C^-1 dC/dtheta) (libEmu/maxmultimin.c:583-588): sum_ij a[i][j] b[j][i] of two host matrices,
+ * one pass over both instead of the reference's N^3 dgemm */
+int gpemu_trace_product(gpemu_ctx *ctx, int n, const double *a, int lda, const double *b, int ldb, double *trace);
 
 /* ---- device memory helpers for callers that keep data resident ------ */
 int gpemu_dev_alloc(gpemu_ctx *ctx, size_t bytes, void **dptr);

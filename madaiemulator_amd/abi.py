@@ -47,6 +47,7 @@ SYMBOLS = {
     "gpemu_predict_batch_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpemu_chol_inverse": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, _dp, _ip]),
     "gpemu_symm_apply": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp]),
+    "gpemu_trace_product": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp]),
     "gpemu_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "gpemu_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gpemu_dev_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -264,6 +265,12 @@ class Context:
         out = np.empty_like(V)
         self._chk(self.L.gpemu_symm_apply(self.h, A.shape[0], _p(A), A.shape[1], V.shape[0], _p(V), _p(out)))
         return out
+
+    def trace_product(self, A, B):
+        A, B = _a(A), _a(B)
+        t = C.c_double(np.nan)
+        self._chk(self.L.gpemu_trace_product(self.h, A.shape[0], _p(A), A.shape[1], _p(B), B.shape[1], C.byref(t)))
+        return t.value
 
     def cinverse(self):
         out = np.empty((self.N, self.N))

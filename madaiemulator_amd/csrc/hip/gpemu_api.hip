@@ -1369,6 +1369,34 @@ extern "C" int gpemu_symm_apply(gpemu_ctx *ctx, int n, const double *a, int lda,
 	return GPEMU_OK;
 }
 
+// trace(A B) = sum_ij A[i][j] B[j][i] of two host-resident n x n matrices (row strides lda, ldb): getGradientCn's
+// trace(C^-1 dC/dtheta) (libEmu/maxmultimin.c:583-588) as one pass over the two matrices instead of an N^3 dgemm.
+// A goes through the same cache as gpemu_symm_apply (it is the C^-1 of the surrounding calls).
+extern "C" int gpemu_trace_product(gpemu_ctx *ctx, int n, const double *a, int lda, const double *b, int ldb, double *trace)
+{
+	if (!ctx || n < 1 || !a || !b || lda < n || ldb < n || !trace) return GPEMU_ERR_ARG;
+	std::vector<double> one((size_t)n, 0.0), tmp((size_t)n);
+	int rc = gpemu_symm_apply(ctx, n, a, lda, 1, one.data(), tmp.data());      // makes sure a is resident in dSym
+	if (rc) return rc;
+	const int Npad = ctx->sym_pad;
+	double *dB = nullptr, *dPart = nullptr;
+	HIPCHK(ctx, hipMalloc(&dB, (size_t)Npad * Npad * sizeof(double)));
+	hipError_t e = hipMalloc(&dPart, (size_t)n * sizeof(double));
+	if (e == hipSuccess)
+		e = hipMemcpy2DAsync(dB, (size_t)Npad * sizeof(double), b, (size_t)ldb * sizeof(double), (size_t)n * sizeof(double), n,
+		                     hipMemcpyHostToDevice, ctx->stream);
+	if (e == hipSuccess) e = launch_trace_product(ctx->stream, ctx->dSym, dB, Npad, n, dPart);
+	if (e == hipSuccess) e = hipMemcpyAsync(tmp.data(), dPart, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	hipFree(dB);
+	if (dPart) hipFree(dPart);
+	HIPCHK(ctx, e);
+	double t = 0.0;
+	for (int i = 0; i < n; i++) t += tmp[i];
+	*trace = t;
+	return GPEMU_OK;
+}
+
 // ---------------------------------------------------------------------------
 // building blocks exported for the parity tests
 // ---------------------------------------------------------------------------

@@ -419,4 +419,28 @@ hipError_t launch_grad_partials(hipStream_t s, const double *S, long lds_, int s
 	return hipGetLastError();
 }
 
+
+
+// sum_ij A[i][j] * B[j][i] over an n x n pair (row stride ld): per-workgroup partial sums in a fixed order,
+// part[blockIdx.x]; getGradientCn's trace(C^-1 dC) (maxmultimin.c:583-588) without forming the product
+__global__ __launch_bounds__(256) void trace_product_kernel(const double *A, const double *B, long ld, int n, double *part)
+{
+	__shared__ double red[256];
+	const int i = blockIdx.x;                       // one row of A (column of B) per workgroup
+	double s = 0.0;
+	for (int j = threadIdx.x; j < n; j += 256) s += A[(long)i * ld + j] * B[(long)j * ld + i];
+	red[threadIdx.x] = s;
+	__syncthreads();
+	for (int st = 128; st > 0; st >>= 1) {
+		if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) part[i] = red[0];
+}
+
+hipError_t launch_trace_product(hipStream_t s, const double *A, const double *B, long ld, int n, double *part)
+{
+	hipLaunchKernelGGL(trace_product_kernel, dim3(n), dim3(256), 0, s, A, B, ld, n, part);
+	return hipGetLastError();
+}
 } // namespace gpemu

@@ -151,6 +151,7 @@ double makeEmulatedMean(gsl_matrix *inverse_cov_matrix, gsl_vector *training_vec
                         gsl_vector *h_vector, gsl_matrix *h_matrix, gsl_vector *beta_vector, int nmodel_points);
 double makeEmulatedVariance(gsl_matrix *inverse_cov_matrix, gsl_vector *kplus_vector, gsl_vector *h_vector,
                             gsl_matrix *h_matrix, double kappa, int nmodel_points, int nregression_fns);
+double getGradientCn(gsl_matrix *dCdtheta, gsl_matrix *cinverse, gsl_vector *training_vector, int nmodel_points, int nthetas);
 
 /* ---- libEmu/maxmultimin.h ------------------------------------------------ */
 double evalFnMulti(const gsl_vector *theta_vec_less_amp, void *params_in);
@@ -184,6 +185,10 @@ void setup_optimization_ranges(optstruct *options, modelstruct *the_model);
 emulator_struct *alloc_emulator_struct(modelstruct *model);
 void free_emulator_struct(emulator_struct *e);
 void emulate_point(emulator_struct *e, gsl_vector *point, double *mean, double *variance);
+void makeHMatrix_es(gsl_matrix *h_matrix, emulator_struct *e);
+void makeCovMatrix_es(gsl_matrix *cov_matrix, emulator_struct *e);
+void makeKVector_es(gsl_vector *kvector, gsl_vector *point, emulator_struct *e);
+void estimateBeta_es(gsl_vector *beta_vector, emulator_struct *e);
 /* extension: npoints query rows (npoints x nparams), mean/variance arrays of npoints */
 void emulate_points(emulator_struct *e, gsl_matrix *points, double *mean, double *variance);
 /* emulate_points in two halves (device work runs in between): used to query all PCA components at the same time */

@@ -8,6 +8,8 @@
  *   getLogLikelyhood          libEmu/estimator-fns.c:38-103
  *   makeEmulatedMean          libEmu/emulator.c:672-704
  *   makeEmulatedVariance      libEmu/emulator.c:720-785
+ *   getGradientCn             libEmu/maxmultimin.c:571-608
+ *   make*_es, estimateBeta_es emulator_struct.c:63-118
  *
  * The O(N^3) factorisation and every C^-1-times-vector product run on the device (gpemu_chol_inverse,
  * gpemu_symm_apply: the matrix is uploaded once per pointer/content and cached in the thread's scratch context);
@@ -217,4 +219,43 @@ double makeEmulatedVariance(gsl_matrix *inverse_cov_matrix, gsl_vector *kplus_ve
 	}
 	free(W); free(A); free(q);
 	return kappa - kck + reg;
+}
+
+/* maxmultimin.c:571-608: -1/2 trace(C^-1 dC) + 1/2 y^T C^-1 dC C^-1 y */
+double getGradientCn(gsl_matrix *dCdtheta, gsl_matrix *cinverse, gsl_vector *training_vector, int nmodel_points, int nthetas)
+{
+	(void)nthetas;
+	const int N = nmodel_points;
+	gpemu_ctx *ctx = gpemu_host_scratch_ctx("getGradientCn");
+	double trace = 0.0;
+	int rc = gpemu_trace_product(ctx, N, cinverse->data, (int)cinverse->tda, dCdtheta->data, (int)dCdtheta->tda, &trace);
+	if (rc) die_ll(ctx, rc, "getGradientCn");
+	double *alpha = apply_cinv(cinverse, training_vector, NULL, N, 0, "getGradientCn");          /* C^-1 y */
+	double *w = (double *)malloc(sizeof(double) * (size_t)N);
+	rc = gpemu_symm_apply(ctx, N, dCdtheta->data, (int)dCdtheta->tda, 1, alpha, w);                /* dC alpha */
+	if (rc) die_ll(ctx, rc, "getGradientCn");
+	double quad = 0.0;
+	for (int i = 0; i < N; i++) quad += alpha[i] * w[i];
+	free(alpha); free(w);
+	return -0.5 * trace + 0.5 * quad;
+}
+
+/* emulator_struct.c:63-118: the same functions on the emulator_struct's own model pointers */
+void makeHMatrix_es(gsl_matrix *h_matrix, emulator_struct *e)
+{
+	makeHMatrix_fnptr(h_matrix, e->model->xmodel, e->nmodel_points, e->nparams, e->nregression_fns, e->model->makeHVector);
+}
+void makeCovMatrix_es(gsl_matrix *cov_matrix, emulator_struct *e)
+{
+	makeCovMatrix_fnptr(cov_matrix, e->model->xmodel, e->model->thetas, e->nmodel_points, e->nthetas, e->nparams,
+	                    e->model->covariance_fn);
+}
+void makeKVector_es(gsl_vector *kvector, gsl_vector *point, emulator_struct *e)
+{
+	makeKVector_fnptr(kvector, e->model->xmodel, point, e->model->thetas, e->nmodel_points, e->nthetas, e->nparams,
+	                  e->model->covariance_fn);
+}
+void estimateBeta_es(gsl_vector *beta_vector, emulator_struct *e)
+{
+	estimateBeta(beta_vector, e->h_matrix, e->cinverse, e->model->training_vector, e->nmodel_points, e->nregression_fns);
 }

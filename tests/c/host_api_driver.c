@@ -139,6 +139,13 @@ int main(int argc, char **argv)
 		memset(&params, 0, sizeof params);
 		params.options = model->options; params.the_model = model; params.h_matrix = H;
 		printf("sigma2 %.17g\n", estimateSigma(cinv, &params));
+		{
+			/* getGradientCn with dC := C itself: -1/2 trace(C^-1 C) + 1/2 y^T C^-1 C C^-1 y = -N/2 + 1/2 y^T C^-1 y */
+			gsl_matrix *c2 = gsl_matrix_alloc(N, N);
+			makeCovMatrix(c2, model->xmodel, model->thetas, N, nthetas, d);
+			printf("gradcn %.17g\n", getGradientCn(c2, cinv, model->training_vector, N, nthetas));
+			gsl_matrix_free(c2);
+		}
 		gsl_vector *k = gsl_vector_alloc(N), *h = gsl_vector_alloc(nreg), *pt = gsl_vector_alloc(d);
 		for (size_t i = 0; i < q->size1; i++) {
 			for (int kk = 0; kk < d; kk++) gsl_vector_set(pt, kk, gsl_matrix_get(q, i, kk));
@@ -158,6 +165,20 @@ int main(int argc, char **argv)
 		printf("\n");
 		printf("cinverse00 %.17g %.17g\n", gsl_matrix_get(e->cinverse, 0, 0),
 		       gsl_matrix_get(e->cinverse, e->nmodel_points - 1, 0));
+		{
+			/* the emulator_struct.c:63-118 wrappers */
+			gsl_vector *b2 = gsl_vector_alloc(e->nregression_fns), *kv = gsl_vector_alloc(e->nmodel_points);
+			gsl_vector_view q0 = gsl_matrix_row(q, 0);
+			estimateBeta_es(b2, e);
+			printf("beta_es");
+			for (int a = 0; a < e->nregression_fns; a++) printf(" %.17g", gsl_vector_get(b2, a));
+			printf("\n");
+			makeKVector_es(kv, &q0.vector, e);
+			printf("kvec_es %.17g %.17g\n", gsl_vector_get(kv, 0), gsl_vector_get(kv, e->nmodel_points - 1));
+			gsl_matrix *hm = gsl_matrix_alloc(e->nmodel_points, e->nregression_fns);
+			makeHMatrix_es(hm, e);
+			printf("hmat_es %.17g\n", gsl_matrix_get(hm, e->nmodel_points - 1, e->nregression_fns - 1));
+		}
 		gsl_vector *pt = gsl_vector_alloc(x->size2);
 		for (size_t i = 0; i < q->size1; i++) {
 			double m, v;

@@ -61,7 +61,8 @@ def test_host_library_exports_reference_symbols():
                  "alloc_multi_emulator", "emulate_point_multi", "emulate_point_multi_pca", "estimate_multi",
                  "chol_inverse_cov_matrix", "estimateBeta", "estimateSigma", "getLogLikelyhood", "makeEmulatedMean",
                  "makeEmulatedVariance", "callEvalLhoodList", "evalFnMultiList", "emulate_points", "makeCovMatrix",
-                 "makeKVector", "makeHMatrix", "covariance_fn", "makeHVector", "makeGradMatLength"):
+                 "makeKVector", "makeHMatrix", "covariance_fn", "makeHVector", "makeGradMatLength", "getGradientCn",
+                 "makeHMatrix_es", "makeCovMatrix_es", "makeKVector_es", "estimateBeta_es"):
         assert hasattr(lib, name), name
 
 
@@ -147,6 +148,10 @@ def test_emulator_struct_and_emulate_point(driver, tmp_path, cov, order):
     assert np.max(np.abs(pred[:, 1] - v)) <= RTOL * kappa
     assert np.array_equal(pred, batch)                      # one point at a time == one batch
     assert res["cinverse00"][0][0] == pytest.approx(e.cinverse[0, 0], rel=RTOL)
+    assert np.allclose(res["beta_es"][0], e.beta, rtol=RTOL)                # emulator_struct.c:63-118 wrappers
+    k0 = O.kvector(cov, X, Q[0], th)
+    assert res["kvec_es"][0] == pytest.approx([k0[0], k0[-1]], rel=1e-12, abs=1e-300)
+    assert res["hmat_es"][0][0] == pytest.approx(e.H[-1, -1], rel=1e-15)
 
 
 @pytest.mark.gpu
@@ -168,6 +173,7 @@ def test_lowlevel_host_matrix_interface(driver, tmp_path, cov, order):
     assert np.allclose(res["beta"][0], e.beta, rtol=RTOL)
     assert res["loglik"][0][0] == pytest.approx(-0.5 * e.logdet - len(y) / 2.0 * 1.83788 - 0.5 * quad, rel=RTOL)
     assert res["sigma2"][0][0] == pytest.approx(y @ e.cinverse @ r / len(y), rel=RTOL)
+    assert res["gradcn"][0][0] == pytest.approx(-len(y) / 2.0 + 0.5 * (y @ e.cinverse @ y), rel=RTOL)
     m, v, _ = e.emulate(Q)
     pred = np.array(res["pred"])
     kappa = O.cov(cov, Q[0], Q[0], th)
