@@ -151,6 +151,9 @@ int gpemu_chol_inverse(gpemu_ctx *ctx, int n, double *a_inout, int lda, double *
  * out[v*n + i] = sum_j a[i*lda + j] * v_rows[v*n + j] for nvec vectors stored as rows.  The matrix is uploaded when
  * its (pointer, size, fingerprint) differs from the copy the context holds. */
 int gpemu_symm_apply(gpemu_ctx *ctx, int n, const double *a, int lda, int nvec, const double *v_rows, double *out_rows);
+/* a5 derivative_l_gauss (libEmu/emulator.c:173-209) written out: out[i*ldo + j] = exp(-0.5 e^{-2t} D^2 - 2t) D^2,
+ * D = xcol[i] - xcol[j] (the ONE design coordinate the reference's formula looks at), t = theta_len */
+int gpemu_derivative_gauss(gpemu_ctx *ctx, int n, const double *xcol, double theta_len, double *out, int ldo);
 /* getGradientCn's trace(C^-1 dC/dtheta) (libEmu/maxmultimin.c:583-588): sum_ij a[i][j] b[j][i] of two host matrices,
  * one pass over both instead of the reference's N^3 dgemm */
 int gpemu_trace_product(gpemu_ctx *ctx, int n, const double *a, int lda, const double *b, int ldb, double *trace);

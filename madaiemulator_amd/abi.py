@@ -47,6 +47,7 @@ SYMBOLS = {
     "gpemu_predict_batch_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpemu_chol_inverse": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, _dp, _ip]),
     "gpemu_symm_apply": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp]),
+    "gpemu_derivative_gauss": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_double, _dp, C.c_int]),
     "gpemu_trace_product": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp]),
     "gpemu_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "gpemu_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -264,6 +265,12 @@ class Context:
         A, V = _a(A), _a(V).reshape(-1, np.shape(A)[0])
         out = np.empty_like(V)
         self._chk(self.L.gpemu_symm_apply(self.h, A.shape[0], _p(A), A.shape[1], V.shape[0], _p(V), _p(out)))
+        return out
+
+    def derivative_gauss(self, xcol, theta_len):
+        xcol = _a(xcol)
+        out = np.empty((xcol.size, xcol.size))
+        self._chk(self.L.gpemu_derivative_gauss(self.h, xcol.size, _p(xcol), float(theta_len), _p(out), xcol.size))
         return out
 
     def trace_product(self, A, B):

@@ -1369,6 +1369,27 @@ extern "C" int gpemu_symm_apply(gpemu_ctx *ctx, int n, const double *a, int lda,
 	return GPEMU_OK;
 }
 
+// a5 derivative_l_gauss (libEmu/emulator.c:173-209) materialised into host memory: the N x N matrix of the literal
+// one-coordinate formula for the design column xcol[n] and the log length scale theta_len
+extern "C" int gpemu_derivative_gauss(gpemu_ctx *ctx, int n, const double *xcol, double theta_len, double *out, int ldo)
+{
+	if (!ctx || n < 1 || !xcol || !out || ldo < n) return GPEMU_ERR_ARG;
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	double *dx = nullptr, *dout = nullptr;
+	HIPCHK(ctx, hipMalloc(&dx, (size_t)n * sizeof(double)));
+	hipError_t e = hipMalloc(&dout, (size_t)n * n * sizeof(double));
+	if (e == hipSuccess) e = hipMemcpyAsync(dx, xcol, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+	if (e == hipSuccess) e = launch_deriv_gauss(ctx->stream, dout, n, dx, n, theta_len);
+	if (e == hipSuccess)
+		e = hipMemcpy2DAsync(out, (size_t)ldo * sizeof(double), dout, (size_t)n * sizeof(double), (size_t)n * sizeof(double), n,
+		                     hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	hipFree(dx);
+	if (dout) hipFree(dout);
+	HIPCHK(ctx, e);
+	return GPEMU_OK;
+}
+
 // trace(A B) = sum_ij A[i][j] B[j][i] of two host-resident n x n matrices (row strides lda, ldb): getGradientCn's
 // trace(C^-1 dC/dtheta) (libEmu/maxmultimin.c:583-588) as one pass over the two matrices instead of an N^3 dgemm.
 // A goes through the same cache as gpemu_symm_apply (it is the C^-1 of the surrounding calls).

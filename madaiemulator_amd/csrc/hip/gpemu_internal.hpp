@@ -157,6 +157,7 @@ hipError_t launch_predict_finish(hipStream_t s, const double *V, long ldv, int M
 hipError_t launch_grad_partials(hipStream_t s, const double *S, long lds, int soff, const double *X, int N, int d,
                                 const double *alpha, int kind, const double *gp /* d+2 scalars */, double *part, int *nparts);
 
+hipError_t launch_deriv_gauss(hipStream_t s, double *out, long ld, const double *xcol, int n, double theta_len);
 hipError_t launch_trace_product(hipStream_t s, const double *A, const double *B, long ld, int n, double *part);
 
 // ---- kernels_linalg.hip

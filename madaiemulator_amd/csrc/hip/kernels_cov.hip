@@ -443,4 +443,25 @@ hipError_t launch_trace_product(hipStream_t s, const double *A, const double *B,
 	hipLaunchKernelGGL(trace_product_kernel, dim3(n), dim3(256), 0, s, A, B, ld, n, part);
 	return hipGetLastError();
 }
+// derivative_l_gauss materialised (libEmu/emulator.c:173-209): out[i][j] = exp(-0.5 e^{-2t} D^2 - 2t) D^2 with
+// D = x_i - x_j in ONE coordinate (the column passed in) -- the literal formula, other coordinates ignored
+__global__ __launch_bounds__(256) void deriv_gauss_kernel(double *out, long ld, const double *xcol, int n, double theta_len)
+{
+	const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+	const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
+	if (j >= n) return;
+	const double xj = xcol[j], e2 = exp(-2.0 * theta_len);
+	for (int t = 0; t < 16; t++) {
+		const int i = i0 + 4 * t;
+		if (i >= n) break;
+		const double r = xcol[i] - xj;
+		out[(long)i * ld + j] = exp(-0.5 * e2 * r * r - 2 * theta_len) * r * r;
+	}
+}
+
+hipError_t launch_deriv_gauss(hipStream_t s, double *out, long ld, const double *xcol, int n, double theta_len)
+{
+	hipLaunchKernelGGL(deriv_gauss_kernel, dim3((n + 63) / 64, (n + 63) / 64), dim3(256), 0, s, out, ld, xcol, n, theta_len);
+	return hipGetLastError();
+}
 } // namespace gpemu

@@ -73,12 +73,24 @@ double covariance_fn_matern_five(gsl_vector *xm, gsl_vector *xn, gsl_vector *the
 
 static void derivative_token(const char *name)
 {
-	fprintf(stderr, "%s: dC/dtheta matrices are not materialised by this library; gradFnMulti computes the\n"
-	                "gradient on the GPU (gpemu_grad).  This symbol only identifies the covariance function.\n", name);
+	fprintf(stderr, "%s: the reference's Matern derivative matrices carry an accumulator from element to element\n"
+	                "(emulator.c:410-425, 506-523) and cannot be produced in parallel; this symbol only identifies the\n"
+	                "covariance function.\n", name);
 	exit(EXIT_FAILURE);
 }
-void derivative_l_gauss(gsl_matrix *a, gsl_matrix *b, double c, int d, int e, int f)
-{ (void)a; (void)b; (void)c; (void)d; (void)e; (void)f; derivative_token("derivative_l_gauss"); }
+/* libEmu/emulator.c:173-209, materialised on the device (gradFnMulti itself never forms it) */
+extern gpemu_ctx *gpemu_host_scratch_ctx(const char *where);
+void derivative_l_gauss(gsl_matrix *dCdTheta, gsl_matrix *xmodel, double thetaLength, int index, int nmodel_points, int nparams)
+{
+	(void)nparams;
+	const int N = nmodel_points, col = index - 2;         /* nthetasConstant = 2 (:178-179) */
+	double *xc = (double *)malloc(sizeof(double) * (size_t)N);
+	for (int i = 0; i < N; i++) xc[i] = gsl_matrix_get(xmodel, i, col);
+	gpemu_ctx *ctx = gpemu_host_scratch_ctx("derivative_l_gauss");
+	int rc = gpemu_derivative_gauss(ctx, N, xc, thetaLength, dCdTheta->data, (int)dCdTheta->tda);
+	free(xc);
+	if (rc) { fprintf(stderr, "derivative_l_gauss: gpemu error %d: %s\n", rc, gpemu_last_error(ctx)); exit(EXIT_FAILURE); }
+}
 void derivative_l_matern_three(gsl_matrix *a, gsl_matrix *b, double c, int d, int e, int f)
 { (void)a; (void)b; (void)c; (void)d; (void)e; (void)f; derivative_token("derivative_l_matern_three"); }
 void derivative_l_matern_five(gsl_matrix *a, gsl_matrix *b, double c, int d, int e, int f)

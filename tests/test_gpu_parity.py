@@ -301,6 +301,19 @@ def test_grad_vs_oracle(gpu_ctx, N, d, order):
     assert np.allclose(g, ref, rtol=1e-7, atol=1e-7 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("N,d,index,tl", [(130, 3, 2, -0.4), (257, 3, 4, -1.3), (64, 1, 2, 0.7)])
+def test_derivative_l_gauss_materialised(gpu_ctx, N, d, index, tl):
+    """a5 written out (emulator.c:173-209): the literal one-coordinate derivative matrix against the oracle, and
+    getGradientCn's trace through gpemu_trace_product on it"""
+    X, y = synth.design(N, d, 300 + N)
+    got = gpu_ctx.derivative_gauss(X[:, index - 2], tl)
+    ref = O.derivative_l(1, X, tl, index)
+    assert relerr(got, ref) < 1e-13
+    th = thetas_for(1, d)
+    Cinv = np.linalg.inv(O.cov_matrix(1, X, th))
+    assert gpu_ctx.trace_product(Cinv, ref) == pytest.approx(np.sum(Cinv * ref.T), rel=1e-11)
+
+
 def test_grad_golden(gpu_ctx, ref_inputs, golden):
     X, y = ref_inputs["uni"]
     gpu_ctx.set_model(1, 1, X, y)
