@@ -216,6 +216,14 @@ void emulate_points_multi(multi_emulator *emu, gsl_matrix *points, int pca_space
 void callEvalLhoodList(double *xmodel_in, int *nparams_in, double *pointList_in, int *nevalPoints_in,
                        double *training_in, int *nmodelPoints_in, int *nthetas_in, double *answer,
                        int *cov_fn_index_in, int *regression_order_in);
+void callEstimate(double *xmodel_in, int *nparams_in, double *training_in, int *nmodelpts, int *nthetas_in, double *final_thetas,
+                  int *use_fixed_nugget, double *fixed_nugget_in, int *cov_fn_index_in, int *regression_order_in);
+void callEmulateAtList(double *xmodel_in, int *nparams_in, double *points_in, int *nemupoints, double *training_in,
+                       int *nmodelpts, double *thetas_in, int *nthetas_in, double *final_emulated_y,
+                       double *final_emulated_variance, int *cov_fn_index_in, int *regression_order_in);
+void callEmulateAtPt(double *xmodel_in, int *nparams_in, double *point_in, double *training_in, int *nmodelpts,
+                     double *thetas_in, int *nthetas_in, double *final_emulated_y, double *final_emulated_variance,
+                     int *cov_fn_index_in, int *regression_order_in);
 
 /* ---- knobs of this implementation (not in the reference) ------------------------ */
 void gpemu_host_set_device(int device);          /* HIP device used by contexts created from this thread on */

@@ -62,7 +62,8 @@ def test_host_library_exports_reference_symbols():
                  "chol_inverse_cov_matrix", "estimateBeta", "estimateSigma", "getLogLikelyhood", "makeEmulatedMean",
                  "makeEmulatedVariance", "callEvalLhoodList", "evalFnMultiList", "emulate_points", "makeCovMatrix",
                  "makeKVector", "makeHMatrix", "covariance_fn", "makeHVector", "makeGradMatLength", "getGradientCn",
-                 "makeHMatrix_es", "makeCovMatrix_es", "makeKVector_es", "estimateBeta_es"):
+                 "makeHMatrix_es", "makeCovMatrix_es", "makeKVector_es", "estimateBeta_es", "callEstimate",
+                 "callEmulateAtList", "callEmulateAtPt", "derivative_l_gauss"):
         assert hasattr(lib, name), name
 
 
@@ -312,6 +313,30 @@ def test_call_eval_lhood_list_without_r():
     os.environ.pop("GPEMU_HOST_BATCH")
     for r, a in zip(rows, ans):
         assert a == pytest.approx(O.eval_fn_multi(1, 1, X, y, r[:nthetas - 1])["value"], rel=RTOL)
+    # callEmulateAtList / callEmulateAtPt (rbind.c:121,214): mean and variance at given thetas, points column-major
+    th = np.array([-0.2, -3.5, -1.0, -0.7])
+    Q = synth.queries(9, d, 4)
+    qin = np.asfortranarray(Q).ravel(order="F").copy()
+    m, v = np.zeros(len(Q)), np.zeros(len(Q))
+    lib.callEmulateAtList(xin.ctypes.data_as(dp), ip(d), qin.ctypes.data_as(dp), ip(len(Q)), y.ctypes.data_as(dp), ip(N),
+                          th.ctypes.data_as(dp), ip(nthetas), m.ctypes.data_as(dp), v.ctypes.data_as(dp), ip(1), ip(1))
+    e = O.Emulator(1, 1, X, y, th)
+    mo, vo, _ = e.emulate(Q)
+    kappa = O.cov(1, Q[0], Q[0], th)
+    assert np.max(np.abs(m - mo)) <= RTOL * max(1.0, np.abs(mo).max()) and np.max(np.abs(v - vo)) <= RTOL * kappa
+    m1, v1 = np.zeros(1), np.zeros(1)
+    q0 = Q[0].copy()
+    lib.callEmulateAtPt(xin.ctypes.data_as(dp), ip(d), q0.ctypes.data_as(dp), y.ctypes.data_as(dp), ip(N),
+                        th.ctypes.data_as(dp), ip(nthetas), m1.ctypes.data_as(dp), v1.ctypes.data_as(dp), ip(1), ip(1))
+    assert m1[0] == pytest.approx(mo[0], rel=1e-8, abs=1e-10) and v1[0] == pytest.approx(vo[0], abs=RTOL * kappa)
+    # callEstimate (rbind.c:35): trained thetas come back finite and beat the start of the search box
+    os.environ.update(GPEMU_SEED="7", GPEMU_RESTARTS="4")
+    final = np.zeros(nthetas)
+    lib.callEstimate(xin.ctypes.data_as(dp), ip(d), y.ctypes.data_as(dp), ip(N), ip(nthetas), final.ctypes.data_as(dp),
+                     ip(0), C.byref(C.c_double(0.0)), ip(1), ip(1))
+    assert np.all(np.isfinite(final))
+    best = O.eval_fn_multi(1, 1, X, y, final[1:])["value"]
+    assert np.isfinite(best) and best < O.eval_fn_multi(1, 1, X, y, np.array([-3.0, -1.0, -0.7]))["value"]
 
 
 @pytest.mark.gpu
