@@ -258,7 +258,7 @@ def main():
         # HBM bytes per launch from the PMC passes committed under profiles/ (separate rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE runs of the same evaluation; FETCH_SIZE is the raw counter, see the .txt next to it)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_v5_final.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_v6_tile_table.json")
         if args.workload == "c3" and B == 16 and os.path.exists(tpath):      # measured for batches of 16
             tj = json.load(open(tpath))["gemm_nt_kernel"]
             traffic = (tj["fetch_bytes_raw"] + tj["write_bytes"]) / tj["launches"]

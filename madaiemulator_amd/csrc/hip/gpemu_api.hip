@@ -128,6 +128,7 @@ static void read_environment()
 	int v = 0;
 	if (geti("GPEMU_GEMM_BIG_TILES", &v) && v > 0) gpemu::g_gemm_big_tiles = v;
 	geti("GPEMU_GEMM_BIG_CFG", &gpemu::g_gemm_big_cfg);
+	geti("GPEMU_GEMM_TABLE", &gpemu::g_gemm_table);
 	if (geti("GPEMU_LOOKAHEAD", &v)) g_lookahead = v != 0;
 	if (geti("GPEMU_LEAF128", &v)) g_leaf128 = v != 0;
 	if (geti("GPEMU_NB_TOP", &v) && v >= LEAF) g_nb_top = (v / LEAF) * LEAF;
@@ -195,6 +196,7 @@ static void free_graphs(gpemu_ctx *ctx)
 {
 	for (auto &kv : ctx->graphs) hipGraphExecDestroy(kv.second);
 	ctx->graphs.clear();
+	ctx->warm.clear();
 }
 
 static void free_model(gpemu_ctx *ctx)
@@ -517,6 +519,13 @@ static int run_potrf(gpemu_ctx *ctx, int inv)
 	}
 	gpemu_ctx::GraphKey key{ctx->Np, ctx->Rp, inv, ctx->nb};
 	auto it = ctx->graphs.find(key);
+	if (it == ctx->graphs.end() && ctx->warm.insert(key).second) {
+		// first factorisation of this shape: plain launches (host-side tables of the GEMM tile order are built
+		// on first use and cannot be allocated under stream capture); the next call records the graph
+		ctx->trace_next = 0; ctx->trace_tag.clear();
+		HIPCHK(ctx, potrf_rec(ctx, 0, ctx->Np, inv));
+		return GPEMU_OK;
+	}
 	if (it == ctx->graphs.end()) {
 		hipGraph_t graph = nullptr;
 		ctx->trace_next = 0; ctx->trace_tag.clear();

@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <set>
 
 #include "gpemu.h"
 
@@ -54,7 +55,8 @@ struct GemmArgs {
 	int nbatch;          // 0/1: single problem
 	int ksplit;          // > 1: grid.y = k-slices of ONE problem; slice s takes k in [k0 + s*klen, k0 + (s+1)*klen) and
 	                     // writes its partial product to C + s*bsC (beta = 0); the consumer sums the slices in order
-	int order_mode;      // 2: dense enumeration of the lower-triangular tiles (set by launch_gemm)
+	int order_mode;      // 2: dense enumeration of the lower-triangular tiles, 3: tile table (set by launch_gemm)
+	const int *tile_table; // order_mode 3: entry blockIdx.x = (tm << 16) | tn, or -1 for none
 	unsigned long long *trace;   // optional {first start, last end} device timestamps of this launch (GPEMU_TRACE)
 };
 
@@ -103,6 +105,7 @@ struct gpemu_ctx {
 		if (Np != o.Np) return Np < o.Np; if (aug_fixed != o.aug_fixed) return aug_fixed < o.aug_fixed;
 		if (inv != o.inv) return inv < o.inv; return nb < o.nb; } };
 	std::map<GraphKey, hipGraphExec_t> graphs;
+	std::set<GraphKey> warm;     // shapes factored once with plain launches (the graph is recorded on the second call)
 	bool use_graph = true;
 
 	// prediction state
@@ -164,7 +167,7 @@ hipError_t launch_trace_product(hipStream_t s, const double *A, const double *B,
 hipError_t launch_gemm(hipStream_t s, const GemmArgs &a);
 hipError_t launch_skinny_nt(hipStream_t s, const double *Kq, long ldk, const double *L, long ldl, double *Vp, long ldv,
                             long sstride, int tq, int ntot, int K, int ntri, int nslice, int klen);
-extern int g_gemm_big_tiles, g_gemm_big_cfg;
+extern int g_gemm_big_tiles, g_gemm_big_cfg, g_gemm_table;
 hipError_t launch_leaf(hipStream_t s, double *T, long ld, int c0, int m_below, int *info,
                        unsigned long long *trace_factor = nullptr, unsigned long long *trace_solve = nullptr,
                        int nbatch = 1, long bstride = 0);

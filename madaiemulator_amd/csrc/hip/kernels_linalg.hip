@@ -8,6 +8,9 @@
 // (libEmu/maxmultimin.c:325,361; libEmu/regression.c:128-171;
 // libEmu/estimator-fns.c:87-88) -- see DESIGN.md for the formulation.
 #include "gpemu_internal.hpp"
+#include <algorithm>
+#include <mutex>
+#include <tuple>
 
 namespace gpemu {
 
@@ -85,7 +88,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 	// tile column, so one XCD keeps re-using 1/8 of the A panels and every B panel; measured equal to grouped /
 	// XCD-chunked orders at these sizes (the operands sit in the 256 MB Infinity Cache).
 	int tm, tn;
-	if (g.order_mode == 2) {
+	if (g.order_mode == 3) {
+		// XCD-blocked order from a host-built table (gemm_tile_table below)
+		const int e = g.tile_table[blockIdx.x];
+		if (e < 0) return;
+		tm = e >> 16;
+		tn = e & 0xffff;
+	} else if (g.order_mode == 2) {
 		// dense enumeration of the lower-triangular tiles (square tiles, diag_off = 0, m >= n): block t -> column tn
 		// with P(tn) <= t < P(tn+1), P(j) = j*tiles_m - j(j-1)/2 tiles in the columns before j.  The plain 2-D
 		// enumeration launches the empty upper tiles too; they exit at once, but the dispatcher deals workgroups in
@@ -434,6 +443,7 @@ int g_gemm_force_cfg = -1;   // test/bench hook: 0 = 128x128, 1 = 128x64, 2 = 64
 // the big shape wins (less LDS/L2 traffic per flop: 60-62 vs 52 TF/s on the prediction GEMM); below that the
 // 64x64 shape is never slower (more workgroups for 256 CUs, 4 resident per CU) and up to 3x faster on the
 // narrow K<=256 updates of the factorisation.
+int g_gemm_table = 8;          // XCD-blocked tile order from a table for launches of >= 512 tiles: side of the super-blocks (GPEMU_GEMM_TABLE; 0: off)
 int g_gemm_big_cfg = 3;        // tile configuration of the big launches (3: 128x128 8 waves, 0: 128x128 4 waves)
 int g_gemm_big_tiles = 2048;   // 128x128 tiles (8 waves) once a launch has this many of them, else 64x64
 
@@ -443,6 +453,60 @@ int choose_gemm_cfg(const GemmArgs &a)
 	return count_tiles(a, 128, 128) * (a.nbatch > 1 ? a.nbatch : 1) >= g_gemm_big_tiles ? g_gemm_big_cfg : 2;
 }
 
+
+// ---------------------------------------------------------------------------
+// Tile order.  Workgroups are dealt round-robin to the 8 XCDs (ids b and b+8 share an XCD and its 4 MB L2).  In the
+// natural order the 64-128 tiles an XCD works on at a time lie in one tile column: one B panel, but a different A
+// panel each -- every tile fetches its own A panel from the fabric (PMC: 3.4 GB per evaluation against 1.2 GB
+// compulsory).  The table lists the valid tiles super-block by super-block (S x S tiles, S = g_gemm_table) and gives
+// XCD x the x-th eighth of that list, so that its concurrent tiles share S A and S B panels and all XCDs get equal
+// shares (unequal shares leave runs of idle slots at the tail: measured -6 %).  DESIGN.md section 7 has the numbers.
+// Tables are built on first use outside stream capture and cached per (device, shape).
+// ---------------------------------------------------------------------------
+struct TileTable { int *dptr; int len; };
+static std::map<std::tuple<int, int, int, int, int, int>, TileTable> g_tile_tables;
+static std::mutex g_tile_mutex;
+
+static TileTable gemm_tile_table(hipStream_t s, int tiles_m, int tiles_n, int tri, int reverse_n)
+{
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	const auto key = std::make_tuple(dev, tiles_m, tiles_n, tri, reverse_n, g_gemm_table);
+	std::lock_guard<std::mutex> lock(g_tile_mutex);
+	auto it = g_tile_tables.find(key);
+	if (it != g_tile_tables.end()) return it->second;
+	hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+	if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return TileTable{nullptr, 0};
+	const int S = g_gemm_table;
+	const int sbm = (tiles_m + S - 1) / S, sbn = (tiles_n + S - 1) / S;
+	// all valid tiles, super-block after super-block (column-major over the blocks and inside each)
+	std::vector<int> seq;
+	for (int bc = 0; bc < sbn; bc++)
+		for (int br = 0; br < sbm; br++)
+			for (int c = 0; c < S; c++)
+				for (int r = 0; r < S; r++) {
+					const int tm = br * S + r, tn0 = bc * S + c;
+					if (tm >= tiles_m || tn0 >= tiles_n || (tri && tn0 > tm)) continue;
+					const int tn = reverse_n ? tiles_n - 1 - tn0 : tn0;
+					seq.push_back((tm << 16) | tn);
+				}
+	// XCD x walks the x-th eighth of that sequence: equal shares (the tail slots of the shorter ones hold -1), and
+	// the tiles it has in flight lie in one or two super-blocks
+	const size_t L = seq.size(), maxlen = (L + 7) / 8;
+	std::vector<int> table(8 * maxlen, -1);
+	for (size_t x = 0; x < 8; x++) {
+		const size_t lo = x * L / 8, hi = (x + 1) * L / 8;
+		for (size_t q = lo; q < hi; q++) table[(q - lo) * 8 + x] = seq[q];
+	}
+	TileTable tt{nullptr, (int)table.size()};
+	if (hipMalloc(&tt.dptr, table.size() * sizeof(int)) != hipSuccess ||
+	    hipMemcpy(tt.dptr, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+		(void)hipGetLastError();
+		return TileTable{nullptr, 0};
+	}
+	g_tile_tables[key] = tt;
+	return tt;
+}
 
 hipError_t launch_gemm(hipStream_t s, const GemmArgs &a_in)
 {
@@ -459,8 +523,15 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs &a_in)
 	const bool dense_tri = a.tri && a.diag_off == 0 && a.m >= a.n && cfg != 1;
 	a.order_mode = dense_tri ? 2 : 0;
 	const int bt = (cfg == 2) ? 64 : 128;
-	const int T = dense_tri ? (int)count_tiles(a, bt, bt)
-	                        : ((a.m + bt - 1) / bt) * ((a.n + (cfg == 1 ? 63 : bt - 1)) / (cfg == 1 ? 64 : bt));
+	int T = dense_tri ? (int)count_tiles(a, bt, bt)
+	                  : ((a.m + bt - 1) / bt) * ((a.n + (cfg == 1 ? 63 : bt - 1)) / (cfg == 1 ? 64 : bt));
+	if (g_gemm_table && cfg != 1 && T >= 512 && (dense_tri || !a.tri) && !a.kstart_mode) {
+		const int tiles_m = (a.m + bt - 1) / bt, tiles_n = (a.n + bt - 1) / bt;
+		if (tiles_m < 32768 && tiles_n < 32768) {
+			const TileTable tt = gemm_tile_table(s, tiles_m, tiles_n, dense_tri ? 1 : 0, a.kend_mode ? 1 : 0);
+			if (tt.dptr) { a.order_mode = 3; a.tile_table = tt.dptr; T = tt.len; }
+		}
+	}
 	if (cfg == 0) {
 		hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 2>), dim3(T, nbatch), dim3(256), 0, s, a);
 	} else if (cfg == 1) {

@@ -8,7 +8,7 @@ nctx=int(sys.argv[1]) if len(sys.argv)>1 else 2
 cs=[abi.Context(0) for _ in range(nctx)]
 for c in cs: c.set_model(kind,order,X,y)
 for B in (8,16):
-    for c in cs: c.loglik_batch(ths[:B])
+    for c in cs: c.loglik_batch(ths[:B]); c.loglik_batch(ths[:B])
     K=max(2,48//B)
     t=time.perf_counter()
     for i in range(K):
