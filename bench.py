@@ -192,8 +192,8 @@ def main():
     want = args.batch if args.batch else int(min(64, max(16, 16 * (8192 / N) ** 2)))
     B = max(1, want)
     chunks = [list(range(j * B, (j + 1) * B)) for j in range(K)]       # step j = evaluations j*B .. (j+1)*B-1
-    for j in range(max(1, W)):                                          # W untimed warm-up steps per context at least
-        for c in ctxs:                                                  # (the first one captures the launch graph)
+    for j in range(max(2, W)):                                          # W untimed warm-up steps per context, two at least
+        for c in ctxs:                                                  # (plain launches first, then the graph is recorded)
             c.loglik_batch_enqueue(np.array([theta(100000 + 97 * j + i) for i in range(B)]))
     for c in ctxs:
         c.loglik_batch_collect()
