@@ -25,7 +25,9 @@ def thetas_for(kind, d, golden=None):
 
 
 # ------------------------------------------------------------------ building blocks
-@pytest.mark.parametrize("m,n,k", [(16, 16, 16), (128, 128, 16), (200, 72, 64), (129, 257, 48), (384, 256, 256)])
+# the last two shapes have >= 512 tiles: their tile order comes from the XCD-blocked table (kernels_linalg.hip, gemm_tile_table)
+@pytest.mark.parametrize("m,n,k", [(16, 16, 16), (128, 128, 16), (200, 72, 64), (129, 257, 48), (384, 256, 256),
+                                   (2048, 1600, 32), (2050, 1601, 16)])
 def test_gemm_nt_asymmetric(gpu_ctx, m, n, k):
     rng = np.random.default_rng(m * 7 + n)
     A, B, C0 = rng.standard_normal((m, k)), rng.standard_normal((n, k)), rng.standard_normal((m, n))
@@ -44,7 +46,8 @@ def test_gemm_identity_asymmetric_exact(gpu_ctx):
     assert np.array_equal(got, B.T)
 
 
-@pytest.mark.parametrize("n", [1, 5, 64, 65, 100, 128, 200, 512, 1000])
+# n = 4500: ragged, outer panels, triangular trailing updates of > 512 tiles (table order)
+@pytest.mark.parametrize("n", [1, 5, 64, 65, 100, 128, 200, 512, 1000, 4500])
 def test_potrf_matches_lapack(gpu_ctx, n):
     rng = np.random.default_rng(n)
     M = rng.standard_normal((n, n))
@@ -582,6 +585,27 @@ def test_chol_inverse_and_symm_apply_on_host_matrices(gpu_ctx, n):
     bad[n // 2, n // 2] = -1.0
     _, _, info, rc = gpu_ctx.chol_inverse(bad)
     assert rc == abi.ERR_NOT_PD and info == n // 2 + 1
+
+
+def test_tile_order_does_not_change_the_bits(monkeypatch):
+    """GPEMU_GEMM_TABLE only permutes which workgroup computes which tile: same sums in the same order per tile"""
+    import os
+    N, d = 4096, 8
+    X, y = synth.design(N, d, 3)
+    th = synth.default_thetas(3, d)
+    vals = []
+    for table in ("0", "8", "5"):
+        monkeypatch.setenv("GPEMU_GEMM_TABLE", table)      # read when a context is created
+        c = abi.Context(0)
+        c.set_model(3, 1, X, y)
+        r1 = c.loglik(th)                                   # plain launches
+        r2 = c.loglik(th)                                   # recorded graph
+        assert r1["value"] == r2["value"]
+        rb = c.loglik_batch(np.array([th, th]))
+        assert rb["value"][0] == rb["value"][1]
+        vals.append((r1["value"], r1["sigma2"], rb["value"][0]))
+        c.close()
+    assert vals[0] == vals[1] == vals[2]
 
 
 def test_model_switching_soak_is_deterministic():
