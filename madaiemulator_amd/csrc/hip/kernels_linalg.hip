@@ -464,14 +464,14 @@ int choose_gemm_cfg(const GemmArgs &a)
 // Tables are built on first use outside stream capture and cached per (device, shape).
 // ---------------------------------------------------------------------------
 struct TileTable { int *dptr; int len; };
-static std::map<std::tuple<int, int, int, int, int, int>, TileTable> g_tile_tables;
+static std::map<std::tuple<int, int, int, int, int>, TileTable> g_tile_tables;
 static std::mutex g_tile_mutex;
 
-static TileTable gemm_tile_table(hipStream_t s, int tiles_m, int tiles_n, int tri, int reverse_n)
+static TileTable gemm_tile_table(hipStream_t s, int tiles_m, int tiles_n, int tri)
 {
 	int dev = 0;
 	(void)hipGetDevice(&dev);
-	const auto key = std::make_tuple(dev, tiles_m, tiles_n, tri, reverse_n, g_gemm_table);
+	const auto key = std::make_tuple(dev, tiles_m, tiles_n, tri, g_gemm_table);
 	std::lock_guard<std::mutex> lock(g_tile_mutex);
 	auto it = g_tile_tables.find(key);
 	if (it != g_tile_tables.end()) return it->second;
@@ -485,9 +485,8 @@ static TileTable gemm_tile_table(hipStream_t s, int tiles_m, int tiles_n, int tr
 		for (int br = 0; br < sbm; br++)
 			for (int c = 0; c < S; c++)
 				for (int r = 0; r < S; r++) {
-					const int tm = br * S + r, tn0 = bc * S + c;
-					if (tm >= tiles_m || tn0 >= tiles_n || (tri && tn0 > tm)) continue;
-					const int tn = reverse_n ? tiles_n - 1 - tn0 : tn0;
+					const int tm = br * S + r, tn = bc * S + c;
+					if (tm >= tiles_m || tn >= tiles_n || (tri && tn > tm)) continue;
 					seq.push_back((tm << 16) | tn);
 				}
 	// XCD x walks the x-th eighth of that sequence: equal shares (the tail slots of the shorter ones hold -1), and
@@ -525,10 +524,12 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs &a_in)
 	const int bt = (cfg == 2) ? 64 : 128;
 	int T = dense_tri ? (int)count_tiles(a, bt, bt)
 	                  : ((a.m + bt - 1) / bt) * ((a.n + (cfg == 1 ? 63 : bt - 1)) / (cfg == 1 ? 64 : bt));
-	if (g_gemm_table && cfg != 1 && T >= 512 && (dense_tri || !a.tri) && !a.kstart_mode) {
+	// (not for the triangular-operand products of the prediction path: their K differs from tile column to tile column, so
+	// equal shares of tiles are unequal shares of work -- measured 2x slower -- and the long-K-first order matters more)
+	if (g_gemm_table && cfg != 1 && T >= 512 && (dense_tri || !a.tri) && !a.kstart_mode && !a.kend_mode) {
 		const int tiles_m = (a.m + bt - 1) / bt, tiles_n = (a.n + bt - 1) / bt;
 		if (tiles_m < 32768 && tiles_n < 32768) {
-			const TileTable tt = gemm_tile_table(s, tiles_m, tiles_n, dense_tri ? 1 : 0, a.kend_mode ? 1 : 0);
+			const TileTable tt = gemm_tile_table(s, tiles_m, tiles_n, dense_tri ? 1 : 0);
 			if (tt.dptr) { a.order_mode = 3; a.tile_table = tt.dptr; T = tt.len; }
 		}
 	}
