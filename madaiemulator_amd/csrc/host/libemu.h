@@ -224,6 +224,15 @@ void callEmulateAtList(double *xmodel_in, int *nparams_in, double *points_in, in
 void callEmulateAtPt(double *xmodel_in, int *nparams_in, double *point_in, double *training_in, int *nmodelpts,
                      double *thetas_in, int *nthetas_in, double *final_emulated_y, double *final_emulated_variance,
                      int *cov_fn_index_in, int *regression_order_in);
+/* one emulator (or nydims of them on one design) kept between calls -- rbind.c:299-600 */
+void setupEmulateMC(double *xmodel_in, int *nparams_in, double *training_in, int *nmodelpts, double *thetas_in, int *nthetas_in,
+                    int *cov_fn_index_in, int *regression_order_in);
+void callEmulateMC(double *point_in, double *mean_out, double *var_out);
+void freeEmulateMC(void);
+void setupEmulateMCMulti(double *xmodel_in, int *nparams_in, double *training_in, int *nydims_in, int *nmodelpts_in,
+                         double *thetas_in, int *nthetas_in, int *cov_fn_index_in, int *regression_order_in);
+void callEmulateMCMulti(double *point_in, int *nydims_in, double *final_mean, double *final_var);
+void freeEmulateMCMulti(int *nydims_in);
 
 /* ---- knobs of this implementation (not in the reference) ------------------------ */
 void gpemu_host_set_device(int device);          /* HIP device used by contexts created from this thread on */

@@ -5,10 +5,12 @@
  *   callEstimate       libRbind/rbind.c:35-98     estimate_thetas on flat arrays
  *   callEmulateAtList  libRbind/rbind.c:121-190   mean / variance at a list of points for given thetas
  *   callEmulateAtPt    libRbind/rbind.c:214-290   ... at one point
- * (setupEmulateMC / callEmulateMC keep a process-global emulator between calls and are not mirrored.)
+ *   setupEmulateMC / callEmulateMC / freeEmulateMC               rbind.c:299-460   one emulator kept between calls (MCMC)
+ *   setupEmulateMCMulti / callEmulateMCMulti / freeEmulateMCMulti rbind.c:483-600  nydims independent emulators of one design
  * The rows of pointList are independent evaluations of one model: they go through evalFnMultiList, i.e. through
  * lock-step batches of GPU factorisations (gpemu_loglik_batch).
  */
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "libemu.h"
@@ -109,4 +111,92 @@ void callEmulateAtPt(double *xmodel_in, int *nparams_in, double *point_in, doubl
 	int one = 1;
 	callEmulateAtList(xmodel_in, nparams_in, point_in, &one, training_in, nmodelpts, thetas_in, nthetas_in, final_emulated_y,
 	                  final_emulated_variance, cov_fn_index_in, regression_order_in);
+}
+
+/* ---- the emulator kept between calls (rbind.c:299-460).  The reference keeps C, C^-1, beta and H on the host and runs
+ * emulateQuick per call; here the factor stays in HBM behind an emulator_struct and a call is one emulate_point. ---- */
+struct emulateMCData { modelstruct *model; emulator_struct *emu; gsl_matrix *x; gsl_vector *y; };
+static struct emulateMCData emuMCData;
+static struct emulateMCData *emuMCDataMulti;
+
+static void mc_setup(struct emulateMCData *m, double *xmodel_in, int d, double *training_in, int N, const double *thetas,
+                     int nthetas_in, int cov_fn_index, int regression_order)
+{
+	m->model = flat_model(xmodel_in, d, training_in, N, cov_fn_index, regression_order, &m->x, &m->y);
+	const int n = nthetas_in < m->model->options->nthetas ? nthetas_in : m->model->options->nthetas;
+	for (int i = 0; i < n; i++) gsl_vector_set(m->model->thetas, i, thetas[i]);
+	m->emu = alloc_emulator_struct(m->model);
+}
+
+static void mc_free(struct emulateMCData *m)
+{
+	if (!m->model) return;
+	free_emulator_struct(m->emu);
+	free_flat_model(m->model, m->x, m->y);
+	memset(m, 0, sizeof *m);
+}
+
+void setupEmulateMC(double *xmodel_in, int *nparams_in, double *training_in, int *nmodelpts, double *thetas_in, int *nthetas_in,
+                    int *cov_fn_index_in, int *regression_order_in)
+{
+	mc_free(&emuMCData);
+	mc_setup(&emuMCData, xmodel_in, *nparams_in, training_in, *nmodelpts, thetas_in, *nthetas_in, *cov_fn_index_in,
+	         *regression_order_in);
+}
+
+void callEmulateMC(double *point_in, double *mean_out, double *var_out)
+{
+	if (!emuMCData.emu) { fprintf(stderr, "callEmulateMC: setupEmulateMC has not been called\n"); exit(EXIT_FAILURE); }   /* rbind.c:416-419 asserts */
+	const int d = emuMCData.model->options->nparams;
+	gsl_vector *pt = gsl_vector_alloc(d);
+	for (int i = 0; i < d; i++) gsl_vector_set(pt, i, point_in[i]);
+	emulate_point(emuMCData.emu, pt, mean_out, var_out);
+	gsl_vector_free(pt);
+}
+
+void freeEmulateMC(void) { mc_free(&emuMCData); }
+
+static int emuMCDataMulti_n;
+
+/* rbind.c:483-527: training_in is (nmodelpts x nydims), thetas_in (nydims x nthetas), both flattened column by column */
+void setupEmulateMCMulti(double *xmodel_in, int *nparams_in, double *training_in, int *nydims_in, int *nmodelpts_in,
+                         double *thetas_in, int *nthetas_in, int *cov_fn_index_in, int *regression_order_in)
+{
+	const int nydims = *nydims_in, N = *nmodelpts_in, nthetas = *nthetas_in;
+	if (emuMCDataMulti) { int n = emuMCDataMulti_n; freeEmulateMCMulti(&n); }
+	emuMCDataMulti = (struct emulateMCData *)calloc((size_t)nydims, sizeof *emuMCDataMulti);
+	emuMCDataMulti_n = nydims;
+	double *th = (double *)malloc(sizeof(double) * (size_t)nthetas);
+	for (int c = 0; c < nydims; c++) {
+		for (int i = 0; i < nthetas; i++) th[i] = thetas_in[c + nydims * i];
+		mc_setup(&emuMCDataMulti[c], xmodel_in, *nparams_in, training_in + (size_t)N * c, N, th, nthetas, *cov_fn_index_in,
+		         *regression_order_in);
+	}
+	free(th);
+}
+
+/* rbind.c:535-576; the nydims queries are all enqueued before the first is collected */
+void callEmulateMCMulti(double *point_in, int *nydims_in, double *final_mean, double *final_var)
+{
+	const int nydims = *nydims_in;
+	if (!emuMCDataMulti || nydims > emuMCDataMulti_n) {
+		fprintf(stderr, "callEmulateMCMulti: setupEmulateMCMulti has not been called for %d outputs\n", nydims);
+		exit(EXIT_FAILURE);
+	}
+	const int d = emuMCDataMulti[0].model->options->nparams;
+	gsl_matrix *pt = gsl_matrix_alloc(1, d);
+	for (int i = 0; i < d; i++) gsl_matrix_set(pt, 0, i, point_in[i]);
+	for (int c = 0; c < nydims; c++) emulate_points_enqueue(emuMCDataMulti[c].emu, pt);
+	for (int c = 0; c < nydims; c++) emulate_points_collect(emuMCDataMulti[c].emu, 1, &final_mean[c], &final_var[c]);
+	gsl_matrix_free(pt);
+}
+
+void freeEmulateMCMulti(int *nydims_in)
+{
+	if (!emuMCDataMulti) return;
+	(void)nydims_in;                                    /* the reference trusts it to equal the count given at setup */
+	for (int c = 0; c < emuMCDataMulti_n; c++) mc_free(&emuMCDataMulti[c]);
+	free(emuMCDataMulti);
+	emuMCDataMulti = NULL;
+	emuMCDataMulti_n = 0;
 }

@@ -1,0 +1,83 @@
+"""randomised parity sweep of the HIP path against the oracle: random (kind, N, d, order, batch, thetas), likelihood
+(single + batch), gradient (pow-exp) and predictions; prints the worst relative errors and every failure.
+usage: python scratch/fuzz_parity.py [cases] [seed]"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from madaiemulator_amd import abi, synth
+from oracle import oracle as O
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+ctx = abi.Context(0)
+worst = {}
+fails = 0
+def note(key, err, what):
+    global fails
+    if not np.isfinite(err) or err > 1e-8:
+        fails += 1
+        print("FAIL", key, err, what, flush=True)
+    if err > worst.get(key, (0, None))[0]:
+        worst[key] = (err, what)
+def rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+t0 = time.time()
+for it in range(cases):
+    kind = int(rng.integers(1, 4))
+    N = int(rng.choice([rng.integers(2, 70), rng.integers(60, 140), rng.integers(120, 700), rng.integers(500, 1300), rng.integers(1000, 2300) if rng.random() < 0.15 else rng.integers(64, 66)]))
+    d = int(rng.choice([1, 2, 3, 5, 8, 13, 16]))
+    order = int(rng.integers(0, 4))
+    while 1 + order * d >= N: order -= 1
+    nb = int(rng.choice([1, 2, 3, 5, 9, 16]))
+    X, y = synth.design(N, d, int(rng.integers(1, 1 << 30)))
+    nth = d + 2 if kind == 1 else 3
+    def draw():
+        th = synth.default_thetas(kind, d).copy()
+        th[2:] += rng.uniform(-0.7, 0.7, size=nth - 2)
+        if kind == 1:
+            th[0] = rng.uniform(-1, 1); th[1] = rng.uniform(-6, -2)
+        else:
+            th[0] = rng.uniform(0.3, 2.0); th[1] = 10 ** rng.uniform(-4, -1)
+        return th
+    ths = np.array([draw() for _ in range(nb)])
+    what = dict(kind=kind, N=N, d=d, order=order, nb=nb)
+    ctx.set_model(kind, order, X, y)
+    got = ctx.loglik_batch(ths)
+    one = ctx.loglik(ths[0])
+    e = O.Emulator(kind, order, X, y, ths[0])
+    r = y - e.H @ e.beta
+    quad = r @ e.cinverse @ r
+    ref = -(-0.5 * e.logdet - N / 2.0 * 1.83788 - 0.5 * quad)
+    # parity bar scaled by the conditioning the oracle itself sees (kappa * eps bounds what two correct fp64 paths share)
+    cond = np.linalg.cond(O.cov_matrix(kind, X, ths[0])) if N <= 700 else 1.0
+    tol_scale = max(1.0, cond * 2e-16 / 1e-9)
+    if got["status"][0] != 0:
+        print("status", got["status"][0], what, "cond %.2e" % cond, flush=True)
+        continue
+    note("batch_value", abs(got["value"][0] - ref) / abs(ref) / tol_scale, what)
+    note("single_value", abs(one["value"] - ref) / abs(ref) / tol_scale, what)
+    note("sigma2", abs(one["sigma2"] - y @ e.cinverse @ r / N) / abs(one["sigma2"]) / tol_scale, what)
+    note("beta", float(np.max(np.abs(one["beta"] - e.beta)) / max(np.max(np.abs(e.beta)), 1e-6 * np.max(np.abs(y)))) / tol_scale, what)   # beta ~ 0 by cancellation (N = 2, y = -1, +1) is noise on both sides
+    if kind == 1 and N <= 400:
+        thg = ths[0].copy(); thg[0] = 0.0
+        gg = ctx.loglik_grad(thg) if hasattr(ctx, "loglik_grad") else None
+        if gg is not None:
+            gref, st = O.grad_fn_multi(kind, order, X, y, thg[1:])
+            if st == 0 and gg["status"] == 0:
+                note("grad", rel(gg["grad"], gref) / tol_scale, what)
+    M = int(rng.choice([1, 7, 16, 17, 100, 300]))
+    Xq = synth.queries(M, d, int(rng.integers(1, 1 << 30)))
+    if M > 3: Xq[0] = X[0]
+    ctx.predict_setup(ths[0])
+    m, v = ctx.predict(Xq)
+    mo, vo, _ = e.emulate(Xq)
+    kappa = abs(ths[0][0]) + 1 if kind != 1 else np.exp(ths[0][0]) + np.exp(ths[0][1])
+    note("mean", float(np.max(np.abs(m - mo)) / max(1.0, np.max(np.abs(mo)))) / tol_scale, what)
+    note("var", float(np.max(np.abs(v - vo)) / kappa) / tol_scale, what)
+    if it % 20 == 19:
+        print("case", it + 1, "elapsed %.0fs" % (time.time() - t0), "fails", fails, flush=True)
+print("worst:")
+for k, (e_, w) in sorted(worst.items()):
+    print("  %-14s %.3e  %s" % (k, e_, w))
+print("FAILS", fails)

@@ -63,7 +63,8 @@ def test_host_library_exports_reference_symbols():
                  "makeEmulatedVariance", "callEvalLhoodList", "evalFnMultiList", "emulate_points", "makeCovMatrix",
                  "makeKVector", "makeHMatrix", "covariance_fn", "makeHVector", "makeGradMatLength", "getGradientCn",
                  "makeHMatrix_es", "makeCovMatrix_es", "makeKVector_es", "estimateBeta_es", "callEstimate",
-                 "callEmulateAtList", "callEmulateAtPt", "derivative_l_gauss"):
+                 "callEmulateAtList", "callEmulateAtPt", "derivative_l_gauss", "setupEmulateMC", "callEmulateMC",
+                 "freeEmulateMC", "setupEmulateMCMulti", "callEmulateMCMulti", "freeEmulateMCMulti"):
         assert hasattr(lib, name), name
 
 
@@ -337,6 +338,31 @@ def test_call_eval_lhood_list_without_r():
     assert np.all(np.isfinite(final))
     best = O.eval_fn_multi(1, 1, X, y, final[1:])["value"]
     assert np.isfinite(best) and best < O.eval_fn_multi(1, 1, X, y, np.array([-3.0, -1.0, -0.7]))["value"]
+    # setupEmulateMC / callEmulateMC / freeEmulateMC (rbind.c:299-460): one emulator kept between calls
+    lib.setupEmulateMC(xin.ctypes.data_as(dp), ip(d), y.ctypes.data_as(dp), ip(N), th.ctypes.data_as(dp), ip(nthetas), ip(1), ip(1))
+    for q in range(3):
+        qq = Q[q].copy()
+        lib.callEmulateMC(qq.ctypes.data_as(dp), m1.ctypes.data_as(dp), v1.ctypes.data_as(dp))
+        assert m1[0] == pytest.approx(mo[q], rel=1e-8, abs=1e-10) and v1[0] == pytest.approx(vo[q], abs=RTOL * kappa)
+    lib.freeEmulateMC()
+    lib.freeEmulateMC()                                   # idempotent
+    # ...Multi (rbind.c:483-600): nydims outputs of one design, one theta row each; arrays flattened column by column
+    Ym = np.column_stack([y, -2.0 * y + X[:, 0], np.cos(3.0 * y)])
+    ths = np.array([th, th + [0.1, 0.2, -0.1, 0.05], th + [-0.3, 0.5, 0.2, -0.2]])
+    nyd = Ym.shape[1]
+    lib.setupEmulateMCMulti(xin.ctypes.data_as(dp), ip(d), np.asfortranarray(Ym).ravel(order="F").copy().ctypes.data_as(dp),
+                            ip(nyd), ip(N), np.asfortranarray(ths).ravel(order="F").copy().ctypes.data_as(dp), ip(nthetas),
+                            ip(1), ip(1))
+    mm, vv = np.zeros(nyd), np.zeros(nyd)
+    for q in (0, 5):
+        qq = Q[q].copy()
+        lib.callEmulateMCMulti(qq.ctypes.data_as(dp), ip(nyd), mm.ctypes.data_as(dp), vv.ctypes.data_as(dp))
+        for c in range(nyd):
+            ec = O.Emulator(1, 1, X, Ym[:, c].copy(), ths[c])
+            mc, vc, _ = ec.emulate(Q[q:q + 1])
+            assert mm[c] == pytest.approx(mc[0], rel=1e-8, abs=1e-10)
+            assert vv[c] == pytest.approx(vc[0], abs=RTOL * O.cov(1, Q[q], Q[q], ths[c]))
+    lib.freeEmulateMCMulti(ip(nyd))
 
 
 @pytest.mark.gpu
