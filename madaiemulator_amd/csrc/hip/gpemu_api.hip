@@ -121,17 +121,20 @@ extern "C" int gpemu_device_count(void)
 	return n;
 }
 
-// process-wide tunables, read from the environment when a context is created (INTEGRATION.md lists them)
+// process-wide tunables, read from the environment every time a context is created (INTEGRATION.md lists them): a
+// variable that is absent or out of range gives the default, so the last context created decides for the process
 static void read_environment()
 {
-	auto geti = [](const char *name, int *out) { const char *v = getenv(name); if (v) *out = atoi(v); return v != nullptr; };
-	int v = 0;
-	if (geti("GPEMU_GEMM_BIG_TILES", &v) && v > 0) gpemu::g_gemm_big_tiles = v;
-	geti("GPEMU_GEMM_BIG_CFG", &gpemu::g_gemm_big_cfg);
-	geti("GPEMU_GEMM_TABLE", &gpemu::g_gemm_table);
-	if (geti("GPEMU_LOOKAHEAD", &v)) g_lookahead = v != 0;
-	if (geti("GPEMU_LEAF128", &v)) g_leaf128 = v != 0;
-	if (geti("GPEMU_NB_TOP", &v) && v >= LEAF) g_nb_top = (v / LEAF) * LEAF;
+	auto geti = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
+	int v = geti("GPEMU_GEMM_BIG_TILES", 2048);
+	gpemu::g_gemm_big_tiles = v > 0 ? v : 2048;
+	gpemu::g_gemm_big_cfg = geti("GPEMU_GEMM_BIG_CFG", 3);
+	v = geti("GPEMU_GEMM_TABLE", 8);
+	gpemu::g_gemm_table = v >= 0 && v <= 64 ? v : 8;
+	g_lookahead = geti("GPEMU_LOOKAHEAD", 0) != 0;
+	g_leaf128 = geti("GPEMU_LEAF128", 0) != 0;
+	v = geti("GPEMU_NB_TOP", 0);
+	g_nb_top = v >= LEAF ? (v / LEAF) * LEAF : 0;
 }
 
 extern "C" int gpemu_ctx_create(gpemu_ctx **out, int device)

@@ -587,6 +587,41 @@ def test_chol_inverse_and_symm_apply_on_host_matrices(gpu_ctx, n):
     assert rc == abi.ERR_NOT_PD and info == n // 2 + 1
 
 
+@pytest.mark.parametrize("env", [{"GPEMU_LEAF128": "1"}, {"GPEMU_LOOKAHEAD": "1"}, {"GPEMU_NO_GRAPH": "1"},
+                                 {"GPEMU_NB_TOP": "256"}, {"GPEMU_NB_TOP": "2048"}, {"GPEMU_GEMM_BIG_CFG": "0", "GPEMU_GEMM_BIG_TILES": "1"},
+                                 {"GPEMU_GEMM_BIG_TILES": "1"}, {"GPEMU_GEMM_BIG_TILES": "1000000"}])
+def test_schedule_switches_keep_parity(monkeypatch, env):
+    """the measurement switches of INTEGRATION.md (alternative leaves, look-ahead, panel widths, tile shapes, no graph)
+    change the schedule, not the result: likelihood and gradient agree with the default schedule to rounding"""
+    N, d = 1500, 4
+    X, y = synth.design(N, d, 8)
+    th = synth.default_thetas(1, d)
+    ths = np.array([synth.perturbed_thetas(1, d, 3, i) for i in range(3)])
+
+    def run():
+        c = abi.Context(0)
+        c.set_model(1, 1, X, y)
+        out = [c.loglik(th), c.loglik(th), c.loglik_batch(ths), c.loglik_batch(ths), c.loglik_grad(th)]
+        c.close()
+        return out
+    base = run()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    got = run()
+    for k in env:
+        monkeypatch.delenv(k)
+    abi.Context(0).close()                   # the next context re-reads the environment: back to the defaults
+    assert got[0]["value"] == got[1]["value"] and np.array_equal(got[2]["value"], got[3]["value"])
+    assert got[0]["value"] == pytest.approx(base[0]["value"], rel=1e-11)
+    assert got[0]["sigma2"] == pytest.approx(base[0]["sigma2"], rel=1e-10)
+    assert np.allclose(got[2]["value"], base[2]["value"], rtol=1e-11, atol=0)
+    assert np.allclose(got[4]["grad"], base[4]["grad"], rtol=1e-8, atol=1e-9 * np.max(np.abs(base[4]["grad"])))
+    e = O.Emulator(1, 1, X, y, th)
+    r = y - e.H @ e.beta
+    ref = -(-0.5 * e.logdet - N / 2.0 * 1.83788 - 0.5 * (r @ e.cinverse @ r))
+    assert got[0]["value"] == pytest.approx(ref, rel=RTOL)
+
+
 def test_tile_order_does_not_change_the_bits(monkeypatch):
     """GPEMU_GEMM_TABLE only permutes which workgroup computes which tile: same sums in the same order per tile"""
     import os
@@ -605,6 +640,8 @@ def test_tile_order_does_not_change_the_bits(monkeypatch):
         assert rb["value"][0] == rb["value"][1]
         vals.append((r1["value"], r1["sigma2"], rb["value"][0]))
         c.close()
+    monkeypatch.delenv("GPEMU_GEMM_TABLE")
+    abi.Context(0).close()                   # back to the default for the contexts of the following tests
     assert vals[0] == vals[1] == vals[2]
 
 
