@@ -210,7 +210,7 @@ static void free_model(gpemu_ctx *ctx)
 	for (auto p : ptrs) { if (*p) hipFree(*p); *p = nullptr; }
 	ctx->T_rows = 0; ctx->pred_ready = false; ctx->cinv_ready = false; ctx->pred_batch = 0; ctx->stage_cap = 0;
 	ctx->pred_pending = 0;
-	ctx->S_dim = 0; ctx->gradpart_len = 0;
+	ctx->S_dim = 0; ctx->S_cap = 0; ctx->gradpart_len = 0; ctx->alpha_cap = 0;
 }
 
 extern "C" void gpemu_ctx_destroy(gpemu_ctx *ctx)
@@ -1007,23 +1007,26 @@ extern "C" int gpemu_predict_batch(gpemu_ctx *ctx, int M, const double *xq, doub
 // explicit inverse: S = Aug Aug^T with Aug = [Z^T ; U]  ->  S[Rp+i][Rp+j] = (C^-1)_ij,
 // S[Rp+i][a] = (C^-1 [y|H])_ia   (lower triangle only)
 // ---------------------------------------------------------------------------
-static int build_corner(gpemu_ctx *ctx, int b = 0)
+// corners of the nbc batch elements b0 .. b0+nbc-1 (one batched product)
+static int build_corner(gpemu_ctx *ctx, int b0 = 0, int nbc = 1)
 {
 	const int Np = ctx->Np, Rp = ctx->Rp;
 	const size_t dim = (size_t)Np + Rp;
-	if (ctx->S_dim < dim) {
+	if (ctx->S_dim < dim || ctx->S_cap < nbc) {
 		if (ctx->dS) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); hipFree(ctx->dS); ctx->dS = nullptr; }
-		HIPCHK(ctx, hipMalloc(&ctx->dS, dim * dim * sizeof(double)));
-		ctx->S_dim = dim;
+		ctx->S_dim = 0; ctx->S_cap = 0;
+		HIPCHK(ctx, hipMalloc(&ctx->dS, (size_t)nbc * dim * dim * sizeof(double)));
+		ctx->S_dim = dim; ctx->S_cap = nbc;
 	}
 	GemmArgs g;
 	memset(&g, 0, sizeof g);
-	g.C = ctx->dS; g.ldc = (long)dim;
-	g.A = ctx->dT + (size_t)b * ctx->T_stride + (size_t)Np * Np; g.lda = Np;
+	g.C = ctx->dS; g.ldc = (long)ctx->S_dim;
+	g.A = ctx->dT + (size_t)b0 * ctx->T_stride + (size_t)Np * Np; g.lda = Np;
 	g.B = g.A; g.ldb = Np;
 	g.m = (int)dim; g.n = (int)dim; g.k0 = 0; g.k1 = Np; g.alpha = 1.0; g.beta = 0;
 	g.tri = 1; g.diag_off = 0;
 	g.kstart_mode = 1; g.kstart_off = Rp;
+	g.nbatch = nbc; g.bsC = (long)(ctx->S_dim * ctx->S_dim); g.bsA = g.bsB = (long)ctx->T_stride;
 	HIPCHK(ctx, gemm(ctx, g));
 	return GPEMU_OK;
 }
@@ -1082,53 +1085,87 @@ extern "C" int gpemu_loglik_grad(gpemu_ctx *ctx, const double *thetas, int nthet
 
 // second half of a gradient evaluation: matrix b of the workspace holds the factorisation with its inverse rows
 // (U = L^-T); builds C^-1 = U U^T and reduces tr(C^-1 dC_k), alpha^T dC_k alpha over its tiles
-static int grad_finish(gpemu_ctx *ctx, int b, const double *th /* full thetas, th[0] = 0 */, const HostLik &r, double *grad)
+// corners S kept in flight at a time by the gradient of a batch: as many as fit in about 10 GB
+static int grad_chunk_size(const gpemu_ctx *ctx, int nb)
 {
-	int rc = build_corner(ctx, b);
+	const double dim = (double)ctx->Np + ctx->Rp;
+	const int fit = (int)(10.0e9 / (dim * dim * 8.0));
+	return std::max(1, std::min(nb, fit));
+}
+
+// gradients of the batch elements b0 .. b0+nbc-1 whose likelihood pieces are in liks[] (elements with liks[i] == nullptr
+// -- not positive definite -- are skipped): one batched C^-1 = U U^T product, one reduction launch per element, one
+// download and one synchronisation for the chunk.
+static int grad_finish_chunk(gpemu_ctx *ctx, int b0, int nbc, const double *const *th /* full thetas, th[0] = 0 */,
+                             const HostLik *const *liks, double *const *grad)
+{
+	int rc = build_corner(ctx, b0, nbc);
 	if (rc) return rc;
 	const int N = ctx->N, d = ctx->d, Rp = ctx->Rp;
-	const size_t dim = ctx->S_dim;
-	// alpha = C^-1 y  = column 0 of the [I rows x R cols] block (scratch kept with the context: hipMalloc/hipFree per
+	const size_t dim = ctx->S_dim, sstride = dim * dim;
+	// alpha = C^-1 y = column 0 of the [I rows x R cols] block (scratch kept with the context: hipMalloc/hipFree per
 	// call are synchronous and cost more than the reduction kernel)
-	if (!ctx->dAlpha) HIPCHK(ctx, hipMalloc(&ctx->dAlpha, ((size_t)ctx->Np + GPEMU_MAX_PARAMS) * sizeof(double)));
-	double *dAlpha = ctx->dAlpha, *dGp = ctx->dAlpha + ctx->Np;
-	hipError_t e = hipSuccess;
-	if (e == hipSuccess)
-		e = hipMemcpy2DAsync(dAlpha, sizeof(double), ctx->dS + (size_t)Rp * dim, dim * sizeof(double), sizeof(double), N,
-		                     hipMemcpyDeviceToDevice, ctx->stream);
-	if (e == hipSuccess)
-		e = hipMemcpyAsync(dGp, th + 2, (size_t)d * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+	const size_t aslot = (size_t)ctx->Np + GPEMU_MAX_PARAMS;
+	if (ctx->alpha_cap < nbc) {
+		if (ctx->dAlpha) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); hipFree(ctx->dAlpha); ctx->dAlpha = nullptr; }
+		ctx->alpha_cap = 0;
+		HIPCHK(ctx, hipMalloc(&ctx->dAlpha, (size_t)nbc * aslot * sizeof(double)));
+		ctx->alpha_cap = nbc;
+	}
 	const int nt = (N + 63) / 64, ntiles = nt * (nt + 1) / 2;
 	const size_t need = (size_t)ntiles * (2 * d + 1);
-	if (e == hipSuccess && ctx->gradpart_len < need) {
-		if (ctx->dGradPart) hipFree(ctx->dGradPart);
+	if (ctx->gradpart_len < need * nbc) {
+		if (ctx->dGradPart) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); hipFree(ctx->dGradPart); }
 		ctx->dGradPart = nullptr; ctx->gradpart_len = 0;
-		e = hipMalloc(&ctx->dGradPart, need * sizeof(double));
-		if (e == hipSuccess) ctx->gradpart_len = need;
+		HIPCHK(ctx, hipMalloc(&ctx->dGradPart, need * nbc * sizeof(double)));
+		ctx->gradpart_len = need * nbc;
 	}
+	std::vector<double> part(need * nbc), alpha((size_t)N * nbc);
+	hipError_t e = hipSuccess;
 	int nparts = 0;
-	if (e == hipSuccess)
-		e = launch_grad_partials(ctx->stream, ctx->dS, (long)dim, Rp, ctx->dX, N, d, dAlpha, ctx->kind, dGp,
-		                         ctx->dGradPart, &nparts);
-	std::vector<double> part(need), alpha(N);
-	if (e == hipSuccess)
-		e = hipMemcpyAsync(part.data(), ctx->dGradPart, need * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-	if (e == hipSuccess)
-		e = hipMemcpyAsync(alpha.data(), dAlpha, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+	for (int i = 0; i < nbc && e == hipSuccess; i++) {
+		if (!liks[i]) continue;
+		double *dAlpha = ctx->dAlpha + (size_t)i * aslot, *dGp = dAlpha + ctx->Np;
+		const double *S = ctx->dS + (size_t)i * sstride;
+		e = hipMemcpy2DAsync(dAlpha, sizeof(double), S + (size_t)Rp * dim, dim * sizeof(double), sizeof(double), N,
+		                     hipMemcpyDeviceToDevice, ctx->stream);
+		if (e == hipSuccess)
+			e = hipMemcpyAsync(dGp, th[i] + 2, (size_t)d * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+		if (e == hipSuccess)
+			e = launch_grad_partials(ctx->stream, S, (long)dim, Rp, ctx->dX, N, d, dAlpha, ctx->kind, dGp,
+			                         ctx->dGradPart + (size_t)i * need, &nparts);
+		if (e == hipSuccess)
+			e = hipMemcpyAsync(part.data() + (size_t)i * need, ctx->dGradPart + (size_t)i * need, need * sizeof(double),
+			                   hipMemcpyDeviceToHost, ctx->stream);
+		if (e == hipSuccess)
+			e = hipMemcpyAsync(alpha.data() + (size_t)i * N, dAlpha, (size_t)N * sizeof(double), hipMemcpyDeviceToHost,
+			                   ctx->stream);
+	}
 	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
 	HIPCHK(ctx, e);
-	std::vector<double> sums(2 * d + 1, 0.0);
-	for (int t = 0; t < nparts; t++)
-		for (int k = 0; k < 2 * d + 1; k++) sums[k] += part[(size_t)t * (2 * d + 1) + k];
-	double aa = 0.0;
-	for (int i = 0; i < N; i++) aa += alpha[i] * alpha[i];
-	const double amp = exp(log(r.sigma2));            // maxmultimin.c:503,514
-	const double nug = exp(th[1]);                    // :515
-	// G(dC) = -1/2 tr(A dC) + 1/2 alpha^T dC alpha ;  grad = -G   (:527,535; getGradientCn :571-608)
-	grad[0] = -1.0 * (-0.5 * nug * sums[2 * d] + 0.5 * nug * aa);
-	for (int k = 0; k < d; k++)
-		grad[k + 1] = -1.0 * (amp * (-0.5 * sums[2 * k] + 0.5 * sums[2 * k + 1]));
+	for (int i = 0; i < nbc; i++) {
+		if (!liks[i]) continue;
+		std::vector<double> sums(2 * d + 1, 0.0);
+		const double *pi = part.data() + (size_t)i * need;
+		for (int t = 0; t < nparts; t++)
+			for (int k = 0; k < 2 * d + 1; k++) sums[k] += pi[(size_t)t * (2 * d + 1) + k];
+		double aa = 0.0;
+		const double *ai = alpha.data() + (size_t)i * N;
+		for (int j = 0; j < N; j++) aa += ai[j] * ai[j];
+		const double amp = exp(log(liks[i]->sigma2));     // maxmultimin.c:503,514
+		const double nug = exp(th[i][1]);                 // :515
+		// G(dC) = -1/2 tr(A dC) + 1/2 alpha^T dC alpha ;  grad = -G   (:527,535; getGradientCn :571-608)
+		grad[i][0] = -1.0 * (-0.5 * nug * sums[2 * d] + 0.5 * nug * aa);
+		for (int k = 0; k < d; k++)
+			grad[i][k + 1] = -1.0 * (amp * (-0.5 * sums[2 * k] + 0.5 * sums[2 * k + 1]));
+	}
 	return GPEMU_OK;
+}
+
+static int grad_finish(gpemu_ctx *ctx, int b, const double *th, const HostLik &r, double *grad)
+{
+	const HostLik *lp = &r;
+	return grad_finish_chunk(ctx, b, 1, &th, &lp, &grad);
 }
 
 static int grad_check_args(gpemu_ctx *ctx, int nthetas)
@@ -1187,31 +1224,48 @@ extern "C" int gpemu_loglik_grad_batch(gpemu_ctx *ctx, int nb, const double *the
 	if (rc) return rc;
 	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 	const int ng = nthetas - 1;
+	std::vector<HostLik> liks((size_t)nb);
+	std::vector<int> st((size_t)nb, GPEMU_OK);
 	for (int b = 0; b < nb; b++) {
 		const int inf = (ctx->hInfo[b] >= INFO_NONE) ? 0 : ctx->hInfo[b];
 		if (info) info[b] = inf;
-		int st = GPEMU_OK;
-		double val = NAN, s2 = NAN;
 		for (int i = 0; i < ng; i++) grad[(size_t)b * ng + i] = NAN;
 		if (beta) for (int a = 0; a < ctx->nreg; a++) beta[(size_t)b * ctx->nreg + a] = NAN;
+		if (neg_loglik) neg_loglik[b] = NAN;
+		if (sigma2) sigma2[b] = NAN;
 		if (inf) {
-			st = fail(ctx, GPEMU_ERR_NOT_PD, "covariance matrix is not positive definite");
-		} else {
-			HostLik r = host_likelihood(ctx, b);
-			if (r.status) {
-				st = fail(ctx, r.status, "H^T C^-1 H is not positive definite");
-			} else {
-				st = grad_finish(ctx, b, &th[(size_t)b * nthetas], r, grad + (size_t)b * ng);
-				if (st != GPEMU_OK) return st;                                   // HIP failure: give up on the batch
-				const double log_2_pi = 1.83788;
-				val = -1 * (-(1.0 / 2.0) * r.logdet - (ctx->N / 2.0) * log_2_pi + r.quad * (-1.0 / 2.0));
-				s2 = r.sigma2;
-				if (beta) for (int a = 0; a < ctx->nreg; a++) beta[(size_t)b * ctx->nreg + a] = r.beta[a];
-			}
+			st[b] = fail(ctx, GPEMU_ERR_NOT_PD, "covariance matrix is not positive definite");
+			continue;
 		}
-		if (neg_loglik) neg_loglik[b] = val;
-		if (sigma2) sigma2[b] = s2;
-		if (status) status[b] = st;
+		liks[b] = host_likelihood(ctx, b);
+		if (liks[b].status) st[b] = fail(ctx, liks[b].status, "H^T C^-1 H is not positive definite");
+	}
+	const int chunk = grad_chunk_size(ctx, nb);
+	for (int b0 = 0; b0 < nb; b0 += chunk) {
+		const int nbc = std::min(chunk, nb - b0);
+		std::vector<const double *> thp((size_t)nbc);
+		std::vector<const HostLik *> lp((size_t)nbc);
+		std::vector<double *> gp((size_t)nbc);
+		bool any = false;
+		for (int i = 0; i < nbc; i++) {
+			thp[i] = &th[(size_t)(b0 + i) * nthetas];
+			lp[i] = st[b0 + i] == GPEMU_OK ? &liks[b0 + i] : nullptr;
+			gp[i] = grad + (size_t)(b0 + i) * ng;
+			any = any || lp[i];
+		}
+		if (!any) continue;
+		rc = grad_finish_chunk(ctx, b0, nbc, thp.data(), lp.data(), gp.data());
+		if (rc != GPEMU_OK) return rc;                                           // HIP failure: give up on the batch
+	}
+	for (int b = 0; b < nb; b++) {
+		if (st[b] == GPEMU_OK) {
+			const HostLik &r = liks[b];
+			const double log_2_pi = 1.83788;
+			if (neg_loglik) neg_loglik[b] = -1 * (-(1.0 / 2.0) * r.logdet - (ctx->N / 2.0) * log_2_pi + r.quad * (-1.0 / 2.0));
+			if (sigma2) sigma2[b] = r.sigma2;
+			if (beta) for (int a = 0; a < ctx->nreg; a++) beta[(size_t)b * ctx->nreg + a] = r.beta[a];
+		}
+		if (status) status[b] = st[b];
 	}
 	return GPEMU_OK;
 }
@@ -1296,7 +1350,7 @@ extern "C" int gpemu_chol_inverse(gpemu_ctx *ctx, int n, double *a, int lda, dou
 	hipError_t e = hipMalloc(&tmp.dT, rows * Np * sizeof(double));
 	if (e == hipSuccess) e = hipMalloc(&tmp.dInfo, sizeof(int));
 	if (e == hipSuccess) e = hipMalloc(&tmp.dS, dim * dim * sizeof(double));
-	if (e == hipSuccess) tmp.S_dim = dim;
+	if (e == hipSuccess) { tmp.S_dim = dim; tmp.S_cap = 1; }
 	tmp.dDiagInv = ctx->dDiagInv;
 	if (e == hipSuccess) e = hipMemcpyAsync(tmp.dT, h.data(), h.size() * 8, hipMemcpyHostToDevice, tmp.stream);
 	if (e == hipSuccess) e = hipMemsetAsync(tmp.dT + (size_t)Np * Np, 0, (size_t)Rp * Np * 8, tmp.stream);

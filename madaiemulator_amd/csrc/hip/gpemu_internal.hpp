@@ -122,8 +122,9 @@ struct gpemu_ctx {
 	double *hStage = nullptr;    // pinned: stage_cap*d query coordinates, then stage_cap means, then stage_cap variances
 	int pred_pending = 0;        // queries of an enqueued, not yet collected prediction batch
 	bool cinv_ready = false;
-	double *dS = nullptr;        // (Rp+Np)^2 corner for explicit inverse / gradient
+	double *dS = nullptr;        // S_cap corners of (Rp+Np)^2 for explicit inverse / gradient (one per batch element in flight)
 	size_t S_dim = 0;
+	int S_cap = 0;
 
 	// gradient scratch
 	double *dGradPart = nullptr;
@@ -132,8 +133,9 @@ struct gpemu_ctx {
 	const double *sym_key = nullptr;
 	int sym_N = 0, sym_lda = 0, sym_pad = 0, sym_vcap = 0;
 	double sym_fp = 0.0;
-	double *dAlpha = nullptr;    // Np doubles of alpha = C^-1 y, then the d length-scale thetas
-	size_t gradpart_len = 0;
+	double *dAlpha = nullptr;    // per corner: Np doubles of alpha = C^-1 y, then GPEMU_MAX_PARAMS length-scale thetas
+	int alpha_cap = 0;
+	size_t gradpart_len = 0;     // doubles of dGradPart (all corners)
 
 	gpemu::ProfState prof;
 	// GPEMU_TRACE=1: per-launch device timestamps (wall_clock64) written by the kernels themselves, so that the
