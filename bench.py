@@ -255,13 +255,16 @@ def main():
         ctx.loglik_batch_enqueue(np.array([theta(2000 + i) for i in range(B)]))     # one lock-step batch, as timed above
         p = ctx.prof_end()
         ach = p["flops"] / (p["ms"] * 1e-3) / 1e12
-        # HBM bytes per launch from the PMC passes committed under profiles/ (separate rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE runs of the same evaluation; FETCH_SIZE is the raw counter, see the .txt next to it)
+        # memory-side bytes per launch from the PMC passes committed under profiles/ (separate rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE runs of the same evaluation).  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE counts half the bytes of
+        # 16-B-per-lane reads; the 8-B-per-lane C-tile reads of this kernel calibrate to the same half
+        # (profiles/r01_pmc_fetch_calibration.txt), so the whole raw fetch is doubled; WRITE_SIZE is exact.  Infinity-
+        # Cache hits are included in both, i.e. this is fabric traffic, an upper bound on HBM traffic.
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_v6_tile_table.json")
         if args.workload == "c3" and B == 16 and os.path.exists(tpath):      # measured for batches of 16
             tj = json.load(open(tpath))["gemm_nt_kernel"]
-            traffic = (tj["fetch_bytes_raw"] + tj["write_bytes"]) / tj["launches"]
+            traffic = (2.0 * tj["fetch_bytes_raw"] + tj["write_bytes"]) / tj["launches"]
         roof = {"bound": "mfma", "kernel": "gemm_nt_kernel (potrf trailing update, v_mfma_f64_16x16x4_f64)",
                 "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS,
                 "traffic": traffic, "launches": p["n"], "avg_launch_us": p["ms"] * 1e3 / max(p["n"], 1),
