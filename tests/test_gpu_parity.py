@@ -226,8 +226,9 @@ def test_loglik_enqueue_collect_pipeline(gpu_ctx):
 @pytest.mark.parametrize("kind,N,d,order,nb", [(1, 512, 8, 1, 5), (3, 1100, 8, 1, 3), (1, 2200, 4, 0, 4), (2, 300, 4, 2, 7)])
 def test_loglik_batch_vs_oracle_and_single(gpu_ctx, kind, N, d, order, nb):
     """gpemu_loglik_batch: nb evaluations of one model factored in lock-step -- every element equals the oracle
-    to 1e-8 and equals the single-evaluation entry to rounding (same kernels; the outer panel width of a batch
-    differs above N = 512, so the summation order may)."""
+    to 1e-8 and equals the single-evaluation entry bit for bit: the outer panel width of a batch differs above
+    N = 512, but a trailing update continues the k-ordered accumulation from the stored C value (the accumulators
+    start from the C tile), so the sums do not depend on where the panels are cut."""
     X, y = synth.design(N, d, 20261003 + N + nb)
     gpu_ctx.set_model(kind, order, X, y)
     ths = np.array([synth.perturbed_thetas(kind, d, 31, i) for i in range(nb)])
@@ -236,10 +237,8 @@ def test_loglik_batch_vs_oracle_and_single(gpu_ctx, kind, N, d, order, nb):
     for b in range(nb):
         one = gpu_ctx.loglik(ths[b])
         for key in ("value", "sigma2", "logdet", "quad"):
-            assert got[key][b] == pytest.approx(one[key], rel=1e-12), (key, b)
-            if N <= 512:
-                assert got[key][b] == one[key], (key, b)
-        assert relerr(got["beta"][b], one["beta"]) < 1e-11
+            assert got[key][b] == one[key], (key, b)
+        assert np.array_equal(got["beta"][b], one["beta"])
     for b in (0, nb - 1):
         e = O.Emulator(kind, order, X, y, ths[b])
         r = y - e.H @ e.beta
