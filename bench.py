@@ -261,7 +261,7 @@ def main():
         # (profiles/r01_pmc_fetch_calibration.txt), so the whole raw fetch is doubled; WRITE_SIZE is exact.  Infinity-
         # Cache hits are included in both, i.e. this is fabric traffic, an upper bound on HBM traffic.
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_v6_tile_table.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_v7_nb2048.json")
         if args.workload == "c3" and B == 16 and os.path.exists(tpath):      # measured for batches of 16
             tj = json.load(open(tpath))["gemm_nt_kernel"]
             traffic = (2.0 * tj["fetch_bytes_raw"] + tj["write_bytes"]) / tj["launches"]

@@ -26,7 +26,7 @@ using namespace gpemu;
 
 static int g_leaf128 = 0;                // 128-column fused leaves (env GPEMU_LEAF128=1); measured 3 % slower than 64
 static int g_lookahead = 0;              // two-stream schedule of the outer panels (env GPEMU_LOOKAHEAD=1); see DESIGN.md
-static int g_nb_top = 0;            // outer panel width (env GPEMU_NB_TOP); 0 = automatic: 512 for one matrix, 1024 for a lock-step batch
+static int g_nb_top = 0;            // outer panel width (env GPEMU_NB_TOP); 0 = automatic: 512 for one matrix, 2048 for a lock-step batch
 constexpr int INFO_NONE = 0x7f7f7f7f;   // "no failed pivot": what hipMemsetAsync(.., 0x7f, ..) leaves in *info
 
 static int fail(gpemu_ctx *ctx, int code, const char *msg)
@@ -447,8 +447,10 @@ static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv)
 		                      (long)ctx->T_stride);
 	}
 	// automatic outer panel width: a batch has enough tiles per launch to afford the longer panel chain of a wider
-	// panel and gains from the larger K of its trailing updates (measured: 3.77 -> 3.55 ms per evaluation at 2x16)
-	const int nb_top = g_nb_top > 0 ? g_nb_top : (ctx->nb >= 2 ? 1024 : 512);
+	// panel and gains from the larger K of its trailing updates and the fewer read-modify-write passes over the
+	// trailing matrix (measured at 2x16, N=8192: 3.77 ms per evaluation at 512, 3.55 at 1024 with the first GEMM
+	// epilogue; 3.329 at 1024, 3.302 at 2048, 3.314 at 4096 now; 2048 also wins at N = 4096, 12288, 16384)
+	const int nb_top = g_nb_top > 0 ? g_nb_top : (ctx->nb >= 2 ? 2048 : 512);
 	if (n > nb_top) {
 		// right-looking over panels of nb_top columns: the trailing update touches the whole remaining
 		// matrix (thousands of tiles, K = panel width), which fills the chip far better than the few huge-K
