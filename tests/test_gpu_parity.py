@@ -644,6 +644,44 @@ def test_tile_order_does_not_change_the_bits(monkeypatch):
     assert vals[0] == vals[1] == vals[2]
 
 
+def test_host_threads_with_their_own_contexts():
+    """the boundary's threading contract (re-entrant across threads with distinct params): three host
+    threads drive their own contexts at the same time (ctypes releases the GIL); every result equals, bit for
+    bit, the one the same context produced alone.  scratch/threads_soak.py is the long form (90 s, 23 000 rounds)."""
+    import threading
+    import time
+    work = []
+    for kind, order, N, d, nb in [(1, 1, 1500, 4, 5), (3, 1, 2300, 8, 3), (2, 2, 777, 3, 7)]:
+        X, y = synth.design(N, d, N)
+        ths = np.array([synth.perturbed_thetas(kind, d, 5, i) for i in range(nb)])
+        c = abi.Context(0)
+        c.set_model(kind, order, X, y)
+        ref_b = c.loglik_batch(ths)
+        c.predict_setup(ths[0])
+        Q = synth.queries(65, d, 3)
+        work.append((c, ths, Q, ref_b, c.predict(Q)))
+    errors, rounds = [], [0] * len(work)
+    stop = time.time() + 3.0
+
+    def run(i):
+        c, ths, Q, ref_b, ref_p = work[i]
+        while time.time() < stop and not errors:
+            b = c.loglik_batch(ths)
+            c.predict_setup(ths[0])
+            m, v = c.predict(Q)
+            if not (np.array_equal(b["value"], ref_b["value"]) and np.array_equal(m, ref_p[0]) and np.array_equal(v, ref_p[1])):
+                errors.append(i)
+            rounds[i] += 1
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(len(work))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for w in work:
+        w[0].close()
+    assert not errors and min(rounds) >= 2, (errors, rounds)
+
+
 def test_model_switching_soak_is_deterministic():
     """two contexts, a random sequence of model changes (size, dimension, kernel, order) with evaluations, batches,
     gradients and predictions in between: workspaces and launch graphs are re-used / rebuilt correctly, and the
