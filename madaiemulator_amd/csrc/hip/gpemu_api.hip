@@ -223,6 +223,9 @@ extern "C" void gpemu_ctx_destroy(gpemu_ctx *ctx)
 	for (auto e : ctx->prof.ev) hipEventDestroy(e);
 	if (ctx->dInfo) hipFree(ctx->dInfo);
 	if (ctx->dTrace) hipFree(ctx->dTrace);
+	if (ctx->dParams) hipFree(ctx->dParams);
+	if (ctx->hParams) hipHostFree(ctx->hParams);
+	for (auto e : ctx->param_ev) if (e) hipEventDestroy(e);
 	if (ctx->dDiagInv) hipFree(ctx->dDiagInv);
 	if (ctx->dSym) hipFree(ctx->dSym);
 	if (ctx->dSymV) hipFree(ctx->dSymV);
@@ -559,19 +562,31 @@ static int stage_matrices(gpemu_ctx *ctx, const CovParams *ps, int nb, int inv)
 	if (rc) return rc;
 	rc = ensure_T(ctx, (size_t)Np + Rp + (inv ? Np : 0), nb);
 	if (rc) return rc;
-	for (int b = 0; b < nb; b++) {
-		double *Tb = ctx->dT + (size_t)b * ctx->T_stride;
-		{
-			const double nlow = 0.5 * (double)Np * Np;
-			ProfScope ps_(ctx, GPEMU_PROF_FILL, 0.0, 8.0 * nlow);
-			HIPCHK(ctx, launch_cov_fill(ctx->stream, Tb, Np, ctx->dX, ctx->N, Np, ctx->dX, ctx->N, Np, ctx->d, ps[b],
-			                            FILL_LOWER | FILL_IDENT_PAD));
-		}
-		HIPCHK(ctx, hipMemcpyAsync(Tb + (size_t)Np * Np, ctx->dRrows, (size_t)Rp * Np * sizeof(double),
-		                           hipMemcpyDeviceToDevice, ctx->stream));
-		if (inv)
-			HIPCHK(ctx, launch_set_identity_rows(ctx->stream, Tb + (size_t)(Np + Rp) * Np, Np, Np));
+	// one upload of the nb hyper-parameter sets, one launch for the nb fills and R-row copies.  The upload goes through a
+	// pinned ring of four entries (a pageable source makes hipMemcpyAsync wait for the stream: enqueued batches of small
+	// models then take 6 us per evaluation instead of 2); an entry is reused once its own copy has executed.
+	constexpr unsigned PARAM_RING = 4;
+	if (!ctx->dParams) {
+		HIPCHK(ctx, hipMalloc(&ctx->dParams, (size_t)GPEMU_MAX_BATCH * sizeof(CovParams)));
+		HIPCHK(ctx, hipHostMalloc((void **)&ctx->hParams, (size_t)PARAM_RING * GPEMU_MAX_BATCH * sizeof(CovParams)));
+		for (unsigned i = 0; i < PARAM_RING; i++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->param_ev[i], hipEventDisableTiming));
 	}
+	{
+		const unsigned slot = ctx->param_next++ % PARAM_RING;
+		HIPCHK(ctx, hipEventSynchronize(ctx->param_ev[slot]));        // (a never-recorded event is complete)
+		CovParams *hp = ctx->hParams + (size_t)slot * GPEMU_MAX_BATCH;
+		memcpy(hp, ps, (size_t)nb * sizeof(CovParams));
+		HIPCHK(ctx, hipMemcpyAsync(ctx->dParams, hp, (size_t)nb * sizeof(CovParams), hipMemcpyHostToDevice, ctx->stream));
+		HIPCHK(ctx, hipEventRecord(ctx->param_ev[slot], ctx->stream));
+	}
+	{
+		const double nlow = 0.5 * (double)Np * Np * nb;
+		ProfScope ps_(ctx, GPEMU_PROF_FILL, 0.0, 8.0 * nlow);
+		HIPCHK(ctx, launch_cov_stage_batch(ctx->stream, ctx->dT, Np, (long)ctx->T_stride, nb, ctx->dX, ctx->N, Np, ctx->d,
+		                                   ctx->dParams, FILL_LOWER | FILL_IDENT_PAD, ctx->dRrows, Rp));
+	}
+	if (inv)
+		HIPCHK(ctx, launch_set_identity_rows(ctx->stream, ctx->dT + (size_t)(Np + Rp) * Np, Np, Np, nb, (long)ctx->T_stride));
 	HIPCHK(ctx, hipMemsetAsync(ctx->dInfo, 0x7f, (size_t)nb * sizeof(int), ctx->stream));
 	return GPEMU_OK;
 }

@@ -133,6 +133,10 @@ struct gpemu_ctx {
 	const double *sym_key = nullptr;
 	int sym_N = 0, sym_lda = 0, sym_pad = 0, sym_vcap = 0;
 	double sym_fp = 0.0;
+	gpemu::CovParams *dParams = nullptr;   // hyper-parameters of the batch elements (GPEMU_MAX_BATCH slots)
+	gpemu::CovParams *hParams = nullptr;   // pinned upload ring: PARAM_RING x GPEMU_MAX_BATCH slots, one event per ring entry
+	hipEvent_t param_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+	unsigned param_next = 0;
 	double *dAlpha = nullptr;    // per corner: Np doubles of alpha = C^-1 y, then GPEMU_MAX_PARAMS length-scale thetas
 	int alpha_cap = 0;
 	size_t gradpart_len = 0;     // doubles of dGradPart (all corners)
@@ -154,7 +158,9 @@ hipError_t launch_cov_fill(hipStream_t s, double *out, long ld, const double *Xr
 constexpr int FILL_LOWER = 1, FILL_CLAMP = 2, FILL_IDENT_PAD = 4;
 hipError_t launch_build_rrows(hipStream_t s, double *R, int Np, int Rp, const double *X, const double *y,
                               int N, int d, int order);
-hipError_t launch_set_identity_rows(hipStream_t s, double *T, long ld, int n);
+hipError_t launch_set_identity_rows(hipStream_t s, double *T, long ld, int n, int nbatch = 1, long bstride = 0);
+hipError_t launch_cov_stage_batch(hipStream_t s, double *T, long ld, long bstride, int nb, const double *X, int N, int Np, int d,
+                                  const CovParams *pp_dev, int mode, const double *Rrows, int Rp);
 hipError_t launch_transpose(hipStream_t s, double *dst, long ldd, const double *src, long lds, int n);
 hipError_t launch_predict_finish(hipStream_t s, const double *V, long ldv, int M, int Np, int nreg, int order, int d,
                                  const double *Xq, const double *betaQ, double kappa, double *mean, double *var,

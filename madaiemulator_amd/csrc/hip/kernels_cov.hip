@@ -51,21 +51,20 @@ __device__ __forceinline__ double fast_sqrt(double a)
 // p.w[k] is the per-dimension scale applied while staging: pow-exp sqrt(0.5)/r_k (so the exponent is
 // -sum d'^2), Matern 1/rho (so sqrt(sum d'^2) is distance/rho).  p.eps is the reference's per-coordinate
 // "same point" threshold on the UNSCALED coordinates; p.cand bounds sum d'^2 for pairs that can pass it.
-__global__ __launch_bounds__(256) void cov_fill_kernel(double *out, long ld, const double *Xr, int nr,
-                                                       const double *Xc, int nc, int d, CovParams p, int mode)
+// tile t of the lower triangle, row-major: t = tr(tr+1)/2 + tc
+__device__ __forceinline__ void lower_tile(long t, int &tr, int &tc)
 {
-	int tr = blockIdx.y, tc = blockIdx.x;
-	if (mode & FILL_LOWER) {
-		// 1-D grid over the lower-triangular tiles only (row-major: t = tr(tr+1)/2 + tc): empty workgroups are not
-		// free, the dispatcher deals them in order like any other
-		const long t = blockIdx.x;
-		int r = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-		while ((long)r * (r + 1) / 2 > t) r--;
-		while ((long)(r + 1) * (r + 2) / 2 <= t) r++;
-		tr = r;
-		tc = (int)(t - (long)r * (r + 1) / 2);
-	}
+	int r = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+	while ((long)r * (r + 1) / 2 > t) r--;
+	while ((long)(r + 1) * (r + 2) / 2 <= t) r++;
+	tr = r;
+	tc = (int)(t - (long)r * (r + 1) / 2);
+}
 
+// one FT x FT tile (tr, tc) of the fill
+__device__ __forceinline__ void cov_fill_tile(double *out, long ld, const double *Xr, int nr, const double *Xc, int nc, int d,
+                                              const CovParams &p, int mode, int tr, int tc)
+{
 	__shared__ double xr_s[FT * (GPEMU_MAX_PARAMS + 1)];
 	__shared__ double tab[32];
 	const int tid = threadIdx.x;
@@ -140,6 +139,51 @@ __global__ __launch_bounds__(256) void cov_fill_kernel(double *out, long ld, con
 	}
 }
 
+__global__ __launch_bounds__(256) void cov_fill_kernel(double *out, long ld, const double *Xr, int nr,
+                                                       const double *Xc, int nc, int d, CovParams p, int mode)
+{
+	int tr = blockIdx.y, tc = blockIdx.x;
+	// FILL_LOWER: 1-D grid over the lower-triangular tiles only: empty workgroups are not free, the dispatcher deals
+	// them in order like any other
+	if (mode & FILL_LOWER) lower_tile(blockIdx.x, tr, tc);
+	cov_fill_tile(out, ld, Xr, nr, Xc, nc, d, p, mode, tr, tc);
+}
+
+// Staging of a lock-step batch in ONE launch: matrix blockIdx.y gets its lower-triangular fill with its own
+// hyper-parameters pp[blockIdx.y] (workgroups 0 .. ntiles-1) and a copy of the shared R rows [y H]^T below it
+// (workgroups ntiles ..: one FT x FT block each).  Per-matrix launches and copies cost ~12 us each on the host and the
+// stream: 1 ms per batch of 64, which is all a batch of small models (N < 1000) takes.
+__global__ __launch_bounds__(256) void cov_stage_batch_kernel(double *T, long ld, long bstride, const double *X, int N, int Np,
+                                                              int d, const CovParams *pp, int mode, const double *Rrows, int Rp)
+{
+	double *out = T + (long)blockIdx.y * bstride;
+	const long nt = Np / FT, ntiles = nt * (nt + 1) / 2;
+	if ((long)blockIdx.x < ntiles) {
+		int tr, tc;
+		lower_tile(blockIdx.x, tr, tc);
+		cov_fill_tile(out, ld, X, N, X, N, d, pp[blockIdx.y], mode, tr, tc);
+		return;
+	}
+	const long rb = blockIdx.x - ntiles;              // block (rb / nt, rb % nt) of the Rp x Np rows
+	const int r0 = (int)(rb / nt) * FT, c0 = (int)(rb % nt) * FT;
+	double *dst = out + (long)Np * ld;
+	for (int e = threadIdx.x; e < FT * FT; e += 256) {
+		const int r = r0 + (e >> 6), c = c0 + (e & 63);
+		if (r < Rp) dst[(long)r * ld + c] = Rrows[(long)r * Np + c];
+	}
+}
+
+hipError_t launch_cov_stage_batch(hipStream_t s, double *T, long ld, long bstride, int nb, const double *X, int N, int Np, int d,
+                                  const CovParams *pp_dev, int mode, const double *Rrows, int Rp)
+{
+	if (Np % FT || FT != 64) return hipErrorInvalidValue;
+	const long nt = Np / FT;
+	const long blocks = nt * (nt + 1) / 2 + ((Rp + FT - 1) / FT) * nt;
+	hipLaunchKernelGGL(cov_stage_batch_kernel, dim3((unsigned)blocks, nb), dim3(256), 0, s, T, ld, bstride, X, N, Np, d, pp_dev,
+	                   mode, Rrows, Rp);
+	return hipGetLastError();
+}
+
 hipError_t launch_cov_fill(hipStream_t s, double *out, long ld, const double *Xr, int nr, int nr_pad,
                            const double *Xc, int nc, int nc_pad, int d, const CovParams &p, int mode)
 {
@@ -206,17 +250,18 @@ hipError_t launch_build_rrows(hipStream_t s, double *R, int Np, int Rp, const do
 	return hipGetLastError();
 }
 
-__global__ void set_identity_rows_kernel(double *T, long ld, int n)
+__global__ void set_identity_rows_kernel(double *T, long ld, int n, long bstride)
 {
+	T += (long)blockIdx.z * bstride;
 	const long i = blockIdx.y;
 	const int j = blockIdx.x * blockDim.x + threadIdx.x;
 	if (j < n) T[i * ld + j] = (i == j) ? 1.0 : 0.0;
 }
 
-hipError_t launch_set_identity_rows(hipStream_t s, double *T, long ld, int n)
+hipError_t launch_set_identity_rows(hipStream_t s, double *T, long ld, int n, int nbatch, long bstride)
 {
-	dim3 grid((n + 255) / 256, n);
-	hipLaunchKernelGGL(set_identity_rows_kernel, grid, dim3(256), 0, s, T, ld, n);
+	dim3 grid((n + 255) / 256, n, nbatch);
+	hipLaunchKernelGGL(set_identity_rows_kernel, grid, dim3(256), 0, s, T, ld, n, bstride);
 	return hipGetLastError();
 }
 
