@@ -453,7 +453,9 @@ static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv)
 	// panel and gains from the larger K of its trailing updates and the fewer read-modify-write passes over the
 	// trailing matrix (measured at 2x16, N=8192: 3.77 ms per evaluation at 512, 3.55 at 1024 with the first GEMM
 	// epilogue; 3.329 at 1024, 3.302 at 2048, 3.314 at 4096 now; 2048 also wins at N = 4096, 12288, 16384)
-	const int nb_top = g_nb_top > 0 ? g_nb_top : (ctx->nb >= 2 ? 2048 : 512);
+	// With the inverse rows under the matrix (gradient, explicit inverse) 1024 is better again: 10.40 against 10.77 ms
+	// per value+gradient evaluation in batches of 16.
+	const int nb_top = g_nb_top > 0 ? g_nb_top : (ctx->nb >= 2 ? (inv ? 1024 : 2048) : 512);
 	if (n > nb_top) {
 		// right-looking over panels of nb_top columns: the trailing update touches the whole remaining
 		// matrix (thousands of tiles, K = panel width), which fills the chip far better than the few huge-K
@@ -1111,8 +1113,8 @@ static int grad_chunk_size(const gpemu_ctx *ctx, int nb)
 }
 
 // gradients of the batch elements b0 .. b0+nbc-1 whose likelihood pieces are in liks[] (elements with liks[i] == nullptr
-// -- not positive definite -- are skipped): one batched C^-1 = U U^T product, one reduction launch per element, one
-// download and one synchronisation for the chunk.
+// -- not positive definite -- are computed and ignored): one batched C^-1 = U U^T product, one reduction launch, one
+// upload, one download and one synchronisation for the chunk.
 static int grad_finish_chunk(gpemu_ctx *ctx, int b0, int nbc, const double *const *th /* full thetas, th[0] = 0 */,
                              const HostLik *const *liks, double *const *grad)
 {
@@ -1120,55 +1122,44 @@ static int grad_finish_chunk(gpemu_ctx *ctx, int b0, int nbc, const double *cons
 	if (rc) return rc;
 	const int N = ctx->N, d = ctx->d, Rp = ctx->Rp;
 	const size_t dim = ctx->S_dim, sstride = dim * dim;
-	// alpha = C^-1 y = column 0 of the [I rows x R cols] block (scratch kept with the context: hipMalloc/hipFree per
-	// call are synchronous and cost more than the reduction kernel)
-	const size_t aslot = (size_t)ctx->Np + GPEMU_MAX_PARAMS;
+	// the length thetas of the chunk in one upload (2-D: they sit behind each corner's alpha scratch), one gather + one
+	// reduction launch for all its corners, one download, one synchronisation
+	const size_t gslot = (size_t)ctx->Np + GPEMU_MAX_PARAMS;
 	if (ctx->alpha_cap < nbc) {
 		if (ctx->dAlpha) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); hipFree(ctx->dAlpha); ctx->dAlpha = nullptr; }
 		ctx->alpha_cap = 0;
-		HIPCHK(ctx, hipMalloc(&ctx->dAlpha, (size_t)nbc * aslot * sizeof(double)));
+		HIPCHK(ctx, hipMalloc(&ctx->dAlpha, (size_t)nbc * gslot * sizeof(double)));
 		ctx->alpha_cap = nbc;
 	}
 	const int nt = (N + 63) / 64, ntiles = nt * (nt + 1) / 2;
-	const size_t need = (size_t)ntiles * (2 * d + 1);
+	const int np = 2 * d + 2;
+	const size_t need = (size_t)ntiles * np;
 	if (ctx->gradpart_len < need * nbc) {
 		if (ctx->dGradPart) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); hipFree(ctx->dGradPart); }
 		ctx->dGradPart = nullptr; ctx->gradpart_len = 0;
 		HIPCHK(ctx, hipMalloc(&ctx->dGradPart, need * nbc * sizeof(double)));
 		ctx->gradpart_len = need * nbc;
 	}
-	std::vector<double> part(need * nbc), alpha((size_t)N * nbc);
-	hipError_t e = hipSuccess;
+	std::vector<double> part(need * nbc), gph((size_t)nbc * GPEMU_MAX_PARAMS, 0.0);
+	for (int i = 0; i < nbc; i++)
+		for (int k = 0; k < d; k++) gph[(size_t)i * GPEMU_MAX_PARAMS + k] = th[i][2 + k];
 	int nparts = 0;
-	for (int i = 0; i < nbc && e == hipSuccess; i++) {
-		if (!liks[i]) continue;
-		double *dAlpha = ctx->dAlpha + (size_t)i * aslot, *dGp = dAlpha + ctx->Np;
-		const double *S = ctx->dS + (size_t)i * sstride;
-		e = hipMemcpy2DAsync(dAlpha, sizeof(double), S + (size_t)Rp * dim, dim * sizeof(double), sizeof(double), N,
-		                     hipMemcpyDeviceToDevice, ctx->stream);
-		if (e == hipSuccess)
-			e = hipMemcpyAsync(dGp, th[i] + 2, (size_t)d * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-		if (e == hipSuccess)
-			e = launch_grad_partials(ctx->stream, S, (long)dim, Rp, ctx->dX, N, d, dAlpha, ctx->kind, dGp,
-			                         ctx->dGradPart + (size_t)i * need, &nparts);
-		if (e == hipSuccess)
-			e = hipMemcpyAsync(part.data() + (size_t)i * need, ctx->dGradPart + (size_t)i * need, need * sizeof(double),
-			                   hipMemcpyDeviceToHost, ctx->stream);
-		if (e == hipSuccess)
-			e = hipMemcpyAsync(alpha.data() + (size_t)i * N, dAlpha, (size_t)N * sizeof(double), hipMemcpyDeviceToHost,
-			                   ctx->stream);
-	}
+	hipError_t e = hipMemcpy2DAsync(ctx->dAlpha + ctx->Np, gslot * sizeof(double), gph.data(), GPEMU_MAX_PARAMS * sizeof(double),
+	                                GPEMU_MAX_PARAMS * sizeof(double), nbc, hipMemcpyHostToDevice, ctx->stream);
+	if (e == hipSuccess)
+		e = launch_grad_partials(ctx->stream, ctx->dS, (long)dim, Rp, (long)sstride, nbc, ctx->dX, N, d, ctx->dAlpha, ctx->Np,
+		                         (long)gslot, ctx->dGradPart, (long)need, &nparts);
+	if (e == hipSuccess)
+		e = hipMemcpyAsync(part.data(), ctx->dGradPart, need * nbc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
 	HIPCHK(ctx, e);
 	for (int i = 0; i < nbc; i++) {
 		if (!liks[i]) continue;
-		std::vector<double> sums(2 * d + 1, 0.0);
+		std::vector<double> sums(np, 0.0);
 		const double *pi = part.data() + (size_t)i * need;
 		for (int t = 0; t < nparts; t++)
-			for (int k = 0; k < 2 * d + 1; k++) sums[k] += pi[(size_t)t * (2 * d + 1) + k];
-		double aa = 0.0;
-		const double *ai = alpha.data() + (size_t)i * N;
-		for (int j = 0; j < N; j++) aa += ai[j] * ai[j];
+			for (int k = 0; k < np; k++) sums[k] += pi[(size_t)t * np + k];
+		const double aa = sums[2 * d + 1];
 		const double amp = exp(log(liks[i]->sigma2));     // maxmultimin.c:503,514
 		const double nug = exp(th[i][1]);                 // :515
 		// G(dC) = -1/2 tr(A dC) + 1/2 alpha^T dC alpha ;  grad = -G   (:527,535; getGradientCn :571-608)

@@ -137,7 +137,7 @@ struct gpemu_ctx {
 	gpemu::CovParams *hParams = nullptr;   // pinned upload ring: PARAM_RING x GPEMU_MAX_BATCH slots, one event per ring entry
 	hipEvent_t param_ev[4] = {nullptr, nullptr, nullptr, nullptr};
 	unsigned param_next = 0;
-	double *dAlpha = nullptr;    // per corner: Np doubles of alpha = C^-1 y, then GPEMU_MAX_PARAMS length-scale thetas
+	double *dAlpha = nullptr;    // gradient, per corner in flight: Np doubles of alpha = C^-1 y, then GPEMU_MAX_PARAMS length thetas
 	int alpha_cap = 0;
 	size_t gradpart_len = 0;     // doubles of dGradPart (all corners)
 
@@ -165,8 +165,8 @@ hipError_t launch_transpose(hipStream_t s, double *dst, long ldd, const double *
 hipError_t launch_predict_finish(hipStream_t s, const double *V, long ldv, int M, int Np, int nreg, int order, int d,
                                  const double *Xq, const double *betaQ, double kappa, double *mean, double *var,
                                  int nslice = 1, long sstride = 0);
-hipError_t launch_grad_partials(hipStream_t s, const double *S, long lds, int soff, const double *X, int N, int d,
-                                const double *alpha, int kind, const double *gp /* d+2 scalars */, double *part, int *nparts);
+hipError_t launch_grad_partials(hipStream_t s, const double *S, long lds, int soff, long sstride, int nb, const double *X, int N,
+                                int d, double *ag, int np_pad, long gstride, double *part, long pstride, int *nparts);
 
 hipError_t launch_deriv_gauss(hipStream_t s, double *out, long ld, const double *xcol, int n, double theta_len);
 hipError_t launch_trace_product(hipStream_t s, const double *A, const double *B, long ld, int n, double *part);

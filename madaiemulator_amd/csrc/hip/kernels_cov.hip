@@ -371,12 +371,27 @@ hipError_t launch_predict_finish(hipStream_t s, const double *V, long ldv, int M
 // plus tr_A = sum_a A_aa for the nugget direction.  A is read from the lower
 // triangle of the corner matrix S (rows/cols offset soff); off-diagonal
 // elements are counted twice.  One 64x64 tile per workgroup (lower tiles only);
-// part[tile][2*d+1].
-// gp[k] = t_k (length thetas, k < d).
+// part[tile][2*d+2]; slot 2d = tr A, slot 2d+1 = this tile's share of alpha^T alpha (diagonal tiles).
+// ag = per element [alpha (np_pad doubles) | gp (length thetas t_k, k < d)], gathered by gather_alpha_kernel: alpha is
+// column 0 of the rows of S under soff (the [I rows x R cols] block of the corner), 66 KB apart at N = 8192 -- read in
+// place by every tile it cost 3 % of a gradient evaluation.
+// blockIdx.y = element of a lock-step batch (strides sstride, gstride, pstride).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void grad_part_kernel(const double *S, long lds_, int soff, const double *X, int N,
-                                                        int d, const double *alpha, const double *gp, double *part)
+__global__ void gather_alpha_kernel(const double *S, long lds_, int soff, long sstride, int N, double *ag, long gstride)
 {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < N) ag[(long)blockIdx.y * gstride + i] = S[(long)blockIdx.y * sstride + (long)(soff + i) * lds_];
+}
+
+__global__ __launch_bounds__(256) void grad_part_kernel(const double *S, long lds_, int soff, long sstride, const double *X,
+                                                        int N, int d, const double *ag, int np_pad, long gstride, double *part,
+                                                        long pstride)
+{
+	S += (long)blockIdx.y * sstride;
+	const double *alpha = ag + (long)blockIdx.y * gstride;
+	const double *gp = alpha + np_pad;
+	part += (long)blockIdx.y * pstride;
+	const int np = 2 * d + 2;
 	// lower-triangular tile index -> (tr, tc)
 	const int t = blockIdx.x;
 	int tr = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
@@ -425,8 +440,15 @@ __global__ __launch_bounds__(256) void grad_part_kernel(const double *S, long ld
 		red[tid] = tsum;
 		__syncthreads();
 		for (int st = 128; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
-		if (tid == 0) part[(long)t * (2 * d + 1) + 2 * d] = red[0];
+		if (tid == 0) part[(long)t * np + 2 * d] = red[0];
 		__syncthreads();
+		// alpha^T alpha, rows of the diagonal tiles in index order
+		if (tid == 0) {
+			double aa = 0.0;
+			if (tr == tc)
+				for (int r = 0; r < 64; r++) aa += ar_s[r] * ar_s[r];
+			part[(long)t * np + 2 * d + 1] = aa;
+		}
 	}
 	for (int k = 0; k < d; k++) {
 		const double th = gp[k];
@@ -443,24 +465,27 @@ __global__ __launch_bounds__(256) void grad_part_kernel(const double *S, long ld
 		red[tid] = s_tr;
 		__syncthreads();
 		for (int st = 128; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
-		if (tid == 0) part[(long)t * (2 * d + 1) + 2 * k] = red[0];
+		if (tid == 0) part[(long)t * np + 2 * k] = red[0];
 		__syncthreads();
 		red[tid] = s_q;
 		__syncthreads();
 		for (int st = 128; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
-		if (tid == 0) part[(long)t * (2 * d + 1) + 2 * k + 1] = red[0];
+		if (tid == 0) part[(long)t * np + 2 * k + 1] = red[0];
 		__syncthreads();
 	}
 }
 
-hipError_t launch_grad_partials(hipStream_t s, const double *S, long lds_, int soff, const double *X, int N, int d,
-                                const double *alpha, int kind, const double *gp, double *part, int *nparts)
+// nb corners sstride apart; ag: nb slots of gstride doubles [alpha scratch (np_pad) | the length thetas]; part: nb blocks
+// of pstride doubles
+hipError_t launch_grad_partials(hipStream_t s, const double *S, long lds_, int soff, long sstride, int nb, const double *X, int N,
+                                int d, double *ag, int np_pad, long gstride, double *part, long pstride, int *nparts)
 {
-	(void)kind;
 	const int nt = (N + 63) / 64;
 	const int ntiles = nt * (nt + 1) / 2;
 	*nparts = ntiles;
-	hipLaunchKernelGGL(grad_part_kernel, dim3(ntiles), dim3(256), 0, s, S, lds_, soff, X, N, d, alpha, gp, part);
+	hipLaunchKernelGGL(gather_alpha_kernel, dim3((N + 255) / 256, nb), dim3(256), 0, s, S, lds_, soff, sstride, N, ag, gstride);
+	hipLaunchKernelGGL(grad_part_kernel, dim3(ntiles, nb), dim3(256), 0, s, S, lds_, soff, sstride, X, N, d, ag, np_pad, gstride,
+	                   part, pstride);
 	return hipGetLastError();
 }
 
