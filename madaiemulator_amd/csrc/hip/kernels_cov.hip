@@ -159,9 +159,15 @@ __global__ __launch_bounds__(256) void cov_stage_batch_kernel(double *T, long ld
 	double *out = T + (long)blockIdx.y * bstride;
 	const long nt = Np / FT, ntiles = nt * (nt + 1) / 2;
 	if ((long)blockIdx.x < ntiles) {
+		// this matrix's hyper-parameters through LDS (the per-dimension scales are indexed per lane)
+		__shared__ CovParams ps;
+		static_assert(sizeof(CovParams) % sizeof(double) == 0, "CovParams is copied as doubles");
+		for (int e = threadIdx.x; e < (int)(sizeof(CovParams) / sizeof(double)); e += 256)
+			reinterpret_cast<double *>(&ps)[e] = reinterpret_cast<const double *>(pp + blockIdx.y)[e];
+		__syncthreads();
 		int tr, tc;
 		lower_tile(blockIdx.x, tr, tc);
-		cov_fill_tile(out, ld, X, N, X, N, d, pp[blockIdx.y], mode, tr, tc);
+		cov_fill_tile(out, ld, X, N, X, N, d, ps, mode, tr, tc);
 		return;
 	}
 	const long rb = blockIdx.x - ntiles;              // block (rb / nt, rb % nt) of the Rp x Np rows
