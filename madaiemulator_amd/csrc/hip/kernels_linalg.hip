@@ -84,9 +84,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 	g.A += (long)blockIdx.y * g.bsA;
 	g.B += (long)blockIdx.y * g.bsB;
 	const int tiles_m = (g.m + BM - 1) / BM;
-	// natural order: consecutive blocks (which the dispatcher deals round-robin over the 8 XCDs) walk down a
-	// tile column, so one XCD keeps re-using 1/8 of the A panels and every B panel; measured equal to grouped /
-	// XCD-chunked orders at these sizes (the operands sit in the 256 MB Infinity Cache).
+	// Tile order.  Launches of >= 512 tiles take it from the XCD-blocked table (order_mode 3, gemm_tile_table below);
+	// smaller ones walk down tile columns (dense enumeration of the lower triangle, order_mode 2, or the plain 2-D
+	// order): equally fast at these sizes -- the operands sit in the 256 MB Infinity Cache -- with more fabric traffic.
 	int tm, tn;
 	if (g.order_mode == 3) {
 		// XCD-blocked order from a host-built table (gemm_tile_table below)
