@@ -1518,6 +1518,17 @@ extern "C" int gpemu_test_gemm_nt(gpemu_ctx *ctx, int m, int n, int k, double al
 	return GPEMU_OK;
 }
 
+// the GEMM tile order of a launch with tiles_m x tiles_n tiles (tri: lower triangle only) and super-blocks of side sb:
+// pure host logic, no device needed.  Returns the table length; fills out[0 .. min(len, cap)).
+extern "C" int gpemu_test_tile_table(int tiles_m, int tiles_n, int tri, int sb, int *out, int cap)
+{
+	if (tiles_m < 1 || tiles_n < 1 || tiles_m > 32767 || tiles_n > 32767 || sb < 1) return GPEMU_ERR_ARG;
+	const std::vector<int> t = gpemu::build_tile_table(tiles_m, tiles_n, tri, sb);
+	if (out)
+		for (int i = 0; i < (int)t.size() && i < cap; i++) out[i] = t[i];
+	return (int)t.size();
+}
+
 namespace gpemu { extern int g_gemm_force_cfg; hipError_t launch_fill_random(hipStream_t s, double *p, size_t n, unsigned seed); }
 
 // times `reps` launches of one GEMM shape with HIP events on the ctx stream (device-resident random operands)

@@ -467,17 +467,11 @@ struct TileTable { int *dptr; int len; };
 static std::map<std::tuple<int, int, int, int, int>, TileTable> g_tile_tables;
 static std::mutex g_tile_mutex;
 
-static TileTable gemm_tile_table(hipStream_t s, int tiles_m, int tiles_n, int tri)
+// host-only part (no HIP call: the CPU tests check it through gpemu_test_tile_table): entry w = q * 8 + x of the table is
+// the q-th tile of XCD x, (tm << 16) | tn, or -1 in the unused tail slots of the shorter shares
+std::vector<int> build_tile_table(int tiles_m, int tiles_n, int tri, int S)
 {
-	int dev = 0;
-	(void)hipGetDevice(&dev);
-	const auto key = std::make_tuple(dev, tiles_m, tiles_n, tri, g_gemm_table);
-	std::lock_guard<std::mutex> lock(g_tile_mutex);
-	auto it = g_tile_tables.find(key);
-	if (it != g_tile_tables.end()) return it->second;
-	hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-	if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return TileTable{nullptr, 0};
-	const int S = g_gemm_table;
+	if (S < 1) S = 1;
 	const int sbm = (tiles_m + S - 1) / S, sbn = (tiles_n + S - 1) / S;
 	// all valid tiles, super-block after super-block (column-major over the blocks and inside each)
 	std::vector<int> seq;
@@ -497,6 +491,20 @@ static TileTable gemm_tile_table(hipStream_t s, int tiles_m, int tiles_n, int tr
 		const size_t lo = x * L / 8, hi = (x + 1) * L / 8;
 		for (size_t q = lo; q < hi; q++) table[(q - lo) * 8 + x] = seq[q];
 	}
+	return table;
+}
+
+static TileTable gemm_tile_table(hipStream_t s, int tiles_m, int tiles_n, int tri)
+{
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	const auto key = std::make_tuple(dev, tiles_m, tiles_n, tri, g_gemm_table);
+	std::lock_guard<std::mutex> lock(g_tile_mutex);
+	auto it = g_tile_tables.find(key);
+	if (it != g_tile_tables.end()) return it->second;
+	hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+	if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return TileTable{nullptr, 0};
+	const std::vector<int> table = build_tile_table(tiles_m, tiles_n, tri, g_gemm_table);
 	TileTable tt{nullptr, (int)table.size()};
 	if (hipMalloc(&tt.dptr, table.size() * sizeof(int)) != hipSuccess ||
 	    hipMemcpy(tt.dptr, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {

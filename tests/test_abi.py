@@ -67,3 +67,32 @@ def test_header_is_plain_c_and_links(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "gfx950" in out.stdout, out.stderr
     subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-I", inc, "-x", "c++", "-fsyntax-only", str(src)])
+
+
+def test_gemm_tile_table_is_a_balanced_permutation():
+    """host logic of the XCD-blocked GEMM tile order (kernels_linalg.hip: build_tile_table): every valid tile exactly
+    once, the 8 XCD shares equal to within one tile, unused slots only at the tail of a share, and the tiles of a
+    share taken super-block by super-block"""
+    import numpy as np
+    L = abi.load()
+    for tiles_m, tiles_n, tri, sb in [(60, 60, 1, 8), (57, 8, 0, 8), (1, 1, 1, 8), (3, 700, 0, 8), (33, 33, 1, 5),
+                                      (128, 128, 1, 16), (9, 9, 1, 1), (121, 120, 1, 8)]:
+        n = L.gpemu_test_tile_table(tiles_m, tiles_n, tri, sb, None, 0)
+        assert n > 0 and n % 8 == 0
+        buf = (ctypes.c_int * n)()
+        assert L.gpemu_test_tile_table(tiles_m, tiles_n, tri, sb, buf, n) == n
+        t = np.array(buf[:], dtype=np.int64).reshape(-1, 8)          # row q, column x = q-th tile of XCD x
+        want = {(tm, tn) for tm in range(tiles_m) for tn in range(tiles_n) if not (tri and tn > tm)}
+        got = [(int(e) >> 16, int(e) & 0xffff) for e in t.ravel() if e >= 0]
+        assert len(got) == len(want) and set(got) == want
+        counts = (t >= 0).sum(axis=0)
+        assert counts.max() - counts.min() <= 1
+        for x in range(8):                                           # padding only at the tail of a share
+            col = t[:, x]
+            assert np.all(col[:counts[x]] >= 0) and np.all(col[counts[x]:] < 0)
+        # a share is a contiguous piece of the super-block sequence: the tiles of 64 consecutive slots span few blocks
+        if len(want) >= 8 * 4 * sb * sb:
+            share = [(int(e) >> 16, int(e) & 0xffff) for e in t[:, 3] if e >= 0][:sb * sb]
+            blocks = {(tm // sb, tn // sb) for tm, tn in share}
+            assert len(blocks) <= 4          # (triangular diagonal blocks hold half the tiles)
+    assert L.gpemu_test_tile_table(0, 4, 0, 8, None, 0) < 0 and L.gpemu_test_tile_table(4, 40000, 0, 8, None, 0) < 0
