@@ -202,7 +202,7 @@ int gpemu_test_gemm_bench(gpemu_ctx *ctx, int m, int n, int k, int ld, int cfg, 
 int gpemu_test_potrf(gpemu_ctx *ctx, int n, double *a, int *info);
 /* the workgroup -> tile table of a GEMM launch with tiles_m x tiles_n tiles (tri = 1: lower triangle) and super-blocks
  * of sb x sb tiles: entry q * 8 + x is the q-th tile of XCD x, (tm << 16) | tn, or -1 (unused tail slot).  Host logic
- * only (no device).  Returns the table length (< 0: GPEMU_ERR_*); writes min(length, cap) entries to out. */
+ * only (no device).  Returns the table length, or -GPEMU_ERR_ARG; writes min(length, cap) entries to out. */
 int gpemu_test_tile_table(int tiles_m, int tiles_n, int tri, int sb, int *out, int cap);
 
 #ifdef __cplusplus

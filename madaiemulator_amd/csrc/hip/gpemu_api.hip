@@ -1522,7 +1522,7 @@ extern "C" int gpemu_test_gemm_nt(gpemu_ctx *ctx, int m, int n, int k, double al
 // pure host logic, no device needed.  Returns the table length; fills out[0 .. min(len, cap)).
 extern "C" int gpemu_test_tile_table(int tiles_m, int tiles_n, int tri, int sb, int *out, int cap)
 {
-	if (tiles_m < 1 || tiles_n < 1 || tiles_m > 32767 || tiles_n > 32767 || sb < 1) return GPEMU_ERR_ARG;
+	if (tiles_m < 1 || tiles_n < 1 || tiles_m > 32767 || tiles_n > 32767 || sb < 1) return -GPEMU_ERR_ARG;
 	const std::vector<int> t = gpemu::build_tile_table(tiles_m, tiles_n, tri, sb);
 	if (out)
 		for (int i = 0; i < (int)t.size() && i < cap; i++) out[i] = t[i];
