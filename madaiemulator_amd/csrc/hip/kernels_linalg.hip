@@ -464,23 +464,26 @@ int choose_gemm_cfg(const GemmArgs &a)
 // Tables are built on first use outside stream capture and cached per (device, shape).
 // ---------------------------------------------------------------------------
 struct TileTable { int *dptr; int len; };
-static std::map<std::tuple<int, int, int, int, int>, TileTable> g_tile_tables;
+static std::map<std::tuple<int, int, int, int, int, int, int>, TileTable> g_tile_tables;
 static std::mutex g_tile_mutex;
 
 // host-only part (no HIP call: the CPU tests check it through gpemu_test_tile_table): entry w = q * 8 + x of the table is
 // the q-th tile of XCD x, (tm << 16) | tn, or -1 in the unused tail slots of the shorter shares
-std::vector<int> build_tile_table(int tiles_m, int tiles_n, int tri, int S)
+std::vector<int> build_tile_table(int tiles_m, int tiles_n, int tri, int S, int bm, int bn)
 {
 	if (S < 1) S = 1;
-	const int sbm = (tiles_m + S - 1) / S, sbn = (tiles_n + S - 1) / S;
-	// all valid tiles, super-block after super-block (column-major over the blocks and inside each)
+	// super-blocks of about (128 S)^2 elements whatever the tile shape
+	const int Sm = std::max(1, S * 128 / std::max(bm, 1)), Sn = std::max(1, S * 128 / std::max(bn, 1));
+	const int sbm = (tiles_m + Sm - 1) / Sm, sbn = (tiles_n + Sn - 1) / Sn;
+	// all valid tiles, super-block after super-block (column-major over the blocks and inside each); a tile of a
+	// triangular update is valid when its first column is not beyond its last row
 	std::vector<int> seq;
 	for (int bc = 0; bc < sbn; bc++)
 		for (int br = 0; br < sbm; br++)
-			for (int c = 0; c < S; c++)
-				for (int r = 0; r < S; r++) {
-					const int tm = br * S + r, tn = bc * S + c;
-					if (tm >= tiles_m || tn >= tiles_n || (tri && tn > tm)) continue;
+			for (int c = 0; c < Sn; c++)
+				for (int r = 0; r < Sm; r++) {
+					const int tm = br * Sm + r, tn = bc * Sn + c;
+					if (tm >= tiles_m || tn >= tiles_n || (tri && (long)tn * bn > (long)tm * bm + bm - 1)) continue;
 					seq.push_back((tm << 16) | tn);
 				}
 	// XCD x walks the x-th eighth of that sequence: equal shares (the tail slots of the shorter ones hold -1), and
@@ -494,17 +497,17 @@ std::vector<int> build_tile_table(int tiles_m, int tiles_n, int tri, int S)
 	return table;
 }
 
-static TileTable gemm_tile_table(hipStream_t s, int tiles_m, int tiles_n, int tri)
+static TileTable gemm_tile_table(hipStream_t s, int tiles_m, int tiles_n, int tri, int bm, int bn)
 {
 	int dev = 0;
 	(void)hipGetDevice(&dev);
-	const auto key = std::make_tuple(dev, tiles_m, tiles_n, tri, g_gemm_table);
+	const auto key = std::make_tuple(dev, tiles_m, tiles_n, tri, g_gemm_table, bm, bn);
 	std::lock_guard<std::mutex> lock(g_tile_mutex);
 	auto it = g_tile_tables.find(key);
 	if (it != g_tile_tables.end()) return it->second;
 	hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
 	if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return TileTable{nullptr, 0};
-	const std::vector<int> table = build_tile_table(tiles_m, tiles_n, tri, g_gemm_table);
+	const std::vector<int> table = build_tile_table(tiles_m, tiles_n, tri, g_gemm_table, bm, bn);
 	TileTable tt{nullptr, (int)table.size()};
 	if (hipMalloc(&tt.dptr, table.size() * sizeof(int)) != hipSuccess ||
 	    hipMemcpy(tt.dptr, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
@@ -526,29 +529,34 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs &a_in)
 	}
 	const int nbatch = a.nbatch > 1 ? a.nbatch : 1;
 	const int cfg = choose_gemm_cfg(a);
-	// lower-triangular updates with square tiles enumerate only their non-empty tiles
-	const bool dense_tri = a.tri && a.diag_off == 0 && a.m >= a.n && cfg != 1;
+	// tile shapes: 0 128x128 (4 waves), 1 128x64, 2 64x64, 3 128x128 (8 waves), 4 256x128 (8 waves, one workgroup
+	// per CU), 5 256x128 (16 waves), 6 128x256 (8 waves)
+	static const int k_bm[] = {128, 128, 64, 128, 256, 256, 128}, k_bn[] = {128, 64, 64, 128, 128, 128, 256};
+	if (cfg < 0 || cfg > 6) return hipErrorInvalidValue;
+	const int bm = k_bm[cfg], bn = k_bn[cfg];
+	const int tiles_m = (a.m + bm - 1) / bm, tiles_n = (a.n + bn - 1) / bn;
+	// lower-triangular updates enumerate only their non-empty tiles: square tiles by a closed form, any shape by table
+	const bool tri_ok = a.tri && a.diag_off == 0 && a.m >= a.n;
+	const bool dense_tri = tri_ok && bm == bn;
 	a.order_mode = dense_tri ? 2 : 0;
-	const int bt = (cfg == 2) ? 64 : 128;
-	int T = dense_tri ? (int)count_tiles(a, bt, bt)
-	                  : ((a.m + bt - 1) / bt) * ((a.n + (cfg == 1 ? 63 : bt - 1)) / (cfg == 1 ? 64 : bt));
+	int T = dense_tri ? (int)count_tiles(a, bm, bn) : tiles_m * tiles_n;
 	// (not for the triangular-operand products of the prediction path: their K differs from tile column to tile column, so
 	// equal shares of tiles are unequal shares of work -- measured 2x slower -- and the long-K-first order matters more)
-	if (g_gemm_table && cfg != 1 && T >= 512 && (dense_tri || !a.tri) && !a.kstart_mode && !a.kend_mode) {
-		const int tiles_m = (a.m + bt - 1) / bt, tiles_n = (a.n + bt - 1) / bt;
+	if (g_gemm_table && cfg != 1 && count_tiles(a, bm, bn) >= (bm * bn > 128 * 128 ? 256 : 512) && (tri_ok || !a.tri) &&
+	    !a.kstart_mode && !a.kend_mode) {
 		if (tiles_m < 32768 && tiles_n < 32768) {
-			const TileTable tt = gemm_tile_table(s, tiles_m, tiles_n, dense_tri ? 1 : 0);
+			const TileTable tt = gemm_tile_table(s, tiles_m, tiles_n, tri_ok ? 1 : 0, bm, bn);
 			if (tt.dptr) { a.order_mode = 3; a.tile_table = tt.dptr; T = tt.len; }
 		}
 	}
-	if (cfg == 0) {
-		hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 2>), dim3(T, nbatch), dim3(256), 0, s, a);
-	} else if (cfg == 1) {
-		hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 2>), dim3(T, nbatch), dim3(256), 0, s, a);
-	} else if (cfg == 3) {
-		hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 4, 4, 2>), dim3(T, nbatch), dim3(512), 0, s, a);
-	} else {
-		hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2, 2>), dim3(T, nbatch), dim3(256), 0, s, a);
+	switch (cfg) {
+	case 0: hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 2>), dim3(T, nbatch), dim3(256), 0, s, a); break;
+	case 1: hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 2>), dim3(T, nbatch), dim3(256), 0, s, a); break;
+	case 3: hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 4, 4, 2>), dim3(T, nbatch), dim3(512), 0, s, a); break;
+	case 4: hipLaunchKernelGGL((gemm_nt_kernel<256, 128, 2, 4, 2>), dim3(T, nbatch), dim3(512), 0, s, a); break;
+	case 5: hipLaunchKernelGGL((gemm_nt_kernel<256, 128, 4, 8, 2>), dim3(T, nbatch), dim3(1024), 0, s, a); break;
+	case 6: hipLaunchKernelGGL((gemm_nt_kernel<128, 256, 2, 2, 4>), dim3(T, nbatch), dim3(512), 0, s, a); break;
+	default: hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2, 2>), dim3(T, nbatch), dim3(256), 0, s, a); break;
 	}
 	return hipGetLastError();
 }

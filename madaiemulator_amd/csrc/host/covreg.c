@@ -6,8 +6,8 @@
  * The scalar covariance functions evaluate ONE element (callers use them for kappa =
  * c(x*,x*), emulator_struct.c:135); which of the three a modelstruct points at selects the
  * device kernel.  Whole matrices / vectors are produced on the GPU (gpemu_cov_matrix,
- * gpemu_kvectors).  The derivative-matrix builders exist only as dispatch tokens: the
- * gradient is computed on the device by gradFnMulti and never materialises dC/dtheta.
+ * gpemu_kvectors, gpemu_derivative_gauss).  gradFnMulti itself never materialises dC/dtheta
+ * (device_bridge.c); the derivative-matrix builders below serve callers that want the matrix.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -71,13 +71,6 @@ double covariance_fn_matern_five(gsl_vector *xm, gsl_vector *xn, gsl_vector *the
 	return c;
 }
 
-static void derivative_token(const char *name)
-{
-	fprintf(stderr, "%s: the reference's Matern derivative matrices carry an accumulator from element to element\n"
-	                "(emulator.c:410-425, 506-523) and cannot be produced in parallel; this symbol only identifies the\n"
-	                "covariance function.\n", name);
-	exit(EXIT_FAILURE);
-}
 /* libEmu/emulator.c:173-209, materialised on the device (gradFnMulti itself never forms it) */
 extern gpemu_ctx *gpemu_host_scratch_ctx(const char *where);
 void derivative_l_gauss(gsl_matrix *dCdTheta, gsl_matrix *xmodel, double thetaLength, int index, int nmodel_points, int nparams)
@@ -91,10 +84,49 @@ void derivative_l_gauss(gsl_matrix *dCdTheta, gsl_matrix *xmodel, double thetaLe
 	free(xc);
 	if (rc) { fprintf(stderr, "derivative_l_gauss: gpemu error %d: %s\n", rc, gpemu_last_error(ctx)); exit(EXIT_FAILURE); }
 }
-void derivative_l_matern_three(gsl_matrix *a, gsl_matrix *b, double c, int d, int e, int f)
-{ (void)a; (void)b; (void)c; (void)d; (void)e; (void)f; derivative_token("derivative_l_matern_three"); }
-void derivative_l_matern_five(gsl_matrix *a, gsl_matrix *b, double c, int d, int e, int f)
-{ (void)a; (void)b; (void)c; (void)d; (void)e; (void)f; derivative_token("derivative_l_matern_five"); }
+/* libEmu/emulator.c:401-433.  Literal: `rtemp` is never reset between (i,j) pairs (:410 vs :423-425), so element
+ * (i,j) depends on every element before it in row-major order, and thetaLength is the raw (log-scale) value.  The
+ * recurrence r <- sqrt(r + |x_i - x_j|^2) is a dependent chain of N^2 steps: it runs here, on the host, in the
+ * reference's order (N^2 (d + sqrt + exp) scalar work, about 3 s at N = 8192).  The device never uses these
+ * matrices: its Matern gradient is the analytic one behind GPEMU_EXACT_GRAD (gpemu.h). */
+void derivative_l_matern_three(gsl_matrix *dCdTheta, gsl_matrix *xmodel, double thetaLength, int index, int nmodel_points,
+                               int nparams)
+{
+	(void)index;                                          /* must be 2 (:403) */
+	const double root3 = 1.732050808;
+	double rtemp = 0.0;
+	const double thetaLCubed = thetaLength * thetaLength * thetaLength;
+	for (int i = 0; i < nmodel_points; i++)
+		for (int j = 0; j < nmodel_points; j++) {
+			for (int p = 0; p < nparams; p++) {
+				const double x_temp = gsl_matrix_get(xmodel, i, p), y_temp = gsl_matrix_get(xmodel, j, p);
+				rtemp += (x_temp - y_temp) * (x_temp - y_temp);
+			}
+			rtemp = sqrt(rtemp);
+			gsl_matrix_set(dCdTheta, i, j, 3.0 * exp(-root3 * rtemp / thetaLength) * (rtemp * rtemp / thetaLCubed));
+		}
+}
+
+/* libEmu/emulator.c:497-532 (same carried rtemp; constants 2.2360680, 3.72768, 1.66667 as written there) */
+void derivative_l_matern_five(gsl_matrix *dCdTheta, gsl_matrix *xmodel, double thetaLength, int index, int nmodel_points,
+                              int nparams)
+{
+	(void)index;
+	const double root5 = 2.2360680;
+	double rtemp = 0.0, rsq;
+	const double thetaLCubed = thetaLength * thetaLength * thetaLength;
+	for (int i = 0; i < nmodel_points; i++)
+		for (int j = 0; j < nmodel_points; j++) {
+			for (int p = 0; p < nparams; p++) {
+				const double x_temp = gsl_matrix_get(xmodel, i, p), y_temp = gsl_matrix_get(xmodel, j, p);
+				rtemp += (x_temp - y_temp) * (x_temp - y_temp);
+			}
+			rsq = rtemp;
+			rtemp = sqrt(rtemp);
+			gsl_matrix_set(dCdTheta, i, j,
+			               (rsq / (thetaLCubed)) * exp(-root5 * rtemp / thetaLength) * (3.72768 * rtemp + 1.66667 * thetaLength));
+		}
+}
 
 int gpemu_host_kind_of(double (*fn)(gsl_vector *, gsl_vector *, gsl_vector *, int, int))
 {

@@ -1,6 +1,8 @@
 /* Host-side logic of the libEmu mirror that needs no GPU: the mt19937 generator behind gsl_rng_default, the
  * regression basis, the PCA decomposition of a multi-output training set and the snapshot writer / reader.
- *   host_cpu_driver INPUT_MODEL_FILE SNAPSHOT_OUT SNAPSHOT_OUT2
+ *   host_cpu_driver INPUT_MODEL_FILE SNAPSHOT_OUT SNAPSHOT_OUT2 [DERIV_OUT]
+ * DERIV_OUT: raw doubles, derivative_l_matern_three then derivative_l_matern_five of the design at thetaLength 0.7
+ * (libEmu/emulator.c:401-433, 497-532: the literal sequential recurrence, host code)
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -72,5 +74,18 @@ int main(int argc, char **argv)
 	dump_multi_modelstruct(out, m2);
 	fclose(out);
 	printf("loaded nt %d nr %d N %d d %d\n", m2->nt, m2->nr, m2->nmodel_points, m2->nparams);
+	if (argc > 4) {
+		const int n = (int)x->size1;
+		gsl_matrix *dC = gsl_matrix_alloc(n, n);
+		FILE *df = fopen(argv[4], "wb");
+		if (!df) return 4;
+		derivative_l_matern_three(dC, x, 0.7, 2, n, (int)x->size2);
+		for (int i = 0; i < n; i++) fwrite(gsl_matrix_ptr(dC, i, 0), sizeof(double), (size_t)n, df);
+		derivative_l_matern_five(dC, x, 0.7, 2, n, (int)x->size2);
+		for (int i = 0; i < n; i++) fwrite(gsl_matrix_ptr(dC, i, 0), sizeof(double), (size_t)n, df);
+		fclose(df);
+		gsl_matrix_free(dC);
+		printf("deriv %d\n", n);
+	}
 	return 0;
 }

@@ -63,7 +63,8 @@ def test_host_library_exports_reference_symbols():
                  "makeEmulatedVariance", "callEvalLhoodList", "evalFnMultiList", "emulate_points", "makeCovMatrix",
                  "makeKVector", "makeHMatrix", "covariance_fn", "makeHVector", "makeGradMatLength", "getGradientCn",
                  "makeHMatrix_es", "makeCovMatrix_es", "makeKVector_es", "estimateBeta_es", "callEstimate",
-                 "callEmulateAtList", "callEmulateAtPt", "derivative_l_gauss", "setupEmulateMC", "callEmulateMC",
+                 "callEmulateAtList", "callEmulateAtPt", "derivative_l_gauss", "derivative_l_matern_three",
+                 "derivative_l_matern_five", "setupEmulateMC", "callEmulateMC",
                  "freeEmulateMC", "setupEmulateMCMulti", "callEmulateMCMulti", "freeEmulateMCMulti"):
         assert hasattr(lib, name), name
 
@@ -76,8 +77,8 @@ def test_host_logic_without_gpu(tmp_path):
     subprocess.check_call(["gcc", "-std=gnu99", "-O1", "-I", os.path.join(ROOT, "include"), "-I", build.HOST_SRC,
                            "-o", exe, os.path.join(ROOT, "tests", "c", "host_cpu_driver.c"),
                            "-L", build.LIBDIR, "-lEmuMI", "-lgpemu_hip", f"-Wl,-rpath,{build.LIBDIR}", "-lm"])
-    s1, s2 = tmp_path / "snap1", tmp_path / "snap2"
-    out = subprocess.run([exe, MULTI, str(s1), str(s2)], capture_output=True, text=True, timeout=120)
+    s1, s2, dfile = tmp_path / "snap1", tmp_path / "snap2", tmp_path / "deriv.bin"
+    out = subprocess.run([exe, MULTI, str(s1), str(s2), str(dfile)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr[-2000:]
     res = parse(out.stdout)
     # MT19937, init_genrand(5489): Matsumoto & Nishimura's reference output
@@ -103,6 +104,13 @@ def test_host_logic_without_gpu(tmp_path):
     z0 = (Yc[0] @ E) / np.sqrt(np.array(res["evals"][0]))
     assert np.allclose(res["z0"][0], z0, rtol=1e-9, atol=1e-12)
     assert s1.read_bytes() == s2.read_bytes() and len(s1.read_bytes()) > 100
+    # a6: derivative_l_matern_three / _five (emulator.c:401-433, 497-532), the literal recurrence with the carried
+    # rtemp -- host code, bit for bit the oracle's restatement
+    n = len(X)
+    dd = np.fromfile(dfile, dtype=np.float64).reshape(2, n, n)
+    assert np.array_equal(dd[0], O.derivative_l(2, X, 0.7, 2))
+    assert np.array_equal(dd[1], O.derivative_l(3, X, 0.7, 2))
+    assert not np.allclose(dd[0], dd[0].T)               # path dependent: not even symmetric
 
 
 @pytest.mark.gpu
