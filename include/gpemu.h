@@ -104,6 +104,23 @@ int gpemu_loglik_batch_enqueue(gpemu_ctx *ctx, int nb, const double *thetas, int
 int gpemu_loglik_batch_collect(gpemu_ctx *ctx, int nb, double *neg_loglik, double *sigma2,
                                double *beta, double *logdet, double *quad, int *info, int *status);
 
+/* ---- modes (SURVEY App. C2-C4 policy: literal by default, corrected forms behind flags) ----------------------
+ * GPEMU_MODE_EXACT_GRAD: gpemu_grad / gpemu_loglik_grad[_batch] return the TRUE gradient of the value gpemu_loglik
+ *   returns at theta[0] = 0, d(-logL)/dtheta_k = 1/2 tr(C^-1 dC_k) - 1/2 r^T C^-1 dC_k C^-1 r with r = y - H beta and
+ *   the true dC/dtheta (pow-exp: full kernel value times D_k^2 e^{-2 theta_k}; Matern: analytic in log rho; nugget
+ *   wherever the nugget rule adds it) instead of the reference's literal formulas (emulator.c:173-209 keeps one
+ *   coordinate's factor; maxmultimin.c:514,532,594 scale by sigma^2 and use y).
+ * GPEMU_MODE_MATERN_LOG: the Matern kernels take amplitude and nugget on the log scale (amp = e^theta0, nug =
+ *   e^theta1) like the pow-exp kernel, instead of raw (emulator.c:355-356,448-449) -- with the raw form evalFnMulti's
+ *   theta[0] = 0 (maxmultimin.c:311) makes C = theta1 * I and the reference cannot train a Matern model at all.
+ *   Applies to fill, likelihood and prediction alike; a snapshot trained with it must be queried with it.
+ * Matern gradients exist only with both flags.  Defaults come from the environment when the context is created
+ * (GPEMU_EXACT_GRAD=1, GPEMU_MATERN_FIXED=1); both off = the reference's literal behaviour. */
+#define GPEMU_MODE_EXACT_GRAD 1
+#define GPEMU_MODE_MATERN_LOG 2
+int gpemu_set_mode(gpemu_ctx *ctx, int flags);
+int gpemu_get_mode(const gpemu_ctx *ctx);
+
 /* ---- a12: gradFnMulti + getGradientCn (maxmultimin.c:416-550,571-608)
  * grad[nthetas-1] as the reference defines it (literal formulas, SURVEY
  * App. A.3): thetas are the FULL vector with theta[0] ignored (set to 0 for
@@ -149,8 +166,10 @@ int gpemu_chol_inverse(gpemu_ctx *ctx, int n, double *a_inout, int lda, double *
 /* the C^-1-times-vector products of estimateBeta / getLogLikelyhood / makeEmulatedMean / makeEmulatedVariance
  * (libEmu/regression.c:120-176, estimator-fns.c:38-103, emulator.c:672-785) with C^-1 passed in host memory:
  * out[v*n + i] = sum_j a[i*lda + j] * v_rows[v*n + j] for nvec vectors stored as rows.  The matrix is uploaded when
- * its (pointer, size, fingerprint) differs from the copy the context holds. */
+ * its (pointer, size, 64-bit checksum over ALL its elements) differs from the copy the context holds: callers such as
+ * the libRbind loops rewrite one cinverse buffer in place.  gpemu_symm_invalidate drops the cached copy explicitly. */
 int gpemu_symm_apply(gpemu_ctx *ctx, int n, const double *a, int lda, int nvec, const double *v_rows, double *out_rows);
+int gpemu_symm_invalidate(gpemu_ctx *ctx);
 /* a5 derivative_l_gauss (libEmu/emulator.c:173-209) written out: out[i*ldo + j] = exp(-0.5 e^{-2t} D^2 - 2t) D^2,
  * D = xcol[i] - xcol[j] (the ONE design coordinate the reference's formula looks at), t = theta_len */
 int gpemu_derivative_gauss(gpemu_ctx *ctx, int n, const double *xcol, double theta_len, double *out, int ldo);

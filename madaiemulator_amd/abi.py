@@ -15,6 +15,7 @@ POWEREXP, MATERN32, MATERN52 = 1, 2, 3
 
 OK, ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_PD, ERR_REGRESSION, ERR_STATE = range(7)
 PROF_NONE, PROF_GEMM, PROF_FILL, PROF_LEAF, PROF_POTRF = range(5)
+MODE_EXACT_GRAD, MODE_MATERN_LOG = 1, 2
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -47,6 +48,9 @@ SYMBOLS = {
     "gpemu_predict_batch_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpemu_chol_inverse": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, _dp, _ip]),
     "gpemu_symm_apply": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp]),
+    "gpemu_symm_invalidate": (C.c_int, [C.c_void_p]),
+    "gpemu_set_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "gpemu_get_mode": (C.c_int, [C.c_void_p]),
     "gpemu_derivative_gauss": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_double, _dp, C.c_int]),
     "gpemu_trace_product": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp]),
     "gpemu_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -267,6 +271,15 @@ class Context:
         out = np.empty_like(V)
         self._chk(self.L.gpemu_symm_apply(self.h, A.shape[0], _p(A), A.shape[1], V.shape[0], _p(V), _p(out)))
         return out
+
+    def set_mode(self, flags):
+        self._chk(self.L.gpemu_set_mode(self.h, int(flags)))
+
+    def get_mode(self):
+        return self.L.gpemu_get_mode(self.h)
+
+    def symm_invalidate(self):
+        self._chk(self.L.gpemu_symm_invalidate(self.h))
 
     def derivative_gauss(self, xcol, theta_len):
         xcol = _a(xcol)

@@ -186,6 +186,11 @@ extern "C" int gpemu_ctx_create(gpemu_ctx **out, int device)
 	}
 	const char *ng = getenv("GPEMU_NO_GRAPH");
 	if (ng && ng[0] == '1') ctx->use_graph = false;
+	{
+		const char *eg = getenv("GPEMU_EXACT_GRAD"), *mf = getenv("GPEMU_MATERN_FIXED");
+		if (eg && atoi(eg) > 0) ctx->mode |= GPEMU_MODE_EXACT_GRAD;
+		if (mf && atoi(mf) > 0) ctx->mode |= GPEMU_MODE_MATERN_LOG;
+	}
 	if (!ok) {
 		(void)hipGetLastError();
 		gpemu_ctx_destroy(ctx);
@@ -239,6 +244,15 @@ extern "C" void gpemu_ctx_destroy(gpemu_ctx *ctx)
 	if (ctx->stream) hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
+
+extern "C" int gpemu_set_mode(gpemu_ctx *ctx, int flags)
+{
+	if (!ctx || (flags & ~(GPEMU_MODE_EXACT_GRAD | GPEMU_MODE_MATERN_LOG))) return GPEMU_ERR_ARG;
+	if (flags != ctx->mode) { ctx->pred_ready = false; ctx->cinv_ready = false; }   // the kernel's meaning may have changed
+	ctx->mode = flags;
+	return GPEMU_OK;
+}
+extern "C" int gpemu_get_mode(const gpemu_ctx *ctx) { return ctx ? ctx->mode : 0; }
 
 extern "C" const char *gpemu_last_error(const gpemu_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 
@@ -383,8 +397,12 @@ static int make_cov_params(gpemu_ctx *ctx, const double *thetas, int nthetas, Co
 		}
 		p->cand = 2.0 * ctx->d * (p->eps * wmax) * (p->eps * wmax) + 1e-300;
 	} else {
-		p->amp = thetas[0];
-		p->nug = thetas[1];
+		// literal (emulator.c:355-356, 448-449): amplitude and nugget are used as they come.  GPEMU_MODE_MATERN_LOG
+		// (SURVEY App. C2 "fixed mode"): both on the log scale like the pow-exp kernel's, so that evalFnMulti's
+		// theta[0] = 0 (maxmultimin.c:311) means amplitude 1 and the model can be trained.
+		const bool logscale = (ctx->mode & GPEMU_MODE_MATERN_LOG) != 0;
+		p->amp = logscale ? exp(thetas[0]) : thetas[0];
+		p->nug = logscale ? exp(thetas[1]) : thetas[1];
 		p->eps = 0.0000000000000001;
 		p->w[0] = 1.0 / exp(thetas[2]);
 		p->cand = 2.0 * ctx->d * (p->eps * p->w[0]) * (p->eps * p->w[0]) + 1e-300;
@@ -1122,9 +1140,12 @@ static int grad_finish_chunk(gpemu_ctx *ctx, int b0, int nbc, const double *cons
 	if (rc) return rc;
 	const int N = ctx->N, d = ctx->d, Rp = ctx->Rp;
 	const size_t dim = ctx->S_dim, sstride = dim * dim;
-	// the length thetas of the chunk in one upload (2-D: they sit behind each corner's alpha scratch), one gather + one
-	// reduction launch for all its corners, one download, one synchronisation
-	const size_t gslot = (size_t)ctx->Np + GPEMU_MAX_PARAMS;
+	// the length thetas (and, exact mode, the regression coefficients) of the chunk in one upload (2-D: they sit behind
+	// each corner's alpha scratch), one gather + one reduction launch for all its corners, one download, one
+	// synchronisation
+	const bool exact = (ctx->mode & GPEMU_MODE_EXACT_GRAD) != 0;
+	const int nlen = ctx->kind == GPEMU_POWEREXP ? d : 1;           // length-scale directions
+	const size_t gslot = (size_t)ctx->Np + 2 * GPEMU_MAX_PARAMS;
 	if (ctx->alpha_cap < nbc) {
 		if (ctx->dAlpha) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); hipFree(ctx->dAlpha); ctx->dAlpha = nullptr; }
 		ctx->alpha_cap = 0;
@@ -1140,15 +1161,19 @@ static int grad_finish_chunk(gpemu_ctx *ctx, int b0, int nbc, const double *cons
 		HIPCHK(ctx, hipMalloc(&ctx->dGradPart, need * nbc * sizeof(double)));
 		ctx->gradpart_len = need * nbc;
 	}
-	std::vector<double> part(need * nbc), gph((size_t)nbc * GPEMU_MAX_PARAMS, 0.0);
-	for (int i = 0; i < nbc; i++)
-		for (int k = 0; k < d; k++) gph[(size_t)i * GPEMU_MAX_PARAMS + k] = th[i][2 + k];
+	std::vector<double> part(need * nbc), gph((size_t)nbc * 2 * GPEMU_MAX_PARAMS, 0.0);
+	for (int i = 0; i < nbc; i++) {
+		for (int k = 0; k < nlen; k++) gph[(size_t)i * 2 * GPEMU_MAX_PARAMS + k] = th[i][2 + k];
+		if (exact && liks[i])
+			for (int a = 0; a < ctx->nreg; a++) gph[(size_t)i * 2 * GPEMU_MAX_PARAMS + GPEMU_MAX_PARAMS + a] = liks[i]->beta[a];
+	}
 	int nparts = 0;
-	hipError_t e = hipMemcpy2DAsync(ctx->dAlpha + ctx->Np, gslot * sizeof(double), gph.data(), GPEMU_MAX_PARAMS * sizeof(double),
-	                                GPEMU_MAX_PARAMS * sizeof(double), nbc, hipMemcpyHostToDevice, ctx->stream);
+	hipError_t e = hipMemcpy2DAsync(ctx->dAlpha + ctx->Np, gslot * sizeof(double), gph.data(), 2 * GPEMU_MAX_PARAMS * sizeof(double),
+	                                2 * GPEMU_MAX_PARAMS * sizeof(double), nbc, hipMemcpyHostToDevice, ctx->stream);
 	if (e == hipSuccess)
 		e = launch_grad_partials(ctx->stream, ctx->dS, (long)dim, Rp, (long)sstride, nbc, ctx->dX, N, d, ctx->dAlpha, ctx->Np,
-		                         (long)gslot, ctx->dGradPart, (long)need, &nparts);
+		                         (long)gslot, ctx->dGradPart, (long)need, &nparts, exact ? ctx->kind : 0, ctx->nreg,
+		                         ctx->dParams + b0);
 	if (e == hipSuccess)
 		e = hipMemcpyAsync(part.data(), ctx->dGradPart, need * nbc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1159,6 +1184,12 @@ static int grad_finish_chunk(gpemu_ctx *ctx, int b0, int nbc, const double *cons
 		const double *pi = part.data() + (size_t)i * need;
 		for (int t = 0; t < nparts; t++)
 			for (int k = 0; k < np; k++) sums[k] += pi[(size_t)t * np + k];
+		if (exact) {
+			// d(-logL)/dtheta = 1/2 sum_ab (A_ab - alpha_a alpha_b) dC_ab: slot nlen = nugget direction, slots < nlen the lengths
+			grad[i][0] = 0.5 * sums[nlen];
+			for (int k = 0; k < nlen; k++) grad[i][k + 1] = 0.5 * sums[k];
+			continue;
+		}
 		const double aa = sums[2 * d + 1];
 		const double amp = exp(log(liks[i]->sigma2));     // maxmultimin.c:503,514
 		const double nug = exp(th[i][1]);                 // :515
@@ -1179,11 +1210,13 @@ static int grad_finish(gpemu_ctx *ctx, int b, const double *th, const HostLik &r
 static int grad_check_args(gpemu_ctx *ctx, int nthetas)
 {
 	if (!ctx->dX) return fail(ctx, GPEMU_ERR_STATE, "model not set");
-	if (ctx->kind != GPEMU_POWEREXP)
+	const int trainable_matern = (ctx->mode & GPEMU_MODE_EXACT_GRAD) && (ctx->mode & GPEMU_MODE_MATERN_LOG);
+	if (ctx->kind != GPEMU_POWEREXP && !trainable_matern)
 		return fail(ctx, GPEMU_ERR_ARG,
-		            "gradient only for the power-exponential kernel: the reference's Matern derivative matrices "
-		            "carry an accumulator across elements (emulator.c:410-425) and cannot be reproduced in parallel");
-	if (nthetas < ctx->d + 2) return fail(ctx, GPEMU_ERR_ARG, "nthetas too small");
+		            "Matern gradient needs GPEMU_MODE_EXACT_GRAD | GPEMU_MODE_MATERN_LOG: the reference's literal Matern "
+		            "derivative matrices (emulator.c:401-433, 497-532) carry an accumulator across elements and its training "
+		            "path zeroes the raw amplitude (maxmultimin.c:311,495) -- there is no literal Matern gradient to reproduce");
+	if (nthetas < nthetas_for(ctx)) return fail(ctx, GPEMU_ERR_ARG, "nthetas too small");
 	return GPEMU_OK;
 }
 
@@ -1394,15 +1427,51 @@ extern "C" int gpemu_chol_inverse(gpemu_ctx *ctx, int n, double *a, int lda, dou
 	return GPEMU_OK;
 }
 
+// 64-bit checksum of every element of a host matrix (four independent multiply-xor lanes, one pass at memory speed):
+// decides whether the device copy of a caller's C^-1 is still current.  The callers (libRbind-style loops,
+// libEmu/regression.c:120-176 and emulator.c:672-785 callers) reuse ONE cinverse buffer and rewrite it in place, so
+// pointer and sizes alone say nothing; a sampled fingerprint could miss an interior change.
+static uint64_t matrix_checksum(const double *a, int n, int lda)
+{
+	uint64_t h[4] = {0x9E3779B97F4A7C15ull, 0xBF58476D1CE4E5B9ull, 0x94D049BB133111EBull, 0xD6E8FEB86659FD93ull};
+	const uint64_t K = 0xFF51AFD7ED558CCDull;
+	for (int i = 0; i < n; i++) {
+		const double *row = a + (size_t)i * lda;
+		int j = 0;
+		for (; j + 4 <= n; j += 4) {
+			uint64_t w[4];
+			memcpy(w, row + j, sizeof w);
+			h[0] = (h[0] ^ w[0]) * K; h[1] = (h[1] ^ w[1]) * K; h[2] = (h[2] ^ w[2]) * K; h[3] = (h[3] ^ w[3]) * K;
+		}
+		for (; j < n; j++) {
+			uint64_t w;
+			memcpy(&w, row + j, sizeof w);
+			h[j & 3] = (h[j & 3] ^ w) * K;
+		}
+		h[0] ^= h[0] >> 29;                                 // row boundary: position-dependent
+	}
+	uint64_t r = h[0];
+	for (int k = 1; k < 4; k++) r = (r ^ (h[k] + (r << 6) + (r >> 2))) * K;
+	return r ^ (r >> 32);
+}
+
+// forget the cached device copy of the host matrix (a caller that knows it has rewritten the buffer can skip the
+// checksum pass this way; not needed for correctness)
+extern "C" int gpemu_symm_invalidate(gpemu_ctx *ctx)
+{
+	if (!ctx) return GPEMU_ERR_ARG;
+	ctx->sym_key = nullptr;
+	return GPEMU_OK;
+}
+
 // out[v][i] = sum_j A[i][j] V[v][j] for nvec vectors stored as rows; A symmetric, host-resident, N x N with row
-// stride lda.  A is uploaded when (pointer, sizes, fingerprint) differ from the cached copy.
+// stride lda.  A is uploaded when (pointer, sizes, checksum of all its elements) differ from the cached copy.
 extern "C" int gpemu_symm_apply(gpemu_ctx *ctx, int n, const double *a, int lda, int nvec, const double *v, double *out)
 {
 	if (!ctx || n < 1 || !a || lda < n || nvec < 1 || !v || !out) return GPEMU_ERR_ARG;
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	const int Npad = round_up(n, 64);
-	const double fp = a[0] + 3.0 * a[(size_t)(n / 2) * lda + n / 3] + 7.0 * a[(size_t)(n - 1) * lda + n - 1] +
-	                  11.0 * a[(size_t)(n - 1) * lda];
+	const uint64_t fp = matrix_checksum(a, n, lda);
 	if (ctx->sym_key != a || ctx->sym_N != n || ctx->sym_lda != lda || ctx->sym_fp != fp || !ctx->dSym) {
 		HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 		if (ctx->sym_pad != Npad || !ctx->dSym) {

@@ -132,7 +132,7 @@ struct gpemu_ctx {
 	double *dSym = nullptr, *dSymV = nullptr, *dSymOut = nullptr;
 	const double *sym_key = nullptr;
 	int sym_N = 0, sym_lda = 0, sym_pad = 0, sym_vcap = 0;
-	double sym_fp = 0.0;
+	uint64_t sym_fp = 0;          // checksum of every element of the cached host matrix
 	gpemu::CovParams *dParams = nullptr;   // hyper-parameters of the batch elements (GPEMU_MAX_BATCH slots)
 	gpemu::CovParams *hParams = nullptr;   // pinned upload ring: PARAM_RING x GPEMU_MAX_BATCH slots, one event per ring entry
 	hipEvent_t param_ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -141,6 +141,7 @@ struct gpemu_ctx {
 	int alpha_cap = 0;
 	size_t gradpart_len = 0;     // doubles of dGradPart (all corners)
 
+	int mode = 0;                 // GPEMU_MODE_* flags (gpemu_set_mode; defaults from the environment)
 	gpemu::ProfState prof;
 	// GPEMU_TRACE=1: per-launch device timestamps (wall_clock64) written by the kernels themselves, so that the
 	// concurrent timeline of several contexts can be read (rocprofv3 serialises kernels)
@@ -166,7 +167,8 @@ hipError_t launch_predict_finish(hipStream_t s, const double *V, long ldv, int M
                                  const double *Xq, const double *betaQ, double kappa, double *mean, double *var,
                                  int nslice = 1, long sstride = 0);
 hipError_t launch_grad_partials(hipStream_t s, const double *S, long lds, int soff, long sstride, int nb, const double *X, int N,
-                                int d, double *ag, int np_pad, long gstride, double *part, long pstride, int *nparts);
+                                int d, double *ag, int np_pad, long gstride, double *part, long pstride, int *nparts,
+                                int exact_kind = 0, int nbeta = 0, const CovParams *pp_dev = nullptr);
 
 hipError_t launch_deriv_gauss(hipStream_t s, double *out, long ld, const double *xcol, int n, double theta_len);
 hipError_t launch_trace_product(hipStream_t s, const double *A, const double *B, long ld, int n, double *part);

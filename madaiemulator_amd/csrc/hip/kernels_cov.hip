@@ -383,10 +383,20 @@ hipError_t launch_predict_finish(hipStream_t s, const double *V, long ldv, int M
 // place by every tile it cost 3 % of a gradient evaluation.
 // blockIdx.y = element of a lock-step batch (strides sstride, gstride, pstride).
 // ---------------------------------------------------------------------------
-__global__ void gather_alpha_kernel(const double *S, long lds_, int soff, long sstride, int N, double *ag, long gstride)
+// nbeta > 0 (exact-gradient mode): alpha = C^-1 (y - H beta) = column 0 minus sum_a beta_a column 1+a of the same rows;
+// beta sits behind the length thetas in the element's slot of ag
+__global__ void gather_alpha_kernel(const double *S, long lds_, int soff, long sstride, int N, double *ag, long gstride,
+                                    int np_pad, int nbeta)
 {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < N) ag[(long)blockIdx.y * gstride + i] = S[(long)blockIdx.y * sstride + (long)(soff + i) * lds_];
+	if (i >= N) return;
+	const double *row = S + (long)blockIdx.y * sstride + (long)(soff + i) * lds_;
+	double a = row[0];
+	if (nbeta > 0) {
+		const double *beta = ag + (long)blockIdx.y * gstride + np_pad + GPEMU_MAX_PARAMS;
+		for (int k = 0; k < nbeta; k++) a -= beta[k] * row[1 + k];
+	}
+	ag[(long)blockIdx.y * gstride + i] = a;
 }
 
 __global__ __launch_bounds__(256) void grad_part_kernel(const double *S, long lds_, int soff, long sstride, const double *X,
@@ -481,17 +491,139 @@ __global__ __launch_bounds__(256) void grad_part_kernel(const double *S, long ld
 	}
 }
 
+// ---------------------------------------------------------------------------
+// Exact gradient of the objective gpemu_loglik returns (GPEMU_MODE_EXACT_GRAD; SURVEY App. C3/C4 "corrected form"):
+//   d(-logL)/dtheta_k = 1/2 sum_ab (A_ab - alpha_a alpha_b) dC_ab/dtheta_k,  A = C^-1, alpha = A (y - H beta)
+// (beta is the GLS minimiser, so its own dependence on theta drops out), with the true derivative matrices
+//   pow-exp  (emulator.c:101-152): dC/dtheta_{k+2} = E_ab * D_k^2 e^{-2 theta_{k+2}},  E = amp exp(-1/2 sum_j D_j^2 e^{-2 theta_j})
+//            -- the FULL kernel value, where the reference's derivative_l_gauss (:173-209) keeps one coordinate's factor
+//   Matern 3/2 (:344-386), s = r/rho, c = 1.732050808: dC/dlog(rho) = amp c^2 s^2 e^{-cs}
+//   Matern 5/2 (:438-480), c = 2.236067978:            dC/dlog(rho) = amp (s^2 (c^2 - 10/3) + (5/3) c s^3) e^{-cs}
+//   nugget: dC/dlog(nug) = nug wherever the nugget rule adds it (every pair of coinciding rows, not only i == j)
+// One 64x64 lower tile per workgroup, as grad_part_kernel; part[tile][k] for k < nd (nd = d for pow-exp, 1 for
+// Matern) and part[tile][nd] for the nugget direction, within the same [tile][2d+2] slots.
+// ---------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(256) void grad_exact_kernel(const double *S, long lds_, int soff, long sstride, const double *X,
+                                                         int N, int d, const double *ag, long gstride, double *part,
+                                                         long pstride, const CovParams *pp)
+{
+	S += (long)blockIdx.y * sstride;
+	const double *alpha = ag + (long)blockIdx.y * gstride;
+	part += (long)blockIdx.y * pstride;
+	const int np = 2 * d + 2;
+	const int nd = (KIND == GPEMU_POWEREXP) ? d : 1;
+	int tr, tc;
+	lower_tile(blockIdx.x, tr, tc);
+	const long t = blockIdx.x;
+
+	__shared__ CovParams ps;
+	__shared__ double xr_s[64 * (GPEMU_MAX_PARAMS + 1)];
+	__shared__ double xc_s[64 * (GPEMU_MAX_PARAMS + 1)];
+	__shared__ double ar_s[64], ac_s[64];
+	__shared__ double red[256];
+	__shared__ double tab[32];
+	const int tid = threadIdx.x;
+	const int sd = d + 1;
+	for (int e = tid; e < (int)(sizeof(CovParams) / sizeof(double)); e += 256)
+		reinterpret_cast<double *>(&ps)[e] = reinterpret_cast<const double *>(pp + blockIdx.y)[e];
+	for (int e = tid; e < 64 * d; e += 256) {
+		int r = e / d, k = e % d;
+		int gr = tr * 64 + r, gc = tc * 64 + r;
+		xr_s[r * sd + k] = (gr < N) ? X[(long)gr * d + k] : 0.0;
+		xc_s[r * sd + k] = (gc < N) ? X[(long)gc * d + k] : 0.0;
+	}
+	if (tid < 64) {
+		int gr = tr * 64 + tid, gc = tc * 64 + tid;
+		ar_s[tid] = (gr < N) ? alpha[gr] : 0.0;
+		ac_s[tid] = (gc < N) ? alpha[gc] : 0.0;
+	}
+	if (tid < 32) tab[tid] = exp2((double)tid * (1.0 / 32.0));
+	__syncthreads();
+
+	const int c = tid & 63, rsub = tid >> 6;
+	const int gc = tc * 64 + c;
+	double wk[16];                 // weight of the element times its kernel factor (pow-exp: E; Matern: dC/dlog rho)
+	double s_nug = 0.0;
+#pragma unroll
+	for (int u = 0; u < 16; u++) {
+		const int r = rsub + 4 * u;
+		const int gr = tr * 64 + r;
+		const bool valid = gr < N && gc < N && gc <= gr;
+		double W = 0.0;
+		if (valid) {
+			const double a = S[(long)(soff + gr) * lds_ + soff + gc];
+			W = ((gc == gr) ? 1.0 : 2.0) * (a - ar_s[r] * ac_s[c]);
+		}
+		double d2 = 0.0;
+		int same = 0;
+		for (int k = 0; k < d; k++) {
+			const double D = xr_s[r * sd + k] - xc_s[c * sd + k];
+			const double v = D * ps.w[(KIND == GPEMU_POWEREXP) ? k : 0];
+			d2 = fma(v, v, d2);
+			same += (fabs(D) < ps.eps) ? 1 : 0;
+		}
+		if (KIND == GPEMU_POWEREXP) {
+			wk[u] = W * (fast_exp_neg(-d2, tab) * ps.amp);
+		} else {
+			const double sdist = fast_sqrt(d2);
+			if (KIND == GPEMU_MATERN32) {
+				const double c3 = 1.732050808;
+				wk[u] = W * (ps.amp * (c3 * c3) * d2 * fast_exp_neg(-c3 * sdist, tab));
+			} else {
+				const double c5 = 2.236067978;
+				wk[u] = W * (ps.amp * (d2 * (c5 * c5 - 10.0 / 3.0) + (5.0 / 3.0) * c5 * d2 * sdist) * fast_exp_neg(-c5 * sdist, tab));
+			}
+		}
+		if (same == d) s_nug += W * ps.nug;
+	}
+	for (int k = 0; k <= nd; k++) {
+		double sk = 0.0;
+		if (k == nd) {
+			sk = s_nug;
+		} else if (KIND == GPEMU_POWEREXP) {
+#pragma unroll
+			for (int u = 0; u < 16; u++) {
+				const int r = rsub + 4 * u;
+				const double v = (xr_s[r * sd + k] - xc_s[c * sd + k]) * ps.w[k];     // v^2 = 1/2 D^2 e^{-2 theta}
+				sk = fma(wk[u], 2.0 * v * v, sk);
+			}
+		} else {
+#pragma unroll
+			for (int u = 0; u < 16; u++) sk += wk[u];
+		}
+		red[tid] = sk;
+		__syncthreads();
+		for (int st = 128; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
+		if (tid == 0) part[t * np + k] = red[0];
+		__syncthreads();
+	}
+}
+
 // nb corners sstride apart; ag: nb slots of gstride doubles [alpha scratch (np_pad) | the length thetas]; part: nb blocks
 // of pstride doubles
 hipError_t launch_grad_partials(hipStream_t s, const double *S, long lds_, int soff, long sstride, int nb, const double *X, int N,
-                                int d, double *ag, int np_pad, long gstride, double *part, long pstride, int *nparts)
+                                int d, double *ag, int np_pad, long gstride, double *part, long pstride, int *nparts,
+                                int exact_kind, int nbeta, const CovParams *pp_dev)
 {
 	const int nt = (N + 63) / 64;
 	const int ntiles = nt * (nt + 1) / 2;
 	*nparts = ntiles;
-	hipLaunchKernelGGL(gather_alpha_kernel, dim3((N + 255) / 256, nb), dim3(256), 0, s, S, lds_, soff, sstride, N, ag, gstride);
-	hipLaunchKernelGGL(grad_part_kernel, dim3(ntiles, nb), dim3(256), 0, s, S, lds_, soff, sstride, X, N, d, ag, np_pad, gstride,
-	                   part, pstride);
+	hipLaunchKernelGGL(gather_alpha_kernel, dim3((N + 255) / 256, nb), dim3(256), 0, s, S, lds_, soff, sstride, N, ag, gstride,
+	                   np_pad, exact_kind ? nbeta : 0);
+	const dim3 grid(ntiles, nb);
+	if (exact_kind == GPEMU_POWEREXP)
+		hipLaunchKernelGGL(grad_exact_kernel<GPEMU_POWEREXP>, grid, dim3(256), 0, s, S, lds_, soff, sstride, X, N, d, ag, gstride,
+		                   part, pstride, pp_dev);
+	else if (exact_kind == GPEMU_MATERN32)
+		hipLaunchKernelGGL(grad_exact_kernel<GPEMU_MATERN32>, grid, dim3(256), 0, s, S, lds_, soff, sstride, X, N, d, ag, gstride,
+		                   part, pstride, pp_dev);
+	else if (exact_kind == GPEMU_MATERN52)
+		hipLaunchKernelGGL(grad_exact_kernel<GPEMU_MATERN52>, grid, dim3(256), 0, s, S, lds_, soff, sstride, X, N, d, ag, gstride,
+		                   part, pstride, pp_dev);
+	else
+		hipLaunchKernelGGL(grad_part_kernel, grid, dim3(256), 0, s, S, lds_, soff, sstride, X, N, d, ag, np_pad, gstride,
+		                   part, pstride);
 	return hipGetLastError();
 }
 

@@ -16,9 +16,47 @@
 
 extern int gpemu_host_kind_of(double (*fn)(gsl_vector *, gsl_vector *, gsl_vector *, int, int));
 
-static int g_device = 0;
+/* ---------------------------------------------------------------- devices
+ * The reference spreads its work over the host's CPUs (estimate_threaded.c:97: one pthread per core).  Here the unit is
+ * the GPU: a list of device SLOTS (GPEMU_DEVICES=0,1,2,... ; a device may be listed more than once: two contexts on
+ * it; default = every visible device, or the one device pinned by gpemu_host_set_device / GPEMU_DEVICE).  Independent
+ * pieces of work -- the PCA components of estimate_multi (multivar_support.c:20-28), the restart groups of
+ * estimate_thetas_threaded (estimate_threaded.c:101-113), the component emulators of alloc_multi_emulator -- are dealt
+ * to the slots; a host thread that works for one slot says so with gpemu_host_thread_device() and every context it
+ * creates lands there. */
+static int g_device = -1;                       /* pinned device (gpemu_host_set_device), -1: none */
+static int g_slots[64], g_nslots = 0;
+static pthread_once_t g_slots_once = PTHREAD_ONCE_INIT;
+static __thread int tls_device = -1;            /* device of the slot this thread works for, -1: slot 0 */
+
+static void slots_init(void)
+{
+	const char *e = getenv("GPEMU_DEVICES");
+	if (e && *e) {
+		const char *p = e;
+		while (*p && g_nslots < 64) {
+			char *end;
+			long v = strtol(p, &end, 10);
+			if (end == p) break;
+			if (v >= 0) g_slots[g_nslots++] = (int)v;
+			p = (*end == ',') ? end + 1 : end;
+		}
+	}
+	if (!g_nslots && g_device >= 0) g_slots[g_nslots++] = g_device;
+	if (!g_nslots) {
+		int n = gpemu_device_count();
+		if (n > 64) n = 64;
+		for (int i = 0; i < n; i++) g_slots[g_nslots++] = i;
+	}
+	if (!g_nslots) g_slots[g_nslots++] = 0;      /* no device: gpemu_ctx_create will say so */
+}
+
 void gpemu_host_set_device(int device) { g_device = device; }
-int gpemu_host_device(void) { return g_device; }
+int gpemu_host_device_slots(void) { pthread_once(&g_slots_once, slots_init); return g_nslots; }
+int gpemu_host_slot_device(int slot) { pthread_once(&g_slots_once, slots_init); return g_slots[((slot % g_nslots) + g_nslots) % g_nslots]; }
+void gpemu_host_thread_device(int device) { tls_device = device; }
+int gpemu_host_thread_device_get(void) { return tls_device; }
+int gpemu_host_device(void) { return tls_device >= 0 ? tls_device : gpemu_host_slot_device(0); }
 
 /* ---------------------------------------------------------------- registry */
 struct entry {
@@ -47,7 +85,7 @@ static struct entry *lookup(const void *key, int create)
 	if (!e && create) {
 		e = (struct entry *)calloc(1, sizeof *e);
 		e->key = key;
-		int rc = gpemu_ctx_create(&e->ctx, g_device);
+		int rc = gpemu_ctx_create(&e->ctx, gpemu_host_device());
 		if (rc) { pthread_mutex_unlock(&g_lock); die(NULL, rc, "gpemu_ctx_create"); }
 		e->next = g_entries;
 		g_entries = e;
@@ -156,6 +194,7 @@ struct group {
 	pthread_mutex_t mu;
 	pthread_cond_t cv;
 	int nlive, narrived, cap, nthetas;
+	int device;                  /* device of the slot the group works for (captured from its creator) */
 	unsigned long generation;
 	modelstruct *model;
 	const void **members;
@@ -185,6 +224,7 @@ void *gpemu_host_group_create(struct estimate_thetas_params **members, int n)
 	pthread_mutex_init(&G->mu, NULL);
 	pthread_cond_init(&G->cv, NULL);
 	G->nlive = n; G->cap = n; G->nmembers = n;
+	G->device = gpemu_host_device();
 	G->nthetas = members[0]->options->nthetas;
 	G->model = members[0]->the_model;
 	G->members = (const void **)malloc(sizeof(void *) * (size_t)n);
@@ -222,7 +262,10 @@ void gpemu_host_group_destroy(void *group)
 static void group_run_round(struct group *G)
 {
 	const int n = G->narrived, nt = G->nthetas;
+	const int saved_device = tls_device;          /* the round runs on whichever member arrived last: use the group's device */
+	tls_device = G->device;
 	gpemu_ctx *ctx = bind_model(G, G->model, "lock-step group");
+	tls_device = saved_device;
 	double *th = (double *)malloc(sizeof(double) * (size_t)n * nt);
 	double *val = (double *)malloc(sizeof(double) * (size_t)n), *s2 = (double *)malloc(sizeof(double) * (size_t)n);
 	double *gr = (double *)malloc(sizeof(double) * (size_t)n * nt);

@@ -235,7 +235,15 @@ void callEmulateMCMulti(double *point_in, int *nydims_in, double *final_mean, do
 void freeEmulateMCMulti(int *nydims_in);
 
 /* ---- knobs of this implementation (not in the reference) ------------------------ */
-void gpemu_host_set_device(int device);          /* HIP device used by contexts created from this thread on */
+void gpemu_host_set_device(int device);          /* pin the whole process to ONE HIP device (before the first device call) */
+/* device slots: GPEMU_DEVICES=0,1,... (repeats allowed), else every visible device, else the pinned one.  Independent
+ * work (PCA components, restart groups, component emulators) is dealt to the slots; a thread working for a slot
+ * declares it with gpemu_host_thread_device(device) and every context created from that thread lives there. */
+int gpemu_host_device_slots(void);
+int gpemu_host_slot_device(int slot);
+void gpemu_host_thread_device(int device);       /* -1: back to slot 0 */
+int gpemu_host_thread_device_get(void);
+int gpemu_host_device(void);                     /* device a context created by the calling thread would get */
 void gpemu_host_set_seed(unsigned long seed);    /* 0 = /dev/urandom as the reference (estimate_threaded.c:159) */
 void gpemu_host_set_search(int nthreads, int restarts_per_job);   /* defaults: 1 thread (1 GPU stream), 50 restarts */
 void gpemu_host_release(void *params_or_emulator); /* drop the device context cached for a params / emulator pointer */

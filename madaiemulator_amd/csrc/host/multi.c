@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <pthread.h>
 #include "libemu.h"
 
 double vector_elt_sum(gsl_vector *vec, int nstop)
@@ -239,11 +240,41 @@ void free_multimodelstruct(multi_modelstruct *m)
 	free(m);
 }
 
-/* multivar_support.c:20-28: the nr scalar GPs are independent; the reference trains them one after the other */
+/* multivar_support.c:20-28: the nr scalar GPs are independent; the reference trains them one after the other.  Here
+ * component c is trained on device slot c mod S (S = gpemu_host_device_slots()), one host thread per slot, each
+ * thread walking its components in order with its whole restart search on its slot's device; no exchange between
+ * the slots -- the results meet in the modelstructs and the snapshot is written once all threads have joined.  A
+ * component's search does not depend on which slot ran it (same seeds, same lock-step group size), so the snapshot is
+ * the one the serial loop writes. */
+struct component_job { multi_modelstruct *m; int slot, nslots; };
+
+static void *component_main(void *arg)
+{
+	struct component_job *j = (struct component_job *)arg;
+	gpemu_host_thread_device(gpemu_host_slot_device(j->slot));
+	for (int i = j->slot; i < j->m->nr; i += j->nslots)
+		estimate_thetas_threaded(j->m->pca_model_array[i], j->m->pca_model_array[i]->options);
+	return NULL;
+}
+
 void estimate_multi(multi_modelstruct *m, FILE *outfp)
 {
-	for (int i = 0; i < m->nr; i++)
-		estimate_thetas_threaded(m->pca_model_array[i], m->pca_model_array[i]->options);
+	int nslots = gpemu_host_thread_device_get() >= 0 ? 1 : gpemu_host_device_slots();
+	if (nslots > m->nr) nslots = m->nr;
+	if (nslots <= 1) {
+		for (int i = 0; i < m->nr; i++)
+			estimate_thetas_threaded(m->pca_model_array[i], m->pca_model_array[i]->options);
+	} else {
+		pthread_t *tid = (pthread_t *)calloc((size_t)nslots, sizeof *tid);
+		struct component_job *jobs = (struct component_job *)calloc((size_t)nslots, sizeof *jobs);
+		for (int s = 0; s < nslots; s++) {
+			jobs[s].m = m; jobs[s].slot = s; jobs[s].nslots = nslots;
+			if (pthread_create(&tid[s], NULL, component_main, &jobs[s])) { perror("pthread_create"); exit(EXIT_FAILURE); }
+		}
+		for (int s = 0; s < nslots; s++)
+			if (pthread_join(tid[s], NULL)) { perror("pthread_join"); exit(EXIT_FAILURE); }
+		free(tid); free(jobs);
+	}
 	dump_multi_modelstruct(outfp, m);
 }
 
@@ -256,7 +287,13 @@ multi_emulator *alloc_multi_emulator(multi_modelstruct *m)
 	e->nthetas = m->pca_model_array[0]->options->nthetas;
 	e->model = m;
 	e->emu_struct_array = (emulator_struct **)malloc(sizeof(emulator_struct *) * (size_t)e->nr);
-	for (int i = 0; i < e->nr; i++) e->emu_struct_array[i] = alloc_emulator_struct(m->pca_model_array[i]);
+	/* component i lives on device slot i mod S: emulate_points_multi starts all of them before it waits for the first */
+	const int pinned = gpemu_host_thread_device_get();
+	for (int i = 0; i < e->nr; i++) {
+		if (pinned < 0) gpemu_host_thread_device(gpemu_host_slot_device(i));
+		e->emu_struct_array[i] = alloc_emulator_struct(m->pca_model_array[i]);
+	}
+	gpemu_host_thread_device(pinned);
 	return e;
 }
 

@@ -277,12 +277,13 @@ struct pool {
 	double best_likelyhood_val;
 };
 
-struct worker { struct pool *pool; struct estimate_thetas_params params; int id; int in_group; };
+struct worker { struct pool *pool; struct estimate_thetas_params params; int id; int in_group; int device; };
 
 static void *worker_main(void *arg)
 {
 	struct worker *w = (struct worker *)arg;
 	struct pool *P = w->pool;
+	gpemu_host_thread_device(w->device);         /* contexts this thread creates live on its slot's device */
 	for (int round = 0;; round++) {
 		int job;
 		if (w->in_group && round > 0) break;      /* lock-step group: exactly one job per member thread */
@@ -306,12 +307,18 @@ static void *worker_main(void *arg)
 	return NULL;
 }
 
+static int env_flag(const char *name) { const char *e = getenv(name); return e && atoi(e) > 0; }
+
 /* libEmu/estimate_threaded.c:78-237.  The reference starts one pthread per CPU, each running jobs of 50 restarts
- * on its own copy of the model.  Here the restarts run as a LOCK-STEP GROUP (default, pow-exp models): up to 16
- * host threads, each an ordinary sequential BFGS run, share one device context; whenever all of them have asked for
- * a likelihood (+gradient) the requests go to the GPU as one batch (device_bridge.c).  The restarts of a job
- * (GPEMU_RESTARTS, default 50, times GPEMU_JOBS) are dealt evenly to the group's threads.  GPEMU_LOCKSTEP=1 (or a
- * Matern model) gives the older scheme: GPEMU_NTHREADS workers with one device context each, one job at a time. */
+ * on its own copy of the model.  Here the restarts run as LOCK-STEP GROUPS (default): up to 16 host threads per
+ * device slot, each an ordinary sequential BFGS run, share one device context; whenever all threads of a group have
+ * asked for a likelihood (+gradient) the requests go to the GPU as one batch (device_bridge.c).  The restarts of a
+ * job (GPEMU_RESTARTS, default 50, times GPEMU_JOBS) are dealt evenly to the threads, the threads in contiguous
+ * shares to the device slots (gpemu_host_device_slots(): every visible GPU unless GPEMU_DEVICES / GPEMU_DEVICE says
+ * otherwise) -- one group per slot, no communication between groups until the arg-max under the result mutex
+ * (estimate_threaded.c:308-313).  A caller that already works for one slot (a component thread of estimate_multi)
+ * keeps the whole search on that slot.  GPEMU_LOCKSTEP=1 (or a Matern model without the corrected gradient) gives
+ * the older scheme: GPEMU_NTHREADS workers with one device context each, one job at a time. */
 void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 {
 	int nthreads = g_nthreads > 0 ? g_nthreads : 1;
@@ -328,14 +335,20 @@ void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 	env = getenv("GPEMU_LOCKSTEP");
 	if (env && atoi(env) > 0) lockstep = atoi(env);
 	if (lockstep > 64) lockstep = 64;
-	if (options->cov_fn_index != POWEREXPCOVFN) lockstep = 1;      /* the batched gradient is pow-exp only */
+	/* the batched gradient exists for pow-exp (literal or exact) and for Matern with the corrected forms (gpemu.h modes) */
+	if (options->cov_fn_index != POWEREXPCOVFN && !(env_flag("GPEMU_EXACT_GRAD") && env_flag("GPEMU_MATERN_FIXED"))) lockstep = 1;
+	/* device slots this search may use */
+	const int pinned = gpemu_host_thread_device_get();
+	int nslots = pinned >= 0 ? 1 : gpemu_host_device_slots();
+	int ngroups = 0;
 	if (lockstep > 1) {
-		/* njobs * restarts BFGS runs in total, spread over the group's threads, one job each */
+		/* njobs * restarts BFGS runs in total, spread over the threads of all groups, one job each */
 		const int total = njobs * restarts;
-		if (lockstep > total) lockstep = total;
-		nthreads = lockstep;
-		njobs = lockstep;
-		restarts = (total + lockstep - 1) / lockstep;
+		nthreads = lockstep * nslots;
+		if (nthreads > total) nthreads = total;
+		ngroups = nslots < nthreads ? nslots : nthreads;
+		njobs = nthreads;
+		restarts = (total + nthreads - 1) / nthreads;
 	}
 	unsigned long seed = g_seed;
 	env = getenv("GPEMU_SEED");
@@ -364,13 +377,23 @@ void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 		W[i].params.random_number = gsl_rng_alloc(gsl_rng_default);
 		gsl_rng_set(W[i].params.random_number, seed ? seed + 7919UL * (unsigned long)i : seed_noblock());
 	}
-	void *group = NULL;
+	void **groups = NULL;
 	if (lockstep > 1) {
+		/* group g = threads [g nthreads / ngroups, (g+1) nthreads / ngroups) on device slot g */
+		groups = (void **)calloc((size_t)ngroups, sizeof(void *));
 		struct estimate_thetas_params **members = (struct estimate_thetas_params **)malloc(sizeof(void *) * (size_t)nthreads);
-		for (int i = 0; i < nthreads; i++) { members[i] = &W[i].params; W[i].in_group = 1; }
-		group = gpemu_host_group_create(members, nthreads);
+		for (int g = 0; g < ngroups; g++) {
+			const int lo = (int)((long)g * nthreads / ngroups), hi = (int)((long)(g + 1) * nthreads / ngroups);
+			const int dev = pinned >= 0 ? pinned : gpemu_host_slot_device(g);
+			for (int i = lo; i < hi; i++) { members[i - lo] = &W[i].params; W[i].in_group = 1; W[i].device = dev; }
+			gpemu_host_thread_device(dev);            /* the group's context is created on the creator's device */
+			groups[g] = gpemu_host_group_create(members, hi - lo);
+			gpemu_host_thread_device(pinned);
+			if (!groups[g]) { fprintf(stderr, "estimate_thetas_threaded: cannot create the lock-step group\n"); exit(EXIT_FAILURE); }
+		}
 		free(members);
-		if (!group) { fprintf(stderr, "estimate_thetas_threaded: cannot create the lock-step group\n"); exit(EXIT_FAILURE); }
+	} else {
+		for (int i = 0; i < nthreads; i++) W[i].device = pinned >= 0 ? pinned : gpemu_host_slot_device(i);
 	}
 	for (int i = 0; i < nthreads; i++)
 		if (pthread_create(&tid[i], NULL, worker_main, &W[i])) { perror("pthread_create"); exit(EXIT_FAILURE); }
@@ -384,7 +407,8 @@ void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 		printf("\n");
 	}
 	printf("-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=\n");
-	if (group) gpemu_host_group_destroy(group);
+	for (int g = 0; g < ngroups; g++) gpemu_host_group_destroy(groups[g]);
+	free(groups);
 	for (int i = 0; i < nthreads; i++) {
 		gpemu_host_release(&W[i].params);
 		gsl_rng_free(W[i].params.random_number);

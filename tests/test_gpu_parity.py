@@ -580,6 +580,19 @@ def test_chol_inverse_and_symm_apply_on_host_matrices(gpu_ctx, n):
     assert relerr(out, V @ ref) < 1e-12
     out2 = gpu_ctx.symm_apply(ref, V[:2])                # cached matrix, fewer vectors
     assert np.array_equal(out2, out[:2])
+    # callers reuse ONE cinverse buffer and rewrite it in place (regression.c:120-176 callers, rbind.c loops): a change
+    # of a single interior element -- none of the corners or of the middle sample an abbreviated fingerprint would
+    # look at -- must reach the device copy
+    i, j = (n * 3) // 7, (n * 2) // 7
+    ref[i, j] += 0.25
+    out3 = gpu_ctx.symm_apply(ref, V)
+    assert relerr(out3, V @ ref.T) < 1e-12 and not np.array_equal(out3, out)
+    assert abs((out3 - out)[:, i] - 0.25 * V[:, j]).max() < 1e-12 * max(1.0, np.abs(V).max())
+    ref[i, j] -= 0.25
+    ref[n - 1, 0] = ref[0, n - 1] = ref[n - 1, 0] + 1.0   # and back, plus a corner
+    assert relerr(gpu_ctx.symm_apply(ref, V), V @ ref) < 1e-12
+    gpu_ctx.symm_invalidate()
+    assert relerr(gpu_ctx.symm_apply(ref, V), V @ ref) < 1e-12
     bad = A.copy()
     bad[n // 2, n // 2] = -1.0
     _, _, info, rc = gpu_ctx.chol_inverse(bad)
