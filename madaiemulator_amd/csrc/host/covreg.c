@@ -32,6 +32,15 @@ double covariance_fn_gaussian(gsl_vector *xm, gsl_vector *xn, gsl_vector *thetas
 	return c;
 }
 
+/* GPEMU_MATERN_FIXED=1 (the device library's GPEMU_MODE_MATERN_LOG, gpemu.h): amplitude and nugget on the log scale,
+ * so that the scalar functions agree with the matrices the device builds in that mode */
+static int matern_log_scale(void)
+{
+	static int cached = -1;
+	if (cached < 0) { const char *e = getenv("GPEMU_MATERN_FIXED"); cached = (e && atoi(e) > 0) ? 1 : 0; }
+	return cached;
+}
+
 static double matern_dist(gsl_vector *xm, gsl_vector *xn, int nparams, int *same)
 {
 	double d2 = 0.0;
@@ -49,7 +58,9 @@ double covariance_fn_matern_three(gsl_vector *xm, gsl_vector *xn, gsl_vector *th
 {
 	(void)nthetas;
 	int same;
-	const double amp = gsl_vector_get(thetas, 0), nugget = gsl_vector_get(thetas, 1);
+	const int ls = matern_log_scale();
+	const double amp = ls ? exp(gsl_vector_get(thetas, 0)) : gsl_vector_get(thetas, 0);
+	const double nugget = ls ? exp(gsl_vector_get(thetas, 1)) : gsl_vector_get(thetas, 1);
 	const double rho = exp(gsl_vector_get(thetas, 2)), root3 = 1.732050808;
 	const double dist = matern_dist(xm, xn, nparams, &same);
 	double c = (dist > 0.0) ? amp * (1 + root3 * (dist / rho)) * exp(-root3 * (dist / rho)) : amp;
@@ -62,7 +73,9 @@ double covariance_fn_matern_five(gsl_vector *xm, gsl_vector *xn, gsl_vector *the
 {
 	(void)nthetas;
 	int same;
-	const double amp = gsl_vector_get(thetas, 0), nugget = gsl_vector_get(thetas, 1);
+	const int ls = matern_log_scale();
+	const double amp = ls ? exp(gsl_vector_get(thetas, 0)) : gsl_vector_get(thetas, 0);
+	const double nugget = ls ? exp(gsl_vector_get(thetas, 1)) : gsl_vector_get(thetas, 1);
 	const double rho = exp(gsl_vector_get(thetas, 2)), root5 = 2.236067978;
 	const double dist = matern_dist(xm, xn, nparams, &same);
 	const double s = dist / rho;

@@ -246,6 +246,9 @@ int gpemu_host_thread_device_get(void);
 int gpemu_host_device(void);                     /* device a context created by the calling thread would get */
 void gpemu_host_set_seed(unsigned long seed);    /* 0 = /dev/urandom as the reference (estimate_threaded.c:159) */
 void gpemu_host_set_search(int nthreads, int restarts_per_job);   /* defaults: 1 thread (1 GPU stream), 50 restarts */
+/* what the BFGS runs did so far in this process: runs, runs that ended at |g| < 0.1, runs that ended with "no progress",
+ * line searches that fell back to "lowest trial value" (no Wolfe point), |g| at the end of the winning run of the last search */
+void gpemu_host_search_stats(long *runs, long *converged, long *noprogress, long *ls_fallbacks, double *best_gnorm);
 void gpemu_host_release(void *params_or_emulator); /* drop the device context cached for a params / emulator pointer */
 /* lock-step group: n restart threads (one struct estimate_thetas_params each, same model) share one device context;
  * their concurrent evalFnMulti / gradFnMulti / evalFnGradMulti / estimateSigmaFull calls are gathered into device

@@ -26,6 +26,19 @@
 #define SCREWUPVALUE (-HUGE_VAL)
 #define SCREWUPVALUE_T (-HUGE_VAL)
 
+/* search statistics (gpemu_host_search_stats): what the minimiser runs of the last estimate_thetas_threaded calls did */
+static long g_stat_runs = 0, g_stat_converged = 0, g_stat_noprogress = 0, g_stat_fallbacks = 0;
+static double g_stat_best_gnorm = -1.0;         /* |gradient| at the end of the winning run of the LAST search */
+static __thread double tls_run_gnorm = -1.0, tls_best_gnorm = -1.0;
+void gpemu_host_search_stats(long *runs, long *converged, long *noprogress, long *ls_fallbacks, double *best_gnorm)
+{
+	if (runs) *runs = __sync_fetch_and_add(&g_stat_runs, 0);
+	if (converged) *converged = __sync_fetch_and_add(&g_stat_converged, 0);
+	if (noprogress) *noprogress = __sync_fetch_and_add(&g_stat_noprogress, 0);
+	if (ls_fallbacks) *ls_fallbacks = __sync_fetch_and_add(&g_stat_fallbacks, 0);
+	if (best_gnorm) *best_gnorm = g_stat_best_gnorm;
+}
+
 static unsigned long g_seed = 0;
 static int g_nthreads = 0, g_restarts = 50;
 void gpemu_host_set_seed(unsigned long seed) { g_seed = seed; }
@@ -136,6 +149,7 @@ static int line_search(struct fdf *F, const double *x, double f0, const double *
 fallback:
 	if (best_f < f0) {
 		if (debug) fprintf(stderr, "#   ls no Wolfe point: taking the lowest trial a %.4g f %.10g\n", best_a, best_f);
+		__sync_fetch_and_add(&g_stat_fallbacks, 1);
 		*alpha_out = best_a; *f_out = best_f; memcpy(g_out, best_g, sizeof(double) * (size_t)n);
 		LS_RETURN(0);
 	}
@@ -208,6 +222,10 @@ int doOptimizeMultiMin(double (*fn)(const gsl_vector *, void *),
 		stepcount++;
 	}
 	if (status == GSL_CONTINUE && sqrt(dot(g, g, n)) < epsAbs) status = GSL_SUCCESS;
+	tls_run_gnorm = sqrt(dot(g, g, n));
+	__sync_fetch_and_add(&g_stat_runs, 1);
+	if (status == GSL_SUCCESS) __sync_fetch_and_add(&g_stat_converged, 1);
+	if (status == GSL_ENOPROG) __sync_fetch_and_add(&g_stat_noprogress, 1);
 	if (stepcount == stepmax) fprintf(stderr, "# (error) multimin: no converge at stepmax %d\n", stepmax);
 
 	for (int i = 0; i < n; i++) gsl_vector_set(xt, i, x[i]);
@@ -241,6 +259,7 @@ void maxWithMultiMin(struct estimate_thetas_params *params)
 		if (likelihood > bestLHood && (isnan(likelihood) == 0 && isinf(likelihood) == 0)) {
 			bestLHood = likelihood;
 			gsl_vector_memcpy(xBest, xFinal);
+			tls_best_gnorm = tls_run_gnorm;
 		}
 		tries++;
 		gsl_vector_set_zero(xFinal);
@@ -275,6 +294,7 @@ struct pool {
 	int ntries, jobnumber;
 	gsl_vector *best_thetas;
 	double best_likelyhood_val;
+	double best_gnorm;
 };
 
 struct worker { struct pool *pool; struct estimate_thetas_params params; int id; int in_group; int device; };
@@ -299,6 +319,7 @@ static void *worker_main(void *arg)
 		if (val > P->best_likelyhood_val) {
 			gsl_vector_memcpy(P->best_thetas, w->params.the_model->thetas);
 			P->best_likelyhood_val = val;
+			P->best_gnorm = tls_best_gnorm;
 			printf("# worker %d won with %g\n", w->id, val);
 		}
 		pthread_mutex_unlock(&P->result_lock);
@@ -360,6 +381,7 @@ void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 	P.ntries = njobs; P.jobnumber = 0;
 	P.best_thetas = gsl_vector_calloc(options->nthetas);
 	P.best_likelyhood_val = SCREWUPVALUE_T;
+	P.best_gnorm = -1.0;
 
 	struct worker *W = (struct worker *)calloc((size_t)nthreads, sizeof *W);
 	pthread_t *tid = (pthread_t *)calloc((size_t)nthreads, sizeof *tid);
@@ -417,6 +439,7 @@ void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 		free(W[i].params.the_model);
 	}
 	gsl_vector_memcpy(the_model->thetas, P.best_thetas);
+	g_stat_best_gnorm = P.best_gnorm;
 	gsl_vector_free(P.best_thetas);
 	pthread_mutex_destroy(&P.job_lock);
 	pthread_mutex_destroy(&P.result_lock);

@@ -116,6 +116,19 @@ int main(int argc, char **argv)
 		gsl_vector *th = gsl_vector_alloc(nthetas - 1);
 		for (int i = 0; i < nthetas - 1; i++) gsl_vector_set(th, i, gsl_vector_get(model->thetas, i + 1));
 		printf("neglogl %.17g\n", evalFnMulti(th, &params));
+		{
+			long runs, conv, noprog, fb;
+			double gn;
+			gpemu_host_search_stats(&runs, &conv, &noprog, &fb, &gn);
+			printf("search %ld %ld %ld %ld %.17g\n", runs, conv, noprog, fb, gn);
+			if (cov == POWEREXPCOVFN || getenv("GPEMU_EXACT_GRAD")) {
+				gsl_vector *g = gsl_vector_alloc(nthetas - 1);
+				gradFnMulti(th, &params, g);
+				printf("grad_at_best");
+				for (int i = 0; i < nthetas - 1; i++) printf(" %.17g", gsl_vector_get(g, i));
+				printf("\n");
+			}
+		}
 		gpemu_host_release(&params);
 	} else if (!strcmp(argv[1], "lowlevel")) {
 		/* the call sequence of the reference's R bindings (libRbind/rbind.c:121-210): N x N matrices in host memory */

@@ -355,11 +355,101 @@ def test_loglik_grad_batch_matern_is_refused(gpu_ctx, ref_inputs):
 
 
 def test_grad_matern_is_refused(gpu_ctx, ref_inputs):
+    """literal mode (the default): the reference's Matern training path exits (maxmultimin.c:495) -- no gradient"""
     X, y = ref_inputs["uni"]
     gpu_ctx.set_model(3, 0, X, y)
-    with pytest.raises(abi.GpemuError) as e:
-        gpu_ctx.grad(np.array([1.0, 0.01, 0.0]))
-    assert e.value.code == abi.ERR_ARG
+    for mode in (0, abi.MODE_EXACT_GRAD, abi.MODE_MATERN_LOG):         # both flags are needed
+        gpu_ctx.set_mode(mode)
+        with pytest.raises(abi.GpemuError) as e:
+            gpu_ctx.grad(np.array([1.0, 0.01, 0.0]))
+        assert e.value.code == abi.ERR_ARG
+    gpu_ctx.set_mode(0)
+
+
+# ------------------------------------------------------------------ corrected forms behind flags (SURVEY App. C2-C4)
+def _fd_gradient(ctx, th, h=2e-3):
+    """central differences of the value gpemu_loglik returns (theta[0] = 0), Richardson-extrapolated (h, 2h)"""
+    th = np.array(th, float)
+    th[0] = 0.0
+    g = np.zeros(th.size - 1)
+    for i in range(1, th.size):
+        def f(t):
+            x = th.copy()
+            x[i] += t
+            return ctx.loglik(x)["value"]
+        d1 = (f(h) - f(-h)) / (2 * h)
+        d2 = (f(2 * h) - f(-2 * h)) / (4 * h)
+        g[i - 1] = (4.0 * d1 - d2) / 3.0
+    return g
+
+
+@pytest.mark.parametrize("kind,d,order", [(1, 1, 1), (1, 3, 0), (1, 8, 1), (2, 3, 1), (3, 1, 0), (3, 8, 1)])
+def test_exact_gradient_matches_finite_differences(kind, d, order):
+    """GPEMU_MODE_EXACT_GRAD: the gradient is the derivative of the value gpemu_loglik returns -- checked against
+    central finite differences at 1e-6 of the largest component (pow-exp d = 1, 3, 8; both Matern kernels on the log
+    scale).  The literal gradient (emulator.c:189,203; maxmultimin.c:514,532,594) is not, for d > 1."""
+    N = 400
+    X, y = synth.design(N, d, 77 + d)
+    y = y + 0.1 * synth.normal(5, N)
+    ctx = abi.Context(0)
+    ctx.set_mode(abi.MODE_EXACT_GRAD | (abi.MODE_MATERN_LOG if kind != 1 else 0))
+    ctx.set_model(kind, order, X, y)
+    if kind == 1:
+        th = np.concatenate([[0.0, -3.0], np.log(0.5) + 0.1 * np.arange(d)])
+    else:
+        th = np.array([0.0, -3.5, np.log(0.7)])
+    r = ctx.loglik_grad(th)
+    assert r["status"] == 0
+    assert r["value"] == ctx.loglik(th)["value"]                        # same factorisation, same value
+    fd = _fd_gradient(ctx, th)
+    scale = np.max(np.abs(fd))
+    assert np.max(np.abs(r["grad"] - fd)) <= 1e-6 * scale, (r["grad"], fd)
+    g2, rc = ctx.grad(th)
+    assert rc == 0 and np.array_equal(g2, r["grad"])
+    # lock-step batch: element for element the single evaluation
+    ths = np.array([th, th + 0.05, th - 0.03])
+    ths[:, 0] = 0.0
+    b = ctx.loglik_grad_batch(ths)
+    assert np.all(b["status"] == 0)
+    for i in range(3):
+        one = ctx.loglik_grad(ths[i])
+        assert np.array_equal(b["grad"][i], one["grad"]) and b["value"][i] == one["value"]
+    if kind == 1 and d > 1:
+        # and the literal formula really is something else
+        ctx.set_mode(0)
+        lit, _ = ctx.grad(th)
+        assert np.max(np.abs(lit - fd)) > 1e-3 * scale
+    ctx.close()
+
+
+def test_matern_log_scale_mode_changes_the_kernel_consistently():
+    """GPEMU_MODE_MATERN_LOG: amp = e^theta0, nug = e^theta1 in fill, likelihood and prediction alike; the literal
+    kernel at (e^theta0, e^theta1, theta2) is the same matrix"""
+    N, d = 300, 4
+    X, y = synth.design(N, d, 3)
+    th_log = np.array([0.3, -3.0, np.log(0.8)])
+    th_raw = np.array([np.exp(0.3), np.exp(-3.0), np.log(0.8)])
+    for kind in (2, 3):
+        a, b = abi.Context(0), abi.Context(0)
+        a.set_mode(abi.MODE_MATERN_LOG)
+        a.set_model(kind, 1, X, y)
+        b.set_model(kind, 1, X, y)
+        assert np.array_equal(a.cov_matrix(th_log), b.cov_matrix(th_raw))
+        la, lb = a.loglik(th_log), b.loglik(th_raw)
+        assert la["value"] == lb["value"] and np.array_equal(la["beta"], lb["beta"])
+        a.predict_setup(th_log)
+        b.predict_setup(th_raw)
+        Xq = synth.queries(50, d, 9)
+        ma, va = a.predict(Xq)
+        mb, vb = b.predict(Xq)
+        assert np.array_equal(ma, mb) and np.array_equal(va, vb)
+        # and against the oracle at the raw thetas
+        e = O.Emulator(kind, 1, X, y, th_raw)
+        mo, vo, _ = e.emulate(Xq)
+        assert np.max(np.abs(ma - mo)) < RTOL * max(1.0, np.abs(mo).max())
+        assert np.max(np.abs(va - vo)) < RTOL * (th_raw[0] + th_raw[1])
+        a.close()
+        b.close()
 
 
 # ------------------------------------------------------------------ a14-a19: prediction

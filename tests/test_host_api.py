@@ -299,6 +299,63 @@ def test_multi_output_pca_snapshot_and_backprojection(driver, tmp_path):
 
 
 @pytest.mark.gpu
+def test_multi_output_training_over_device_slots_writes_the_same_snapshot(driver, tmp_path):
+    """SURVEY 8(e) axis 1 in the C product: estimate_multi (multivar_support.c:20-28) deals the PCA components to the
+    device slots of GPEMU_DEVICES, one host thread and one set of device contexts per slot -- here two slots on the
+    one GPU of the box.  A component's search does not depend on the slot that ran it, so under a fixed seed the
+    snapshot is byte for byte the one the serial loop writes; the predictions of the multi-slot emulator
+    (alloc_multi_emulator: component c on slot c mod S) are the serial ones too."""
+    cli = build.CLI_BIN
+    snaps = {}
+    for name, devs in (("serial", "0"), ("two_slots", "0,0"), ("three_slots", "0,0,0")):
+        snap = tmp_path / f"snap_{name}"
+        env = dict(os.environ, GPEMU_SEED="2024", GPEMU_RESTARTS="2", GPEMU_DEVICES=devs)
+        out = run([cli, "estimate_thetas", MULTI, str(snap), "--regression_order=1"], env=env)
+        snaps[name] = snap.read_bytes()
+        assert len(snaps[name]) > 1000
+    assert snaps["serial"] == snaps["two_slots"] == snaps["three_slots"]
+    X, _ = synth.read_input_model_file(MULTI)
+    qf = tmp_path / "q.dat"
+    np.savetxt(qf, X[:7] + 0.01, fmt="%.17g")
+    preds = [run([driver, "multi", str(tmp_path / "snap_serial"), str(qf)], env=dict(os.environ, GPEMU_DEVICES=devs))
+             for devs in ("0", "0,0")]
+    assert preds[0] == preds[1] and "pred" in preds[0]
+
+
+def _write_model_file(path, X, y):
+    N, d = X.shape
+    path.write_text(f"1\n{d}\n{N}\n" + "\n".join(" ".join(repr(float(v)) for v in row) for row in X) + "\n" +
+                    "\n".join(repr(float(v)) for v in y) + "\n")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cov", [1, 3])
+def test_training_with_the_corrected_gradient_converges(driver, tmp_path, cov):
+    """SURVEY App. C2-C4 flags: with GPEMU_EXACT_GRAD=1 (and GPEMU_MATERN_FIXED=1 for the Matern 5/2 model, which the
+    reference cannot train at all) estimate_thetas_threaded trains N=1024, d=8: the winning BFGS run ends at
+    |gradient| < 0.1 (maxmultimin.c:725), no line search needs the 'lowest trial value' fallback the literal
+    gradient forces, and the gradient at the optimum -- the exact one -- is indeed small."""
+    N, d = 1024, 8
+    X, y = synth.design(N, d, 4242)
+    y = y + 0.2 * synth.normal(17, N)
+    f = tmp_path / "train.dat"
+    _write_model_file(f, X, y)
+    env = dict(os.environ, GPEMU_SEED="99", GPEMU_JOBS="16", GPEMU_RESTARTS="1", GPEMU_EXACT_GRAD="1", GPEMU_DEVICES="0")
+    if cov != 1:
+        env["GPEMU_MATERN_FIXED"] = "1"
+    res = parse(run([driver, "train", str(f), str(cov), "0"], env=env))
+    th = np.array(res["thetas"][0])
+    runs, conv, noprog, fallbacks, best_gnorm = res["search"][0]
+    assert runs == 16 and np.all(np.isfinite(th)) and np.isfinite(res["neglogl"][0][0])
+    assert fallbacks == 0
+    assert 0.0 <= best_gnorm < 0.1
+    assert np.sqrt(np.sum(np.square(res["grad_at_best"][0]))) < 0.1
+    if cov == 1:
+        # the value at the optimum against the oracle (pow-exp: the literal kernel is unchanged by the flags)
+        assert res["neglogl"][0][0] == pytest.approx(O.eval_fn_multi(1, 0, X, y, th[1:])["value"], rel=1e-6)
+
+
+@pytest.mark.gpu
 def test_call_eval_lhood_list_without_r():
     """libRbind's batched likelihood entry (rbind.c:626-724): flat .C() signature, column-major arrays"""
     import ctypes as C
