@@ -13,8 +13,15 @@ value = evaluations per second = K * B * n_gpus / time ("evaluations_per_step" i
 Workload = BASELINE.json configs[2]: N=8192, d=8, Matern 5/2, regression order 1, 1e6 batched predictions.
 The evaluation is at given (supplied) thetas: the reference cannot train a Matern model.
 
+A third timed region measures what estimate_thetas really calls per BFGS step (libEmu/maxmultimin.c:615-618,
+675-680): evalFnGradMulti, value + gradient from one factorisation, as lock-step batches (gpemu_loglik_grad_batch) on
+a pow-exp model of the same size (the reference has no Matern gradient).
+
 Multi-GPU: the evaluations / query blocks are independent units sharded one share per rank with no data-path
 collective; a single all-gather of the per-rank results ends each region ("weak" scaling: per-rank work fixed).
+`python bench.py --gpus N` with no RANK in the environment starts the N ranks itself (a child
+`python -m torch.distributed.run --nproc-per-node N bench.py ...`, before this process touches the GPU) and forwards
+rank 0's line; under the driver's own torchrun launch the ranks are already there.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with "roofline" and "cpu_baseline" objects.
 """
@@ -61,20 +68,28 @@ def _cpu_eval_worker(args):
 
 def cpu_baseline(kind, order, N, d, seed):
     """Reference-faithful CPU restatement (oracle/, kind "port") on the host cores: one independent evaluation
-    per core, the reference's own parallelisation (estimate_threaded.c:97,172).  Bounded sample at N_s < N,
-    extrapolated by (N/N_s)^3 (the path is N^3: unblocked Cholesky + explicit inverse)."""
+    per core, the reference's own parallelisation (estimate_threaded.c:97,172).  Bounded samples at N_s < N
+    (1024, 1536, 2048: about a minute of wall time), a power-law fit over them, and the N^3 extrapolation from the
+    largest one (the path is N^3: unblocked Cholesky + explicit inverse) as the reported value."""
     from oracle import oracle as O
     O.build()
-    cores = min(os.cpu_count() or 1, 16)
-    Ns = 2048
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    sizes = [1024, 1536, 2048]
     t0 = time.perf_counter()
+    per = {}
     with mp.get_context("spawn").Pool(cores) as pool:
-        alone = pool.map(_cpu_eval_worker, [(kind, order, Ns, d, seed, 0)])[0]      # one core, the others idle
-        times = pool.map(_cpu_eval_worker, [(kind, order, Ns, d, seed, i) for i in range(cores)])
+        alone = pool.map(_cpu_eval_worker, [(kind, order, sizes[1], d, seed, 0)])[0]      # one core, the others idle
+        for Ns in sizes:
+            per[Ns] = float(np.mean(pool.map(_cpu_eval_worker, [(kind, order, Ns, d, seed, i) for i in range(cores)])))
     wall = time.perf_counter() - t0
-    per_eval = float(np.mean(times))
+    Ns = sizes[-1]
+    per_eval = per[Ns]
     scale = (N / Ns) ** 3
     evals_per_s = cores / (per_eval * scale)
+    # t = c N^p over the three samples (least squares in log-log): p > 3 once the matrices leave the caches
+    lx, ly = np.log(np.array(sizes, float)), np.log(np.array([per[n] for n in sizes]))
+    pfit, cfit = np.polyfit(lx, ly, 1)
+    fit_eval_s = float(np.exp(cfit) * N ** pfit)
     # predictions: emulate_point on the oracle at Ns, scaled by N^2 (three N^2 dgemv + N^2*nreg dgemm per query)
     from madaiemulator_amd import synth
     X, y = synth.design(Ns, d, seed)
@@ -84,14 +99,17 @@ def cpu_baseline(kind, order, N, d, seed):
     per_q = (time.perf_counter() - tq) / 4
     preds_per_s = cores / (per_q * (N / Ns) ** 2)
     return {
-        "value": evals_per_s, "unit": "likelihood-evals/s", "cores": cores, "kind": "port",
-        "sample": (f"one oracle evaluation alone at N={Ns}, d={d}: {alone:.2f} s; {cores} concurrent (one per core): {per_eval:.2f} s each "
-                   f"({wall:.1f} s wall); extrapolated to N={N} by (N/{Ns})^3; predictions: 4 oracle emulate_point "
-                   f"calls at N={Ns} ({per_q*1e3:.1f} ms each) scaled by (N/{Ns})^2"),
-        "value_1core": 1.0 / (alone * scale), "seconds_per_eval_at_sample_1core": alone,
+        "value": evals_per_s, "unit": "likelihood-evals/s", "cores": cores, "nproc": os.cpu_count(), "kind": "port",
+        "sample": (f"{cores} concurrent oracle evaluations (one per core) at N={sizes}, d={d}: "
+                   f"{', '.join('%.2f' % per[n] for n in sizes)} s each ({wall:.1f} s wall in all); one alone at N={sizes[1]}: "
+                   f"{alone:.2f} s; value = N={Ns} sample extrapolated to N={N} by (N/{Ns})^3; power-law fit over the three "
+                   f"samples t ~ N^{pfit:.2f} gives {fit_eval_s:.0f} s per evaluation at N={N}; predictions: 4 oracle "
+                   f"emulate_point calls at N={Ns} ({per_q*1e3:.1f} ms each) scaled by (N/{Ns})^2"),
+        "seconds_per_eval_at_samples": {str(n): per[n] for n in sizes}, "fit_exponent": float(pfit),
+        "value_from_fit": cores / fit_eval_s,
+        "value_1core": 1.0 / (alone * (N / sizes[1]) ** 3), "seconds_per_eval_alone": {str(sizes[1]): alone},
         "predictions_per_s_1core": 1.0 / (per_q * (N / Ns) ** 2),
         "predictions_per_s": preds_per_s,
-        "seconds_per_eval_at_sample": per_eval,
     }
 
 
@@ -111,7 +129,24 @@ def main():
                          "default 16 at N >= 8192, up to 64 for smaller models (the panel chain weighs more there)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-predict", action="store_true")
+    ap.add_argument("--no-grad", action="store_true", help="skip the value+gradient region")
+    ap.add_argument("--no-single", action="store_true", help="skip the one-evaluation-at-a-time latency figure")
+    ap.add_argument("--grad-steps", type=int, default=None, help="timed value+gradient batches (default min(steps, 8))")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # no launcher: start the N ranks ourselves, as fresh children, BEFORE anything in this process touches the GPU
+        # (no torch import yet), one rank per GPU over RCCL; rank 0 prints the line, which is forwarded
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.call(cmd, env=env))
 
     import torch        # torch first: its bundled HIP runtime must be the one in the process (the reverse order
     torch.cuda.is_available()   # leaves torch without a device); the device library binds to the same soname
@@ -132,6 +167,9 @@ def main():
             dist.init_process_group(backend)
     tdev = "cuda" if backend == "nccl" else "cpu"
     ngpus = world_size
+    assert world_size == max(1, args.gpus), f"--gpus {args.gpus} but the launcher started {world_size} rank(s)"
+    if distributed:
+        assert dist.get_world_size() == args.gpus
 
     def barrier():
         if distributed:
@@ -198,17 +236,30 @@ def main():
     for c in ctxs:
         c.loglik_batch_collect()
     barrier()
+    # every step's results are collected: a context keeps up to RESULT_RING - 1 batches in flight and hands back the
+    # oldest one (pinned result ring, gpemu_loglik_batch_collect_back) before the ring wraps
+    RING = abi.RESULT_RING
+    pending = [[] for _ in ctxs]            # per context: step indices enqueued and not yet collected
+    values = np.full((K, B), np.nan)
     t0 = time.perf_counter()
     for j, ch in enumerate(chunks):
-        ctxs[j % nstreams].loglik_batch_enqueue(np.array([theta(i) for i in ch]))
-    used = min(len(chunks), nstreams)
-    lasts = [c.loglik_batch_collect() for c in ctxs[:used]]
+        s_ = j % nstreams
+        c = ctxs[s_]
+        if len(pending[s_]) == RING - 1:
+            r = c.loglik_batch_collect_back(RING - 2, B)
+            assert np.all(r["status"] == 0), r
+            values[pending[s_].pop(0)] = r["value"]
+        c.loglik_batch_enqueue(np.array([theta(i) for i in ch]))
+        pending[s_].append(j)
+    for s_, c in enumerate(ctxs):
+        while pending[s_]:
+            r = c.loglik_batch_collect_back(len(pending[s_]) - 1, B)
+            assert np.all(r["status"] == 0), r
+            values[pending[s_].pop(0)] = r["value"]
     barrier()
     tA = time.perf_counter() - t0
-    lb = lasts[(len(chunks) - 1) % nstreams]
-    last = {"value": float(lb["value"][-1])}
-    for l in lasts:
-        assert np.all(l["status"] == 0) and np.all(np.isfinite(l["value"])), l
+    assert np.all(np.isfinite(values)), "a likelihood value of the timed region is not finite"
+    last = {"value": float(values[-1, -1])}
     if distributed:
         tt = torch.tensor([tA], dtype=torch.float64, device=tdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -218,6 +269,21 @@ def main():
         assert len(rows) == world_size
     evals_per_s = ngpus * K * B / tA
 
+    # one evaluation at a time on one context (the shape of a sequential caller: one BFGS run, alloc_emulator_struct;
+    # emulator_struct.c:28-32): host call to host result, i.e. `--batch 1 --streams 1`
+    single = None
+    if not args.no_single:
+        for i in range(3):
+            ctx.loglik(theta(700000 + i))
+        t0 = time.perf_counter()
+        ns = 10
+        for i in range(ns):
+            r1 = ctx.loglik(theta(710000 + i))
+            assert r1["status"] == 0 and np.isfinite(r1["value"])
+        ts = (time.perf_counter() - t0) / ns
+        single = {"ms_per_evaluation": ts * 1e3, "evals_per_s": 1.0 / ts,
+                  "frac_of_mfma_peak": (N ** 3 / 3.0) / ts / 1e12 / PEAK_FP64_MFMA_TFLOPS}
+
     # ---- region B: batched predictions, queries resident in HBM
     pred = None
     if not args.no_predict:
@@ -225,16 +291,17 @@ def main():
         ctx.predict_setup(th0)
         nb = 20
         per = -(-nq // nb)
-        Xq = synth.queries(per, d, seed + 11 + rank)
-        dq, dm, dv = ctx.dev_alloc(Xq.nbytes), ctx.dev_alloc(per * 8), ctx.dev_alloc(per * 8)
+        # nb * per DISTINCT query points, resident in HBM before the clock starts; every batch reads its own block
+        Xq = synth.queries(nb * per, d, seed + 11 + rank)
+        dq, dm, dv = ctx.dev_alloc(Xq.nbytes), ctx.dev_alloc(nb * per * 8), ctx.dev_alloc(nb * per * 8)
         ctx.upload(dq, Xq)
         for _ in range(min(W, 2)):
             ctx.predict_dev(per, dq, dm, dv)
         ctx.sync()
         barrier()
         t0 = time.perf_counter()
-        for _ in range(nb):
-            ctx.predict_dev(per, dq, dm, dv)
+        for b in range(nb):
+            ctx.predict_dev(per, dq + b * per * d * 8, dm + b * per * 8, dv + b * per * 8)
         ctx.sync()
         barrier()
         tB = time.perf_counter() - t0
@@ -242,10 +309,49 @@ def main():
             tt = torch.tensor([tB], dtype=torch.float64, device=tdev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             tB = float(tt.item())
-        mean = ctx.download(dm, (per,))
-        assert np.all(np.isfinite(mean))
+        mean = ctx.download(dm, (nb * per,))
+        var = ctx.download(dv, (nb * per,))
+        assert np.all(np.isfinite(mean)) and np.all(np.isfinite(var)) and len(np.unique(mean[:4096])) > 4000
         pred = {"value": ngpus * nb * per / tB, "unit": "predictions/s", "points_per_rank": nb * per,
-                "batches": nb, "ms_per_batch": tB / nb * 1e3}
+                "distinct_points": True, "batches": nb, "ms_per_batch": tB / nb * 1e3}
+
+    # ---- region C: value + gradient (evalFnGradMulti, maxmultimin.c:615-618 -- what estimate_thetas calls per BFGS
+    #      step), lock-step batches of Bg on a pow-exp model of the same N and d (own context, own HBM workspace)
+    vg = None
+    if not args.no_grad:
+        Bg = min(B, 16)
+        Kg = args.grad_steps if args.grad_steps else max(2, min(K, 8))
+        gctx = abi.Context(dev)
+        Xg_, yg_ = synth.design(N, d, seed + 1)
+        gctx.set_model(1, 0, Xg_, yg_)
+
+        def gtheta(i):
+            return synth.perturbed_thetas(1, d, seed + 1, rank + world_size * i)
+        for j in range(2):
+            gctx.loglik_grad_batch(np.array([gtheta(50000 + 31 * j + i) for i in range(Bg)]))
+        barrier()
+        t0 = time.perf_counter()
+        gvals = []
+        for j in range(Kg):
+            r = gctx.loglik_grad_batch(np.array([gtheta(j * Bg + i) for i in range(Bg)]))
+            assert np.all(r["status"] == 0) and np.all(np.isfinite(r["value"])) and np.all(np.isfinite(r["grad"])), r
+            gvals.append(r["value"])
+        barrier()
+        tC = time.perf_counter() - t0
+        if distributed:
+            tt = torch.tensor([tC], dtype=torch.float64, device=tdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tC = float(tt.item())
+        gflops = float(N) ** 3 * Bg * Kg                # 2N^3/3 (factorisation with the inverse rows) + N^3/3 (C^-1 = U U^T)
+        ach = gflops / tC / 1e12
+        vg = {"value": ngpus * Kg * Bg / tC, "unit": "value+gradient evals/s", "steps": Kg, "evaluations_per_step": Bg,
+              "ms_per_evaluation": tC / (Kg * Bg) * 1e3, "workload": f"pow-exp, N={N}, d={d}, regression_order=0",
+              "gradient": "literal (reference formulas)" if not (gctx.get_mode() & abi.MODE_EXACT_GRAD) else "exact",
+              "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / PEAK_FP64_MFMA_TFLOPS, "flops_per_eval": float(N) ** 3,
+                           "note": "whole host-visible call (staging, factorisation with inverse rows, U U^T, gradient "
+                                   "reductions, host finishing) against N^3 algorithmic flops per evaluation"}}
+        gctx.close()
 
     # ---- roofline of the dominant kernel (fp64 MFMA GEMM of the Cholesky trailing updates), HIP events on the
     #      ctx stream around every launch; rank 0 only
@@ -261,13 +367,18 @@ def main():
         # (profiles/r01_pmc_fetch_calibration.txt), so the whole raw fetch is doubled; WRITE_SIZE is exact.  Infinity-
         # Cache hits are included in both, i.e. this is fabric traffic, an upper bound on HBM traffic.
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_v7_nb2048.json")
-        if args.workload == "c3" and B == 16 and os.path.exists(tpath):      # measured for batches of 16
+        tpath = None
+        for cand in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic_v7_nb2048.json"):      # newest first
+            if os.path.exists(os.path.join(ROOT, "profiles", cand)):
+                tpath = os.path.join(ROOT, "profiles", cand)
+                break
+        if args.workload == "c3" and B == 16 and tpath:      # measured for batches of 16
             tj = json.load(open(tpath))["gemm_nt_kernel"]
             traffic = (2.0 * tj["fetch_bytes_raw"] + tj["write_bytes"]) / tj["launches"]
         roof = {"bound": "mfma", "kernel": "gemm_nt_kernel (potrf trailing update, v_mfma_f64_16x16x4_f64)",
                 "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS,
-                "traffic": traffic, "launches": p["n"], "avg_launch_us": p["ms"] * 1e3 / max(p["n"], 1),
+                "traffic": traffic, "traffic_source": os.path.basename(tpath) if (traffic is not None) else None,
+                "launches": p["n"], "avg_launch_us": p["ms"] * 1e3 / max(p["n"], 1),
                 "flops_per_eval": p["flops"] / B, "evaluations_per_launch": B}
         ctx.prof_begin(abi.PROF_POTRF)
         ctx.loglik_batch_enqueue(np.array([theta(3000 + i) for i in range(B)]))
@@ -313,6 +424,9 @@ def main():
                        "step": f"one lock-step batch of {B} independent likelihood evaluations"},
             "evaluations_per_step": B, "ms_per_evaluation": tA / (K * B) * 1e3,
             "predictions": pred,
+            "value_grad": vg,
+            "single_evaluation": single,
+            "rccl_ranks": (world_size if (distributed and backend == "nccl") else (1 if not distributed else 0)),
             "roofline": roof, "roofline_other": roof_other,
             "cpu_baseline": cpu,
             "speedup_vs_cpu_all_cores": (evals_per_s / cpu["value"]) if cpu else None,

@@ -103,6 +103,12 @@ int gpemu_loglik_batch(gpemu_ctx *ctx, int nb, const double *thetas, int nthetas
 int gpemu_loglik_batch_enqueue(gpemu_ctx *ctx, int nb, const double *thetas, int nthetas);
 int gpemu_loglik_batch_collect(gpemu_ctx *ctx, int nb, double *neg_loglik, double *sigma2,
                                double *beta, double *logdet, double *quad, int *info, int *status);
+/* the results of the last GPEMU_RESULT_RING enqueued batches stay readable (pinned ring): `back` = 0 is the newest
+ * batch, 1 the one before, ...  Waits for that batch only, so a throughput caller collects EVERY batch while the
+ * following ones are already running (what a restart pool consuming its results does). */
+#define GPEMU_RESULT_RING 4
+int gpemu_loglik_batch_collect_back(gpemu_ctx *ctx, int back, int nb, double *neg_loglik, double *sigma2,
+                                    double *beta, double *logdet, double *quad, int *info, int *status);
 
 /* ---- modes (SURVEY App. C2-C4 policy: literal by default, corrected forms behind flags) ----------------------
  * GPEMU_MODE_EXACT_GRAD: gpemu_grad / gpemu_loglik_grad[_batch] return the TRUE gradient of the value gpemu_loglik

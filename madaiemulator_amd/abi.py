@@ -16,6 +16,7 @@ POWEREXP, MATERN32, MATERN52 = 1, 2, 3
 OK, ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_PD, ERR_REGRESSION, ERR_STATE = range(7)
 PROF_NONE, PROF_GEMM, PROF_FILL, PROF_LEAF, PROF_POTRF = range(5)
 MODE_EXACT_GRAD, MODE_MATERN_LOG = 1, 2
+RESULT_RING = 4
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -37,6 +38,7 @@ SYMBOLS = {
     "gpemu_loglik_batch": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _ip]),
     "gpemu_loglik_batch_enqueue": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int]),
     "gpemu_loglik_batch_collect": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _ip]),
+    "gpemu_loglik_batch_collect_back": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _ip]),
     "gpemu_grad": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _ip]),
     "gpemu_loglik_grad": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _dp, _dp, _dp, _ip]),
     "gpemu_loglik_grad_batch": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, _dp, _dp, _dp, _dp, _ip, _ip]),
@@ -202,6 +204,16 @@ class Context:
         status = np.zeros(nb, dtype=np.int32)
         self._chk(self.L.gpemu_loglik_batch_collect(self.h, nb, _p(v), _p(s2), _p(beta), _p(ld), _p(qd),
                                                     info.ctypes.data_as(_ip), status.ctypes.data_as(_ip)))
+        return dict(value=v, sigma2=s2, beta=beta, logdet=ld, quad=qd, info=info, status=status)
+
+    def loglik_batch_collect_back(self, back, nb):
+        """results of the batch enqueued `back` batches before the newest (ring of RESULT_RING); waits for it only"""
+        v, s2, ld, qd = (np.full(nb, np.nan) for _ in range(4))
+        beta = np.full((nb, self.nreg), np.nan)
+        info = np.zeros(nb, dtype=np.int32)
+        status = np.zeros(nb, dtype=np.int32)
+        self._chk(self.L.gpemu_loglik_batch_collect_back(self.h, back, nb, _p(v), _p(s2), _p(beta), _p(ld), _p(qd),
+                                                         info.ctypes.data_as(_ip), status.ctypes.data_as(_ip)))
         return dict(value=v, sigma2=s2, beta=beta, logdet=ld, quad=qd, info=info, status=status)
 
     def loglik_batch(self, thetas):

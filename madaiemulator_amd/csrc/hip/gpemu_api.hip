@@ -177,8 +177,11 @@ extern "C" int gpemu_ctx_create(gpemu_ctx **out, int device)
 	ok = ok && hipMalloc(&ctx->dInfo, sizeof(int)) == hipSuccess &&
 	     hipMalloc(&ctx->dDiagInv, (size_t)GPEMU_MAX_BATCH * 8 * 256 * sizeof(double)) == hipSuccess &&
 	     hipMalloc(&ctx->dRes, ctx->res_len * sizeof(double)) == hipSuccess &&
-	     hipHostMalloc((void **)&ctx->hRes, ctx->res_len * sizeof(double)) == hipSuccess &&
-	     hipHostMalloc((void **)&ctx->hInfo, sizeof(int)) == hipSuccess;
+	     hipHostMalloc((void **)&ctx->hResRing, (size_t)gpemu_ctx::RES_RING * ctx->res_len * sizeof(double)) == hipSuccess &&
+	     hipHostMalloc((void **)&ctx->hInfoRing, (size_t)gpemu_ctx::RES_RING * sizeof(int)) == hipSuccess;
+	for (int i = 0; ok && i < gpemu_ctx::RES_RING; i++)
+		ok = hipEventCreateWithFlags(&ctx->res_ev[i], hipEventDisableTiming) == hipSuccess;
+	ctx->hRes = ctx->hResRing; ctx->hInfo = ctx->hInfoRing;
 	const char *tr = getenv("GPEMU_TRACE");
 	if (ok && tr && atoi(tr) > 0) {                 // in-kernel timestamps: 4096 launch slots of 8 x u64
 		ctx->trace_cap = 4096;
@@ -236,8 +239,9 @@ extern "C" void gpemu_ctx_destroy(gpemu_ctx *ctx)
 	if (ctx->dSymV) hipFree(ctx->dSymV);
 	if (ctx->dSymOut) hipFree(ctx->dSymOut);
 	if (ctx->dRes) hipFree(ctx->dRes);
-	if (ctx->hRes) hipHostFree(ctx->hRes);
-	if (ctx->hInfo) hipHostFree(ctx->hInfo);
+	if (ctx->hResRing) hipHostFree(ctx->hResRing);
+	if (ctx->hInfoRing) hipHostFree(ctx->hInfoRing);
+	for (auto e : ctx->res_ev) if (e) hipEventDestroy(e);
 	if (ctx->hStage) hipHostFree(ctx->hStage);
 	for (auto e : ctx->ev_pool) hipEventDestroy(e);
 	if (ctx->stream2) hipStreamDestroy(ctx->stream2);
@@ -321,14 +325,16 @@ static int ensure_batch_slots(gpemu_ctx *ctx, int nb)
 	free_graphs(ctx);                      // captured launches hold the old pointers
 	if (ctx->dInfo) hipFree(ctx->dInfo);
 	if (ctx->dRes) hipFree(ctx->dRes);
-	if (ctx->hRes) hipHostFree(ctx->hRes);
-	if (ctx->hInfo) hipHostFree(ctx->hInfo);
+	if (ctx->hResRing) hipHostFree(ctx->hResRing);
+	if (ctx->hInfoRing) hipHostFree(ctx->hInfoRing);
 	if (ctx->dGramPart) hipFree(ctx->dGramPart);
-	ctx->dInfo = nullptr; ctx->dRes = nullptr; ctx->hRes = nullptr; ctx->hInfo = nullptr; ctx->dGramPart = nullptr;
+	ctx->dInfo = nullptr; ctx->dRes = nullptr; ctx->hRes = ctx->hResRing = nullptr; ctx->hInfo = ctx->hInfoRing = nullptr; ctx->dGramPart = nullptr;
+	ctx->res_seq = 0;                      // results still in the old ring are gone with it
 	HIPCHK(ctx, hipMalloc(&ctx->dInfo, (size_t)nb * sizeof(int)));
 	HIPCHK(ctx, hipMalloc(&ctx->dRes, (size_t)nb * ctx->res_len * sizeof(double)));
-	HIPCHK(ctx, hipHostMalloc((void **)&ctx->hRes, (size_t)nb * ctx->res_len * sizeof(double)));
-	HIPCHK(ctx, hipHostMalloc((void **)&ctx->hInfo, (size_t)nb * sizeof(int)));
+	HIPCHK(ctx, hipHostMalloc((void **)&ctx->hResRing, (size_t)gpemu_ctx::RES_RING * nb * ctx->res_len * sizeof(double)));
+	HIPCHK(ctx, hipHostMalloc((void **)&ctx->hInfoRing, (size_t)gpemu_ctx::RES_RING * nb * sizeof(int)));
+	ctx->hRes = ctx->hResRing; ctx->hInfo = ctx->hInfoRing;
 	HIPCHK(ctx, hipMalloc(&ctx->dGramPart, (size_t)nb * (ctx->Np / 64) * ctx->Rp * ctx->Rp * sizeof(double)));
 	ctx->batch_cap = nb;
 	return GPEMU_OK;
@@ -620,9 +626,17 @@ static int enqueue_results(gpemu_ctx *ctx)
 	                                 (long)ctx->T_stride));
 	HIPCHK(ctx, launch_finish(ctx->stream, ctx->dGramPart, Np / 64, Rp, ctx->nrhs, ctx->dT, Np, ctx->N, ctx->dRes, nb,
 	                          (long)ctx->T_stride, (long)ctx->res_len));
+	// the results land in the next slot of a pinned ring (RES_RING batches stay readable: a throughput caller collects
+	// batch j while batches j+1 .. j+RES_RING-1 are in flight); hRes / hInfo point at the newest slot
+	const int slot = (int)(ctx->res_seq % gpemu_ctx::RES_RING);
+	ctx->res_seq++;
+	ctx->hRes = ctx->hResRing + (size_t)slot * ctx->batch_cap * ctx->res_len;
+	ctx->hInfo = ctx->hInfoRing + (size_t)slot * ctx->batch_cap;
+	ctx->res_nb[slot] = nb;
 	HIPCHK(ctx, hipMemcpyAsync(ctx->hRes, ctx->dRes, ((size_t)(nb - 1) * ctx->res_len + (size_t)Rp * Rp + 1) * sizeof(double),
 	                           hipMemcpyDeviceToHost, ctx->stream));
 	HIPCHK(ctx, hipMemcpyAsync(ctx->hInfo, ctx->dInfo, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(ctx, hipEventRecord(ctx->res_ev[slot], ctx->stream));
 	return GPEMU_OK;
 }
 
@@ -760,6 +774,30 @@ extern "C" int gpemu_loglik_batch_collect(gpemu_ctx *ctx, int nb, double *neg_lo
 		                           quad ? quad + b : nullptr, info ? info + b : nullptr);
 		if (status) status[b] = rc;
 	}
+	return GPEMU_OK;
+}
+
+// results of the batch enqueued `back` batches before the newest one (0 = newest); waits for THAT batch only
+extern "C" int gpemu_loglik_batch_collect_back(gpemu_ctx *ctx, int back, int nb, double *neg_loglik, double *sigma2,
+                                               double *beta, double *logdet, double *quad, int *info, int *status)
+{
+	if (!ctx) return GPEMU_ERR_ARG;
+	if (back < 0 || back >= gpemu_ctx::RES_RING || (unsigned long long)back >= ctx->res_seq)
+		return fail(ctx, GPEMU_ERR_STATE, "no such batch in the result ring");
+	const int slot = (int)((ctx->res_seq - 1 - (unsigned long long)back) % gpemu_ctx::RES_RING);
+	if (nb < 1 || nb != ctx->res_nb[slot]) return fail(ctx, GPEMU_ERR_STATE, "batch size differs from the enqueued batch");
+	HIPCHK(ctx, hipEventSynchronize(ctx->res_ev[slot]));
+	double *saveR = ctx->hRes;
+	int *saveI = ctx->hInfo;
+	ctx->hRes = ctx->hResRing + (size_t)slot * ctx->batch_cap * ctx->res_len;
+	ctx->hInfo = ctx->hInfoRing + (size_t)slot * ctx->batch_cap;
+	for (int b = 0; b < nb; b++) {
+		const int rc = collect_one(ctx, b, neg_loglik ? neg_loglik + b : nullptr, sigma2 ? sigma2 + b : nullptr,
+		                           beta ? beta + (size_t)b * ctx->nreg : nullptr, logdet ? logdet + b : nullptr,
+		                           quad ? quad + b : nullptr, info ? info + b : nullptr);
+		if (status) status[b] = rc;
+	}
+	ctx->hRes = saveR; ctx->hInfo = saveI;
 	return GPEMU_OK;
 }
 

@@ -96,8 +96,14 @@ struct gpemu_ctx {
 	double *dDiagInv = nullptr;  // eight inverted 16x16 diagonal blocks of the current 128-column leaf
 	double *dGramPart = nullptr; // [Np/128][Rp*Rp]
 	double *dRes = nullptr;      // Rp*Rp gram + logdet + spare
-	double *hRes = nullptr;      // pinned mirror
-	int *hInfo = nullptr;        // pinned
+	double *hRes = nullptr;      // pinned mirror: the newest slot of the ring below
+	int *hInfo = nullptr;        // pinned, likewise
+	static constexpr int RES_RING = 4;   // result slots: batch j stays readable while j+1 .. j+3 are enqueued
+	double *hResRing = nullptr;  // RES_RING x batch_cap x res_len
+	int *hInfoRing = nullptr;    // RES_RING x batch_cap
+	hipEvent_t res_ev[RES_RING] = {nullptr, nullptr, nullptr, nullptr};   // recorded behind the copies into a slot
+	int res_nb[RES_RING] = {0, 0, 0, 0};
+	unsigned long long res_seq = 0;      // batches enqueued since the ring was (re)allocated
 	size_t res_len = 0;
 
 	// cached launch graphs for potrf, keyed by (Np, rows_total, with_inverse)

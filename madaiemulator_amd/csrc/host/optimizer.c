@@ -57,6 +57,8 @@ void set_random_init_value(gsl_rng *rand, gsl_vector *x, gsl_matrix *ranges, int
 	}
 }
 
+static int env_flag(const char *name) { const char *e = getenv(name); return e && atoi(e) > 0; }
+
 /* ------------------------------------------------------------------ BFGS */
 struct fdf {
 	void (*fdf)(const gsl_vector *, void *, double *, gsl_vector *);
@@ -116,6 +118,17 @@ static int line_search(struct fdf *F, const double *x, double f0, const double *
 #define NOTE_TRIAL() do { if (fa < best_f) { best_f = fa; best_a = a; memcpy(best_g, g, sizeof(double) * (size_t)n); } } while (0)
 #define LS_RETURN(code) do { free(g); free(best_g); return (code); } while (0)
 	const int debug = getenv("GPEMU_OPT_DEBUG") != NULL;
+	/* With the exact gradient (GPEMU_EXACT_GRAD, gpemu.h) the search is an ordinary strong-Wolfe search on a smooth
+	 * function and is given the sections it needs: -logL has plateaus (all length scales large) next to walls (a
+	 * vanishing nugget), so a bracket can be 10^5 times wider than the acceptable interval.  With the literal
+	 * gradient the tests cannot be trusted (see above) and the search gives up early. */
+	const int exact = env_flag("GPEMU_EXACT_GRAD");
+	const int max_zoom = exact ? 48 : 16;
+	/* no trial point further than 6 log-units from x in any hyper-parameter (a factor 400 in a length scale) */
+	double pmax = 0.0;
+	for (int i = 0; i < n; i++) if (fabs(p[i]) > pmax) pmax = fabs(p[i]);
+	const double amax = pmax > 0.0 ? 6.0 / pmax : HUGE_VAL;
+	if (a > amax) a = amax;
 	if (debug) fprintf(stderr, "#   ls f0 %.10g d0 %.4g alpha1 %.4g\n", f0, d0, alpha1);
 	for (int it = 0; it < 12 && !bracketed; it++) {
 		fa = phi(F, x, p, a, g, &da, xt, gt);
@@ -126,12 +139,21 @@ static int line_search(struct fdf *F, const double *x, double f0, const double *
 		}
 		if (fabs(da) <= -sigma * d0) { *alpha_out = a; *f_out = fa; memcpy(g_out, g, sizeof(double) * (size_t)n); LS_RETURN(0); }
 		if (da >= 0.0) { lo = a; flo = fa; dlo = da; hi = a_prev; fhi = f_prev; dhi = d_prev; bracketed = 1; break; }
+		if (a >= amax) {
+			/* sufficient decrease at the step bound, still descending: take the bounded step (More-Thuente's
+			 * "step at the upper bound"), the next iteration searches from there */
+			*alpha_out = a; *f_out = fa; memcpy(g_out, g, sizeof(double) * (size_t)n); LS_RETURN(0);
+		}
 		a_prev = a; f_prev = fa; d_prev = da;
 		a *= 2.5;
+		if (a > amax) a = amax;
 	}
 	if (!bracketed) goto fallback;
-	for (int it = 0; it < 16; it++) {
+	for (int it = 0; it < max_zoom; it++) {
 		a = cubic_min(lo, flo, dlo, hi, fhi, dhi);
+		/* a wall at the far end (value not finite, or orders of magnitude above the drop on offer): the acceptable
+		 * points hug lo, halving the bracket would take dozens of sections */
+		if (isinf(fhi) || fhi - f0 > 1e3 * fmax(fabs(d0 * (hi - lo)), fabs(f0 - flo))) a = lo + 0.1 * (hi - lo);
 		fa = phi(F, x, p, a, g, &da, xt, gt);
 		if (debug) fprintf(stderr, "#   ls zoom [%.4g,%.4g] a %.4g fa %.10g da %.4g\n", lo, hi, a, fa, da);
 		NOTE_TRIAL();
@@ -143,7 +165,7 @@ static int line_search(struct fdf *F, const double *x, double f0, const double *
 			lo = a; flo = fa; dlo = da;
 		}
 		if (fabs(hi - lo) < 1e-10 * fmax(1.0, fabs(lo))) break;
-		if (best_f < f0 && it >= 5) break;         /* six sections without an acceptable point: take the best decrease */
+		if (!exact && best_f < f0 && it >= 5) break;   /* six sections without an acceptable point: take the best decrease */
 	}
 	/* accept the best sufficient-decrease point seen, if any */
 fallback:
@@ -327,8 +349,6 @@ static void *worker_main(void *arg)
 	if (w->in_group) gpemu_host_group_leave(&w->params);
 	return NULL;
 }
-
-static int env_flag(const char *name) { const char *e = getenv(name); return e && atoi(e) > 0; }
 
 /* libEmu/estimate_threaded.c:78-237.  The reference starts one pthread per CPU, each running jobs of 50 restarts
  * on its own copy of the model.  Here the restarts run as LOCK-STEP GROUPS (default): up to 16 host threads per

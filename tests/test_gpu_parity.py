@@ -278,6 +278,29 @@ def test_loglik_batch_pipeline_and_size_change(gpu_ctx):
     assert rc == 0 and relerr(beta, gpu_ctx.loglik(ths[0])["beta"]) < 1e-12
 
 
+def test_result_ring_keeps_every_batch_of_a_pipeline(gpu_ctx):
+    """gpemu_loglik_batch_collect_back: the results of the last RESULT_RING enqueued batches stay readable, so a caller
+    that keeps the stream busy still collects EVERY batch (bench.py does; a restart pool consuming results would)"""
+    X, y = synth.design(700, 8, 21)
+    gpu_ctx.set_model(3, 1, X, y)
+    batches = [np.array([synth.perturbed_thetas(3, 8, 40 + j, i) for i in range(3)]) for j in range(7)]
+    ref = [gpu_ctx.loglik_batch(b) for b in batches]
+    R = abi.RESULT_RING
+    got = {}
+    for j, b in enumerate(batches):
+        if j >= R - 1:                                    # the ring is about to wrap: take the oldest batch still in it
+            got[j - (R - 1)] = gpu_ctx.loglik_batch_collect_back(R - 2, 3)
+        gpu_ctx.loglik_batch_enqueue(b)
+    for back in range(R - 2, -1, -1):
+        got[len(batches) - 1 - back] = gpu_ctx.loglik_batch_collect_back(back, 3)
+    assert sorted(got) == list(range(len(batches)))
+    for j in range(len(batches)):
+        assert np.array_equal(got[j]["value"], ref[j]["value"]) and np.array_equal(got[j]["beta"], ref[j]["beta"])
+    with pytest.raises(abi.GpemuError) as e:
+        gpu_ctx.loglik_batch_collect_back(R, 3)
+    assert e.value.code == abi.ERR_STATE
+
+
 def test_set_training_swaps_outputs(gpu_ctx):
     # multi_modelstruct: one design, nr training vectors
     X, y = synth.design(300, 3, 6)
