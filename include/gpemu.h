@@ -225,6 +225,10 @@ int gpemu_test_gemm_bench(gpemu_ctx *ctx, int m, int n, int k, int ld, int cfg, 
 /* in-place lower Cholesky of a host n*n matrix (both triangles read as lower);
  * returns L in the lower triangle, zeros above. */
 int gpemu_test_potrf(gpemu_ctx *ctx, int n, double *a, int *info);
+/* the matrix a lock-step batch is factored FROM: stages nb matrices as gpemu_loglik_batch does (one launch of the batch
+ * staging kernel, lower tiles only) and copies the N x N block of matrix b to out[N*N] without factorising; tiles
+ * strictly above the diagonal are not written by that path. */
+int gpemu_test_staged_matrix(gpemu_ctx *ctx, int nb, const double *thetas, int nthetas, int b, double *out);
 /* the workgroup -> tile table of a GEMM launch with tiles_m x tiles_n tiles (tri = 1: lower triangle) and super-blocks
  * of sb x sb tiles: entry q * 8 + x is the q-th tile of XCD x, (tm << 16) | tn, or -1 (unused tail slot).  Host logic
  * only (no device).  Returns the table length, or -GPEMU_ERR_ARG; writes min(length, cap) entries to out. */

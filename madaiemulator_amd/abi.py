@@ -67,6 +67,7 @@ SYMBOLS = {
     "gpemu_test_gemm_bench": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, _dp, _dp]),
     "gpemu_test_potrf": (C.c_int, [C.c_void_p, C.c_int, _dp, _ip]),
+    "gpemu_test_staged_matrix": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, C.c_int, _dp]),
     "gpemu_test_tile_table": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _ip, C.c_int]),
 }
 
@@ -365,6 +366,13 @@ class Context:
         ms, fl = C.c_double(0), C.c_double(0)
         self._chk(self.L.gpemu_test_gemm_bench(self.h, m, n, k, ld, cfg, tri, beta, reps, C.byref(ms), C.byref(fl)))
         return ms.value, fl.value
+
+    def staged_matrix(self, thetas, b=0):
+        """N x N block of matrix b as the batch staging launch (FILL_LOWER) leaves it; upper tiles are not written"""
+        th = _a(thetas).reshape(-1, np.shape(thetas)[-1])
+        out = np.zeros((self.N, self.N))
+        self._chk(self.L.gpemu_test_staged_matrix(self.h, th.shape[0], _p(th), th.shape[1], int(b), _p(out)))
+        return out
 
     def test_potrf(self, A):
         A = _a(A).copy()

@@ -1625,6 +1625,30 @@ extern "C" int gpemu_test_gemm_nt(gpemu_ctx *ctx, int m, int n, int k, double al
 	return GPEMU_OK;
 }
 
+// The matrix a lock-step batch is factored from: stages nb matrices exactly as gpemu_loglik_batch does (ONE launch of
+// cov_stage_batch_kernel: lower tiles only, every matrix its own hyper-parameters) and copies the N x N block of matrix b
+// to the host without factorising.  Tiles strictly above the diagonal are not written by that path (out keeps what the
+// workspace held there).
+extern "C" int gpemu_test_staged_matrix(gpemu_ctx *ctx, int nb, const double *thetas, int nthetas, int b, double *out)
+{
+	if (!ctx || !thetas || !out || nb < 1 || nb > GPEMU_MAX_BATCH || b < 0 || b >= nb) return GPEMU_ERR_ARG;
+	if (!ctx->dX) return fail(ctx, GPEMU_ERR_STATE, "model not set");
+	std::vector<CovParams> ps((size_t)nb);
+	for (int i = 0; i < nb; i++) {
+		int rc = make_cov_params(ctx, thetas + (size_t)i * nthetas, nthetas, &ps[i]);
+		if (rc) return rc;
+	}
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	ctx->pred_ready = false; ctx->cinv_ready = false;
+	int rc = stage_matrices(ctx, ps.data(), nb, 0);
+	if (rc) return rc;
+	const int N = ctx->N, Np = ctx->Np;
+	HIPCHK(ctx, hipMemcpy2DAsync(out, (size_t)N * sizeof(double), ctx->dT + (size_t)b * ctx->T_stride, (size_t)Np * sizeof(double),
+	                             (size_t)N * sizeof(double), N, hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	return GPEMU_OK;
+}
+
 // the GEMM tile order of a launch with tiles_m x tiles_n tiles (tri: lower triangle only) and super-blocks of side sb:
 // pure host logic, no device needed.  Returns the table length; fills out[0 .. min(len, cap)).
 extern "C" int gpemu_test_tile_table(int tiles_m, int tiles_n, int tri, int sb, int *out, int cap)

@@ -19,6 +19,13 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden2():
+    """round-2 fixtures (tests/golden/make_golden_v2.py): mpmath-checked gradient / Matern prediction vectors, G6/G7"""
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "golden_v2.npz"))
+
+
+@pytest.fixture(scope="session")
 def ref_inputs():
     """the reference's own example inputs (data files copied into tests/golden/ref_inputs)"""
     import numpy as np

@@ -326,6 +326,28 @@ def test_grad_vs_oracle(gpu_ctx, N, d, order):
     assert np.allclose(g, ref, rtol=1e-7, atol=1e-7 * np.abs(ref).max())
 
 
+def test_grad_and_matern_prediction_golden_v2(gpu_ctx, ref_inputs, golden2):
+    """round-2 fixtures whose independent re-derivation is mpmath at 50 digits (tests/golden/make_golden_v2.py):
+    G4mp literal gradient d=1 and d=3, G5mp Matern 5/2 prediction"""
+    X1, y1 = ref_inputs["uni"]
+    gpu_ctx.set_model(1, 1, X1, y1)
+    g, rc = gpu_ctx.grad(np.array([0.3, -3.0, -0.4]))
+    ref = golden2["g4mp_uni"]
+    assert rc == 0 and np.allclose(g, ref, rtol=1e-8, atol=1e-8 * np.abs(ref).max())
+    X3, _ = ref_inputs["multi"]
+    gpu_ctx.set_model(1, 0, X3[:34], golden2["g4mp_y34"])
+    g, rc = gpu_ctx.grad(golden2["g4mp_th3"])
+    ref = golden2["g4mp_multi34"]
+    assert rc == 0 and np.allclose(g, ref, rtol=1e-8, atol=1e-8 * np.abs(ref).max())
+    gpu_ctx.set_model(3, 1, X1, y1)
+    th = golden2["g5mp_th"]
+    _, rc = gpu_ctx.predict_setup(th)
+    m, v = gpu_ctx.predict(golden2["g5mp_q"])
+    assert rc == 0
+    assert np.max(np.abs(m - golden2["g5mp_mean"])) < RTOL * max(1.0, np.abs(golden2["g5mp_mean"]).max())
+    assert np.max(np.abs(v - golden2["g5mp_var"])) < RTOL * (th[0] + th[1])
+
+
 @pytest.mark.parametrize("N,d,index,tl", [(130, 3, 2, -0.4), (257, 3, 4, -1.3), (64, 1, 2, 0.7)])
 def test_derivative_l_gauss_materialised(gpu_ctx, N, d, index, tl):
     """a5 written out (emulator.c:173-209): the literal one-coordinate derivative matrix against the oracle, and
@@ -589,6 +611,114 @@ def test_full_size_properties(gpu_ctx, kind, N):
     # (4) away from the design the variance lies in (0, kappa + regression term] and the mean is finite
     m, v = gpu_ctx.predict(synth.queries(4096, d, 99))
     assert np.all(np.isfinite(m)) and np.all(v > 0) and np.all(v < 2.0 * kappa)
+
+
+# ------------------------------------------------------------------ BASELINE sizes against the ORACLE itself
+def _sample_pairs(N, rng, n_random=10000):
+    """(i, j <= i) index pairs: random, diagonal, last row, last tile column, first column"""
+    i = rng.integers(0, N, n_random)
+    j = (rng.random(n_random) * (i + 1)).astype(np.int64)
+    diag = rng.integers(0, N, 400)
+    last_row_j = rng.integers(0, N, 300)
+    ltc_j = rng.integers(N - 64, N, 300)                          # last tile column: j in the last 64, i >= j
+    ltc_i = ltc_j + (rng.random(300) * (N - ltc_j)).astype(np.int64)
+    fc_i = rng.integers(0, N, 200)
+    I = np.concatenate([i, diag, np.full(300, N - 1), ltc_i, fc_i, [0, N - 1, N - 1, 63, 64, 64]])
+    J = np.concatenate([j, diag, last_row_j, ltc_j, np.zeros(200, np.int64), [0, N - 1, 0, 63, 63, 64]])
+    return I.astype(np.int64), J.astype(np.int64)
+
+
+@pytest.mark.parametrize("kind,N", [(3, 8192), (1, 16384)])
+def test_full_size_fill_elements_against_the_oracle(gpu_ctx, kind, N):
+    """BASELINE.json configs[2] and configs[4] sizes: > 10^4 sampled elements of the device fill -- random lower pairs,
+    diagonal, last row, last tile column, duplicated design points (off-diagonal nugget, emulator.c:136-150) -- against
+    the oracle's covariance function (emulator.c:101-152, 438-480 restated) at 1e-13, for BOTH fill paths: the 2-D
+    cov_fill_kernel (gpemu_cov_matrix) and the one-launch lower-tile staging of a lock-step batch (what
+    gpemu_loglik_batch factors), element 0 and the last element of a batch of 3."""
+    d = 8
+    X, y = synth.design(N, d, 20261003 + kind)
+    X = X.copy()
+    dups = [(N - 1, 5), (4097, 4096), (N // 2 + 63, 64), (1000, 999)]      # row i repeats row j
+    for i, j in dups:
+        X[i] = X[j]
+    rng = np.random.default_rng(kind * 1000 + N)
+    I, J = _sample_pairs(N, rng)
+    I = np.concatenate([I, [p[0] for p in dups]])
+    J = np.concatenate([J, [p[1] for p in dups]])
+    assert len(I) > 10000 and np.all(J <= I)
+    ths = np.array([synth.perturbed_thetas(kind, d, 5, i) for i in range(3)])
+    gpu_ctx.set_model(kind, 0, X, y)
+
+    def ref_for(th):
+        return np.array([O.cov(kind, X[a], X[b], th) for a, b in zip(I, J)])
+
+    refs = [ref_for(th) for th in ths]
+    # the duplicated pairs carry the nugget off the diagonal
+    th0 = ths[0]
+    nug = th0[1] if kind != 1 else np.exp(th0[1])
+    amp = th0[0] if kind != 1 else np.exp(th0[0])
+    assert np.allclose(refs[0][-len(dups):], amp + nug, rtol=1e-15)
+    # (a) 2-D fill, full matrix
+    Cm = gpu_ctx.cov_matrix(th0)
+    got = Cm[I, J]
+    assert np.max(np.abs(got - refs[0]) / np.abs(refs[0])) < ELEM_RTOL
+    assert np.array_equal(Cm[J, I], got)                         # both triangles computed, symmetric
+    del Cm
+    # (b) the staging launch of a lock-step batch (lower tiles only), first and last matrix of the batch
+    for b in (0, 2):
+        Sm = gpu_ctx.staged_matrix(ths, b)
+        got = Sm[I, J]
+        assert np.max(np.abs(got - refs[b]) / np.abs(refs[b])) < ELEM_RTOL, b
+        del Sm
+
+
+def _oracle_eval_worker(args):
+    kind, order, N, d, seed, th = args
+    X, y = synth.design(N, d, seed)
+    return O.eval_fn_multi(kind, order, X, y, np.asarray(th)[1:])
+
+
+def _oracle_emulate_worker(args):
+    kind, order, N, d, seed, th, qseed = args
+    X, y = synth.design(N, d, seed)
+    e = O.Emulator(kind, order, X, y, np.asarray(th))
+    m, v, st = e.emulate(synth.queries(64, d, qseed))
+    return m, v, st, e.beta, e.logdet
+
+
+def test_n4096_full_oracle_evaluation_and_predictions(gpu_ctx):
+    """BASELINE.json configs[1] (N=4096, d=8, pow-exp): ONE full oracle evalFnMulti (maxmultimin.c:288-394 restated:
+    fill, unblocked Cholesky, explicit inverse, estimateBeta twice) and 64 oracle emulate_point calls
+    (emulator_struct.c:124-143, emulator.c:672-785) against gpemu_loglik / gpemu_predict_batch at the parity bar.
+    Two oracle passes of ~N^3 each: they run side by side on two host cores (about four minutes)."""
+    import multiprocessing as mp
+    kind, order, N, d, seed = 1, 0, 4096, 8, 20261003 + 1
+    th = synth.default_thetas(kind, d).copy()
+    th[0] = 0.0                                               # evalFnMulti's theta[0] (maxmultimin.c:311)
+    with mp.get_context("spawn").Pool(2) as pool:
+        ra = pool.map_async(_oracle_eval_worker, [(kind, order, N, d, seed, th.tolist())])
+        rb = pool.map_async(_oracle_emulate_worker, [(kind, order, N, d, seed, th.tolist(), 321)])
+        # the device side meanwhile
+        X, y = synth.design(N, d, seed)
+        gpu_ctx.set_model(kind, order, X, y)
+        got = gpu_ctx.loglik(th)
+        gotb = gpu_ctx.loglik_batch(np.array([th, synth.perturbed_thetas(kind, d, 9, 1), th]))
+        gpu_ctx.predict_setup(th)
+        Xq = synth.queries(64, d, 321)
+        m, v = gpu_ctx.predict(Xq)
+        o = ra.get(timeout=850)[0]
+        mo, vo, st, obeta, ologdet = rb.get(timeout=850)[0]
+    assert got["status"] == 0 and o["info"] == 0
+    assert got["value"] == pytest.approx(o["value"], rel=RTOL)
+    assert got["sigma2"] == pytest.approx(o["sigma2"], rel=RTOL)
+    assert got["logdet"] == pytest.approx(o["logdet"], rel=RTOL)
+    assert got["quad"] == pytest.approx(o["quad"], rel=RTOL)
+    assert relerr(got["beta"], o["beta"]) < RTOL
+    assert gotb["value"][0] == got["value"] and gotb["value"][2] == got["value"]     # batch element = single evaluation
+    assert relerr(got["beta"], obeta) < RTOL and got["logdet"] == pytest.approx(ologdet, rel=RTOL)
+    kappa = np.exp(th[0]) + np.exp(th[1])
+    assert np.max(np.abs(m - mo)) < RTOL * max(1.0, np.abs(mo).max())
+    assert np.max(np.abs(v - vo)) < RTOL * kappa
 
 
 # ------------------------------------------------------------------ ragged and extreme shapes

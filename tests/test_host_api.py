@@ -113,6 +113,31 @@ def test_host_logic_without_gpu(tmp_path):
     assert not np.allclose(dd[0], dd[0].T)               # path dependent: not even symmetric
 
 
+G6SNAP = os.path.join(ROOT, "tests", "golden", "g6_multi_snapshot.txt")
+
+
+def test_snapshot_golden_g7_roundtrips_byte_for_byte(driver, tmp_path):
+    """G7: the hand-written MODEL_SNAPSHOT_FILE fixture (reference grammar and printf formats, multi_modelstruct.c:346-401,
+    modelstruct.c:375-409) goes through load_multi_modelstruct -> dump_multi_modelstruct unchanged.  Host code only."""
+    out = tmp_path / "g6_again.txt"
+    res = parse(run([driver, "roundtrip", G6SNAP, str(out)]))
+    assert res["nt"][0][0] == 6
+    assert out.read_bytes() == open(G6SNAP, "rb").read()
+
+
+@pytest.mark.gpu
+def test_multi_output_golden_g6_through_the_c_layer(driver, tmp_path):
+    """G6: load the fixture snapshot, alloc_multi_emulator, emulate_point_multi at the fixture's 16 queries (13 random +
+    3 training points): observable-space means and variances against the golden vectors"""
+    g2 = np.load(os.path.join(ROOT, "tests", "golden", "golden_v2.npz"))
+    qf = tmp_path / "q.dat"
+    np.savetxt(qf, g2["g6_q"], fmt="%.17g")
+    res = parse(run([driver, "multi", G6SNAP, str(qf)]))
+    pred = np.array(res["pred"]).reshape(len(g2["g6_q"]), -1, 2)
+    assert np.max(np.abs(pred[:, :, 0] - g2["g6_mean"])) < 1e-8 * max(1.0, np.abs(g2["g6_mean"]).max())
+    assert np.max(np.abs(pred[:, :, 1] - g2["g6_var"])) < 1e-8 * max(1e-3, np.abs(g2["g6_var"]).max())
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("path,d,order", [(UNI, 1, 0), (UNI, 1, 1), (TWOD, 2, 1)])
 def test_evalfn_gradfn_like_gsl_multimin_would_call_them(driver, path, d, order):

@@ -148,3 +148,59 @@ def test_pca_backprojection():
     mo, vo = O.pca_backproject(ybar, evals, evecs, m, v)
     assert np.allclose(mo, ybar + evecs @ (np.sqrt(evals) * m))
     assert np.allclose(vo, (evecs ** 2) @ (evals * v))
+
+
+# ------------------------------------------------------------------ round-2 fixtures (make_golden_v2.py)
+def test_gradient_golden_mpmath_checked(golden2, ref_inputs):
+    """G4mp: gradFnMulti vectors that make_golden_v2.py re-derived with mpmath at 50 digits (1e-9)"""
+    X1, y1 = ref_inputs["uni"]
+    g, st = O.grad_fn_multi(1, 1, X1, y1, np.array([-3.0, -0.4]))
+    assert st == 0 and np.array_equal(g, golden2["g4mp_uni"])
+    X3, _ = ref_inputs["multi"]
+    g, st = O.grad_fn_multi(1, 0, X3[:34], golden2["g4mp_y34"], golden2["g4mp_th3"][1:])
+    assert st == 0 and np.array_equal(g, golden2["g4mp_multi34"])
+
+
+def test_matern_prediction_golden_mpmath_checked(golden2, ref_inputs):
+    """G5mp: emulate_point, Matern 5/2, regression order 1, uni-simple"""
+    X1, y1 = ref_inputs["uni"]
+    e = O.Emulator(3, 1, X1, y1, golden2["g5mp_th"])
+    m, v, st = e.emulate(golden2["g5mp_q"])
+    assert np.array_equal(m, golden2["g5mp_mean"]) and np.array_equal(v, golden2["g5mp_var"])
+
+
+def _parse_g6():
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g6_multi_snapshot.txt")
+    toks = open(here).read().split()
+    nt, nr, d, N, cov, order = (int(t) for t in toks[:6])
+    pos = 6
+    X = np.array(toks[pos:pos + N * d], float).reshape(N, d); pos += N * d
+    Y = np.array(toks[pos:pos + N * nt], float).reshape(N, nt); pos += N * nt
+    ev = np.array(toks[pos:pos + nr], float); pos += nr
+    evc = np.array(toks[pos:pos + nt * nr], float).reshape(nt, nr); pos += nt * nr
+    Z = np.array(toks[pos:pos + N * nr], float).reshape(N, nr); pos += N * nr
+    thetas = []
+    for c in range(nr):
+        nth = int(toks[pos])
+        blk = pos + 10 + 2 * nth + N * d
+        thetas.append(np.array(toks[blk + N:blk + N + nth], float))
+        pos = blk + N + nth + d
+    assert pos == len(toks)
+    return here, dict(X=X, Y=Y, evals=ev, evecs=evc, Z=Z, thetas=thetas, cov=cov, order=order)
+
+
+def test_multi_output_golden_g6(golden2):
+    """G6: emulate_point_multi (multivar_support.c:103-157) on the hand-written multi-simple snapshot: oracle per PCA
+    component + the reference's back-projection reproduce the fixture"""
+    _, s = _parse_g6()
+    Q = golden2["g6_q"]
+    nr = len(s["thetas"])
+    mr, vr = np.empty((len(Q), nr)), np.empty((len(Q), nr))
+    for c in range(nr):
+        e = O.Emulator(s["cov"], s["order"], s["X"], s["Z"][:, c], s["thetas"][c])
+        mr[:, c], vr[:, c], _ = e.emulate(Q)
+    ybar = s["Y"].mean(axis=0)
+    for q in range(len(Q)):
+        mo, vo = O.pca_backproject(ybar, s["evals"], s["evecs"], mr[q], vr[q])
+        assert np.array_equal(mo, golden2["g6_mean"][q]) and np.array_equal(vo, golden2["g6_var"][q])
