@@ -26,6 +26,7 @@ rank 0's line; under the driver's own torchrun launch the ranks are already ther
 Prints ONE JSON line on rank 0 (contract in the task statement) with "roofline" and "cpu_baseline" objects.
 """
 import argparse
+import ctypes as C
 import json
 import multiprocessing as mp
 import os
@@ -301,7 +302,8 @@ def main():
         barrier()
         t0 = time.perf_counter()
         for b in range(nb):
-            ctx.predict_dev(per, dq + b * per * d * 8, dm + b * per * 8, dv + b * per * 8)
+            ctx.predict_dev(per, C.c_void_p(dq.value + b * per * d * 8), C.c_void_p(dm.value + b * per * 8),
+                            C.c_void_p(dv.value + b * per * 8))
         ctx.sync()
         barrier()
         tB = time.perf_counter() - t0

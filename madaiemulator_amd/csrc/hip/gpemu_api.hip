@@ -26,6 +26,7 @@ using namespace gpemu;
 
 static int g_leaf128 = 0;                // 128-column fused leaves (env GPEMU_LEAF128=1); measured 3 % slower than 64
 static int g_lookahead = 0;              // two-stream schedule of the outer panels (env GPEMU_LOOKAHEAD=1); see DESIGN.md
+static int g_fill_gram = 1;              // MFMA Gram form of the training fill (env GPEMU_FILL_GRAM=0: difference form always)
 static int g_nb_top = 0;            // outer panel width (env GPEMU_NB_TOP); 0 = automatic: 512 for one matrix, 2048 for a lock-step batch
 constexpr int INFO_NONE = 0x7f7f7f7f;   // "no failed pivot": what hipMemsetAsync(.., 0x7f, ..) leaves in *info
 
@@ -133,6 +134,7 @@ static void read_environment()
 	gpemu::g_gemm_table = v >= 0 && v <= 64 ? v : 8;
 	g_lookahead = geti("GPEMU_LOOKAHEAD", 0) != 0;
 	g_leaf128 = geti("GPEMU_LEAF128", 0) != 0;
+	g_fill_gram = geti("GPEMU_FILL_GRAM", 1) != 0;
 	v = geti("GPEMU_NB_TOP", 0);
 	g_nb_top = v >= LEAF ? (v / LEAF) * LEAF : 0;
 }
@@ -213,7 +215,7 @@ static void free_graphs(gpemu_ctx *ctx)
 static void free_model(gpemu_ctx *ctx)
 {
 	free_graphs(ctx);
-	double **ptrs[] = {&ctx->dX, &ctx->dY, &ctx->dRrows, &ctx->dT, &ctx->dGramPart, &ctx->dLinvAug, &ctx->dBetaQ,
+	double **ptrs[] = {&ctx->dX, &ctx->dXg, &ctx->dY, &ctx->dRrows, &ctx->dT, &ctx->dGramPart, &ctx->dLinvAug, &ctx->dBetaQ,
 	                   &ctx->dKq, &ctx->dV, &ctx->dXq, &ctx->dMean, &ctx->dVar, &ctx->dS, &ctx->dGradPart, &ctx->dAlpha};
 	for (auto p : ptrs) { if (*p) hipFree(*p); *p = nullptr; }
 	ctx->T_rows = 0; ctx->pred_ready = false; ctx->cinv_ready = false; ctx->pred_batch = 0; ctx->stage_cap = 0;
@@ -362,6 +364,26 @@ extern "C" int gpemu_set_model(gpemu_ctx *ctx, int kind, int order, int N, int d
 	HIPCHK(ctx, hipMalloc(&ctx->dGramPart, (size_t)ctx->batch_cap * (ctx->Np / 64) * ctx->Rp * ctx->Rp * sizeof(double)));
 	HIPCHK(ctx, hipMemcpyAsync(ctx->dX, ctx->hX.data(), (size_t)N * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
 	HIPCHK(ctx, hipMemcpyAsync(ctx->dY, ctx->hY.data(), (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+	{
+		// the design centred per dimension (operands of the Gram-form fill) and the half ranges that bound its error
+		std::vector<double> lo(d, HUGE_VAL), hi(d, -HUGE_VAL), xg((size_t)N * d);
+		bool finite = true;
+		for (int i = 0; i < N; i++)
+			for (int k = 0; k < d; k++) {
+				const double v = X[(size_t)i * d + k];
+				if (!(fabs(v) <= 1e300)) finite = false;
+				if (v < lo[k]) lo[k] = v;
+				if (v > hi[k]) hi[k] = v;
+			}
+		ctx->xhalf.assign(d, HUGE_VAL);
+		if (finite) {
+			for (int k = 0; k < d; k++) ctx->xhalf[k] = 0.5 * (hi[k] - lo[k]);
+			for (int i = 0; i < N; i++)
+				for (int k = 0; k < d; k++) xg[(size_t)i * d + k] = X[(size_t)i * d + k] - 0.5 * (hi[k] + lo[k]);
+			HIPCHK(ctx, hipMalloc(&ctx->dXg, (size_t)N * d * sizeof(double)));
+			HIPCHK(ctx, hipMemcpy(ctx->dXg, xg.data(), (size_t)N * d * sizeof(double), hipMemcpyHostToDevice));
+		}
+	}
 	HIPCHK(ctx, launch_build_rrows(ctx->stream, ctx->dRrows, ctx->Np, ctx->Rp, ctx->dX, ctx->dY, N, d, order));
 	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 	int rc = ensure_T(ctx, (size_t)ctx->Np + ctx->Rp);
@@ -412,6 +434,20 @@ static int make_cov_params(gpemu_ctx *ctx, const double *thetas, int nthetas, Co
 		p->eps = 0.0000000000000001;
 		p->w[0] = 1.0 / exp(thetas[2]);
 		p->cand = 2.0 * ctx->d * (p->eps * p->w[0]) * (p->eps * p->w[0]) + 1e-300;
+	}
+	// Gram form of the training fill (kernels_cov.hip): only while the centred, scaled design stays small -- the
+	// cancellation error of |x'|^2 + |y'|^2 - 2 x'.y' is a few ulp of 2 * norm2
+	p->gram = 0; p->cand_g = 0.0;
+	if (g_fill_gram && ctx->dXg && (int)ctx->xhalf.size() == ctx->d) {
+		double norm2 = 0.0;
+		for (int k = 0; k < ctx->d; k++) {
+			const double t = ctx->xhalf[k] * p->w[ctx->kind == GPEMU_POWEREXP ? k : 0];
+			norm2 += t * t;
+		}
+		if (norm2 <= 16.0) {
+			p->gram = 1;
+			p->cand_g = p->cand + 64.0 * 2.220446049250313e-16 * (2.0 * norm2 + 1.0);
+		}
 	}
 	return GPEMU_OK;
 }
@@ -609,7 +645,7 @@ static int stage_matrices(gpemu_ctx *ctx, const CovParams *ps, int nb, int inv)
 		const double nlow = 0.5 * (double)Np * Np * nb;
 		ProfScope ps_(ctx, GPEMU_PROF_FILL, 0.0, 8.0 * nlow);
 		HIPCHK(ctx, launch_cov_stage_batch(ctx->stream, ctx->dT, Np, (long)ctx->T_stride, nb, ctx->dX, ctx->N, Np, ctx->d,
-		                                   ctx->dParams, FILL_LOWER | FILL_IDENT_PAD, ctx->dRrows, Rp));
+		                                   ctx->dParams, FILL_LOWER | FILL_IDENT_PAD, ctx->dRrows, Rp, ctx->dXg));
 	}
 	if (inv)
 		HIPCHK(ctx, launch_set_identity_rows(ctx->stream, ctx->dT + (size_t)(Np + Rp) * Np, Np, Np, nb, (long)ctx->T_stride));

@@ -32,6 +32,9 @@ struct CovParams {
 	double nug;
 	double eps;
 	double cand;
+	int gram;            // 1: the square training fill may use the MFMA Gram form of the squared distances (kernels_cov.hip)
+	int pad_;
+	double cand_g;       // Gram form: squared scaled distances at or below this are recomputed from differences
 	double w[GPEMU_MAX_PARAMS];
 };
 
@@ -82,6 +85,8 @@ struct gpemu_ctx {
 	int kind = 0, order = 0, N = 0, d = 0, nreg = 0, nrhs = 0;
 	int Np = 0, Rp = 0;
 	double *dX = nullptr;        // N x d
+	double *dXg = nullptr;       // N x d, centred per dimension (x - mid_k): operands of the Gram-form fill
+	std::vector<double> xhalf;   // d: half range of each design coordinate
 	double *dY = nullptr;        // N
 	double *dRrows = nullptr;    // Rp x Np : row 0 = y, rows 1..nreg = H columns, zero padded
 	std::vector<double> hX, hY;
@@ -167,7 +172,7 @@ hipError_t launch_build_rrows(hipStream_t s, double *R, int Np, int Rp, const do
                               int N, int d, int order);
 hipError_t launch_set_identity_rows(hipStream_t s, double *T, long ld, int n, int nbatch = 1, long bstride = 0);
 hipError_t launch_cov_stage_batch(hipStream_t s, double *T, long ld, long bstride, int nb, const double *X, int N, int Np, int d,
-                                  const CovParams *pp_dev, int mode, const double *Rrows, int Rp);
+                                  const CovParams *pp_dev, int mode, const double *Rrows, int Rp, const double *Xg = nullptr);
 hipError_t launch_transpose(hipStream_t s, double *dst, long ldd, const double *src, long lds, int n);
 hipError_t launch_predict_finish(hipStream_t s, const double *V, long ldv, int M, int Np, int nreg, int order, int d,
                                  const double *Xq, const double *betaQ, double kappa, double *mean, double *var,

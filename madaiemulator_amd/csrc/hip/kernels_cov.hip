@@ -18,21 +18,27 @@ constexpr int DCH = 8;            // dimensions handled per register chunk
 // coordinates are pre-scaled while staging (2 ops per dimension), exp and sqrt are short table / Newton
 // forms, and the exact "same point" test of the nugget rule runs only for pairs whose distance makes it possible.
 
-// exp(x) for x <= 0: x = (32 m + j) ln2/32 + r, |r| <= ln2/64; exp = 2^m * 2^(j/32) * P6(r).  ~1 ulp.
-__device__ __forceinline__ double fast_exp_neg(double x, const double *tab /* LDS: 2^(j/32), j < 32 */)
+// exp(x) for x <= 0: x = (64 m + j) ln2/64 + r, |r| <= ln2/128; exp = 2^m * 2^(j/64) * P5(r) (truncation 4e-17), ~1 ulp.
+// 11 fp64 VALU operations (16 cycles each on gfx950): the rounding to an integer is the 1.5 * 2^52 addition (the integer
+// sits in the low mantissa word: no rint, no convert), the scaling by 2^m an integer add on the exponent field (no
+// ldexp).  Arguments below -700 are treated as -700 (1e-304: the result stays a normal number for the exponent add).
+constexpr int EXP_TAB = 64;
+__device__ __forceinline__ double fast_exp_neg(double x, const double *tab /* LDS: 2^(j/64), j < 64 */)
 {
-	x = fmax(x, -800.0);
-	const double kf = rint(x * 46.166241308446828384);              // 32 / ln 2
-	double r = fma(kf, -2.16608493865351192653e-02, x);             // ln2_hi / 32 (exact product with kf)
-	r = fma(kf, -5.96317165397058693751e-12, r);                    // ln2_lo / 32
-	const int ki = (int)kf;
-	double p = fma(r, 1.0 / 720.0, 1.0 / 120.0);
-	p = fma(p, r, 1.0 / 24.0);
+	x = fmax(x, -700.0);
+	const double magic = 6755399441055744.0;                              // 1.5 * 2^52
+	const double t = fma(x, 92.332482616893656768, magic);                // 64 / ln 2
+	const int ki = __double2loint(t);
+	const double kf = t - magic;
+	double r = fma(kf, -1.08304246932675596327e-02, x);                   // ln2_hi / 64 (32 significant bits: exact product)
+	r = fma(kf, -2.98158582698529346878e-12, r);                          // ln2_lo / 64
+	double p = fma(r, 1.0 / 120.0, 1.0 / 24.0);
 	p = fma(p, r, 1.0 / 6.0);
 	p = fma(p, r, 0.5);
 	p = fma(p, r, 1.0);
 	p = fma(p, r, 1.0);
-	return ldexp(tab[ki & 31] * p, ki >> 5);
+	const double v = tab[ki & (EXP_TAB - 1)] * p;
+	return __hiloint2double(__double2hiint(v) + ((ki >> 6) << 20), __double2loint(v));
 }
 
 // sqrt(a), a >= 0: hardware rsqrt estimate + two Heron corrections
@@ -66,7 +72,7 @@ __device__ __forceinline__ void cov_fill_tile(double *out, long ld, const double
                                               const CovParams &p, int mode, int tr, int tc)
 {
 	__shared__ double xr_s[FT * (GPEMU_MAX_PARAMS + 1)];
-	__shared__ double tab[32];
+	__shared__ double tab[EXP_TAB];
 	const int tid = threadIdx.x;
 	const int sd = d + 1;
 	for (int e = tid; e < FT * d; e += 256) {
@@ -74,7 +80,7 @@ __device__ __forceinline__ void cov_fill_tile(double *out, long ld, const double
 		int gr = tr * FT + r;
 		xr_s[r * sd + k] = (gr < nr) ? Xr[(long)gr * d + k] * p.w[(p.kind == GPEMU_POWEREXP) ? k : 0] : 0.0;
 	}
-	if (tid < 32) tab[tid] = exp2((double)tid * (1.0 / 32.0));
+	if (tid < EXP_TAB) tab[tid] = exp2((double)tid * (1.0 / EXP_TAB));
 	__syncthreads();
 
 	const int col = tc * FT + (tid & 63);
@@ -139,6 +145,119 @@ __device__ __forceinline__ void cov_fill_tile(double *out, long ld, const double
 	}
 }
 
+// ---------------------------------------------------------------------------
+// Gram form of the same tile for the square training matrix (Xr = Xc = the design): the squared scaled distances of
+// a 64 x 64 tile come from the fp64 MFMA as  |x'|^2 + |y'|^2 - 2 x'.y'  -- the 2d subtract/FMA wave-instructions per
+// element of the difference form (16 of its ~45 at d = 8, each 16 cycles on the fp64 VALU) become d/4 + 1 matrix
+// instructions per 256 elements on the other pipe.  x' = (x - mid) w: Xg holds the design centred per dimension
+// (host, set_model), so |x'| is half the scaled range.  The host enables this form (p.gram) only while
+// sum_k (w_k halfrange_k)^2 <= 16: the cancellation error in the squared distance, a few ulp of |x'|^2 + |y'|^2, then
+// stays below 2e-14 absolute -- 2e-14 RELATIVE in a pow-exp element, less in a Matern one -- against the 1e-13 parity
+// bar; beyond that (extreme length scales) the difference form above is used.  Pairs whose squared distance comes out
+// below p.cand_g (the nugget rule's candidates plus that error) recompute it from coordinate differences and run the
+// exact "same point" test on the raw coordinates (emulator.c:136-150 / :368-384 / :462-478).
+// MFMA maps (16x16x4 f64): A lane (q, g) = A[row q][k g], B lane = B[k g][col q], D reg r = D[row g + 4r][col q].
+// Wave w owns tile rows 16w .. 16w+15 and all four 16-column blocks.
+// ---------------------------------------------------------------------------
+typedef double d4g_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double cov_from_dist2(const CovParams &p, double a, const double *tab)
+{
+	if (p.kind == GPEMU_POWEREXP) return fast_exp_neg(-a, tab) * p.amp;                   // emulator.c:133,141
+	const double sdist = fast_sqrt(a);                                                    // distance / rho
+	if (p.kind == GPEMU_MATERN32) {
+		const double root3 = 1.732050808;                                                 // emulator.c:359 (literal)
+		return p.amp * (1 + root3 * sdist) * fast_exp_neg(-root3 * sdist, tab);
+	}
+	const double root5 = 2.236067978;                                                     // emulator.c:452 (literal)
+	return p.amp * (1 + root5 * sdist + (5.0 / 3.0) * sdist * sdist) * fast_exp_neg(-root5 * sdist, tab);
+}
+
+__device__ __forceinline__ void cov_fill_tile_gram(double *out, long ld, const double *X, const double *Xg, int n, int d,
+                                                   const CovParams &p, int mode, int tr, int tc)
+{
+	__shared__ double tab[EXP_TAB];
+	__shared__ double wsc[GPEMU_MAX_PARAMS];
+	const int tid = threadIdx.x;
+	if (tid < EXP_TAB) tab[tid] = exp2((double)tid * (1.0 / EXP_TAB));
+	if (tid < GPEMU_MAX_PARAMS) wsc[tid] = (tid < d) ? p.w[(p.kind == GPEMU_POWEREXP) ? tid : 0] : 0.0;
+	__syncthreads();
+	const int lane = tid & 63, wave = tid >> 6;
+	const int q = lane & 15, g = lane >> 4;
+	const int arow = tr * FT + 16 * wave + q;                 // A operand row of this lane
+	const bool av = arow < n;
+	const double *ap = Xg + (long)(av ? arow : 0) * d;
+	const double *bp[4];
+	bool bv[4];
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		const int bc = tc * FT + 16 * j + q;
+		bv[j] = bc < n;
+		bp[j] = Xg + (long)(bv[j] ? bc : 0) * d;
+	}
+	d4g_t acc[4];
+#pragma unroll
+	for (int j = 0; j < 4; j++) acc[j] = (d4g_t){0.0, 0.0, 0.0, 0.0};
+	double na = 0.0, nb[4] = {0.0, 0.0, 0.0, 0.0};
+	for (int k0 = 0; k0 < d; k0 += 4) {
+		const int k = k0 + g;
+		const bool kv = k < d;
+		const double wk = wsc[kv ? k : 0];
+		const double xa = (kv && av) ? ap[k] * wk : 0.0;
+		na = fma(xa, xa, na);
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			const double xb = (kv && bv[j]) ? bp[j][k] * wk : 0.0;
+			nb[j] = fma(xb, xb, nb[j]);
+			acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, -2.0 * xb, acc[j], 0, 0, 0);
+		}
+	}
+	// |x'|^2 of the lane's A row / B column: sum the four k-groups (lanes q, q+16, q+32, q+48)
+	na += __shfl_xor(na, 16); na += __shfl_xor(na, 32);
+#pragma unroll
+	for (int j = 0; j < 4; j++) { nb[j] += __shfl_xor(nb[j], 16); nb[j] += __shfl_xor(nb[j], 32); }
+	// one more matrix step adds |x'_row|^2 + |y'_col|^2: k slot 0 = (|x'|^2, 1), k slot 1 = (1, |y'|^2)
+	{
+		const double ea = (g == 0) ? na : (g == 1 ? 1.0 : 0.0);
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			const double eb = (g == 0) ? 1.0 : (g == 1 ? nb[j] : 0.0);
+			acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ea, eb, acc[j], 0, 0, 0);
+		}
+	}
+#pragma unroll
+	for (int r = 0; r < 4; r++) {
+		const int row = tr * FT + 16 * wave + g + 4 * r;
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			const int col = tc * FT + 16 * j + q;
+			double v;
+			if (row < n && col < n) {
+				double a = acc[j][r];
+				bool same = false;
+				if (a <= p.cand_g) {
+					// rare: (nearly) coinciding points -> distance from differences, exact nugget test on the raw coordinates
+					int cnt = 0;
+					a = 0.0;
+					for (int k = 0; k < d; k++) {
+						const double D = X[(long)row * d + k] - X[(long)col * d + k];
+						const double t = D * wsc[k];
+						a = fma(t, t, a);
+						cnt += (fabs(D) < p.eps) ? 1 : 0;
+					}
+					same = cnt == d;
+				}
+				v = cov_from_dist2(p, a, tab);
+				if (same) v += p.nug;
+				if ((mode & FILL_CLAMP) && v < 1E-10) v = 0.0;                            // emulator.c:588-590
+			} else {
+				v = ((mode & FILL_IDENT_PAD) && row == col) ? 1.0 : 0.0;
+			}
+			out[(long)row * ld + col] = v;
+		}
+	}
+}
+
 __global__ __launch_bounds__(256) void cov_fill_kernel(double *out, long ld, const double *Xr, int nr,
                                                        const double *Xc, int nc, int d, CovParams p, int mode)
 {
@@ -154,7 +273,8 @@ __global__ __launch_bounds__(256) void cov_fill_kernel(double *out, long ld, con
 // (workgroups ntiles ..: one FT x FT block each).  Per-matrix launches and copies cost ~12 us each on the host and the
 // stream: 1 ms per batch of 64, which is all a batch of small models (N < 1000) takes.
 __global__ __launch_bounds__(256) void cov_stage_batch_kernel(double *T, long ld, long bstride, const double *X, int N, int Np,
-                                                              int d, const CovParams *pp, int mode, const double *Rrows, int Rp)
+                                                              int d, const CovParams *pp, int mode, const double *Rrows, int Rp,
+                                                              const double *Xg)
 {
 	double *out = T + (long)blockIdx.y * bstride;
 	const long nt = Np / FT, ntiles = nt * (nt + 1) / 2;
@@ -167,7 +287,8 @@ __global__ __launch_bounds__(256) void cov_stage_batch_kernel(double *T, long ld
 		__syncthreads();
 		int tr, tc;
 		lower_tile(blockIdx.x, tr, tc);
-		cov_fill_tile(out, ld, X, N, X, N, d, ps, mode, tr, tc);
+		if (ps.gram && Xg) cov_fill_tile_gram(out, ld, X, Xg, N, d, ps, mode, tr, tc);
+		else cov_fill_tile(out, ld, X, N, X, N, d, ps, mode, tr, tc);
 		return;
 	}
 	const long rb = blockIdx.x - ntiles;              // block (rb / nt, rb % nt) of the Rp x Np rows
@@ -180,13 +301,13 @@ __global__ __launch_bounds__(256) void cov_stage_batch_kernel(double *T, long ld
 }
 
 hipError_t launch_cov_stage_batch(hipStream_t s, double *T, long ld, long bstride, int nb, const double *X, int N, int Np, int d,
-                                  const CovParams *pp_dev, int mode, const double *Rrows, int Rp)
+                                  const CovParams *pp_dev, int mode, const double *Rrows, int Rp, const double *Xg)
 {
 	if (Np % FT || FT != 64) return hipErrorInvalidValue;
 	const long nt = Np / FT;
 	const long blocks = nt * (nt + 1) / 2 + ((Rp + FT - 1) / FT) * nt;
 	hipLaunchKernelGGL(cov_stage_batch_kernel, dim3((unsigned)blocks, nb), dim3(256), 0, s, T, ld, bstride, X, N, Np, d, pp_dev,
-	                   mode, Rrows, Rp);
+	                   mode, Rrows, Rp, Xg);
 	return hipGetLastError();
 }
 
@@ -522,7 +643,7 @@ __global__ __launch_bounds__(256) void grad_exact_kernel(const double *S, long l
 	__shared__ double xc_s[64 * (GPEMU_MAX_PARAMS + 1)];
 	__shared__ double ar_s[64], ac_s[64];
 	__shared__ double red[256];
-	__shared__ double tab[32];
+	__shared__ double tab[EXP_TAB];
 	const int tid = threadIdx.x;
 	const int sd = d + 1;
 	for (int e = tid; e < (int)(sizeof(CovParams) / sizeof(double)); e += 256)
@@ -538,7 +659,7 @@ __global__ __launch_bounds__(256) void grad_exact_kernel(const double *S, long l
 		ar_s[tid] = (gr < N) ? alpha[gr] : 0.0;
 		ac_s[tid] = (gc < N) ? alpha[gc] : 0.0;
 	}
-	if (tid < 32) tab[tid] = exp2((double)tid * (1.0 / 32.0));
+	if (tid < EXP_TAB) tab[tid] = exp2((double)tid * (1.0 / EXP_TAB));
 	__syncthreads();
 
 	const int c = tid & 63, rsub = tid >> 6;

@@ -686,28 +686,13 @@ def _oracle_emulate_worker(args):
     return m, v, st, e.beta, e.logdet
 
 
-def test_n4096_full_oracle_evaluation_and_predictions(gpu_ctx):
-    """BASELINE.json configs[1] (N=4096, d=8, pow-exp): ONE full oracle evalFnMulti (maxmultimin.c:288-394 restated:
-    fill, unblocked Cholesky, explicit inverse, estimateBeta twice) and 64 oracle emulate_point calls
-    (emulator_struct.c:124-143, emulator.c:672-785) against gpemu_loglik / gpemu_predict_batch at the parity bar.
-    Two oracle passes of ~N^3 each: they run side by side on two host cores (about four minutes)."""
-    import multiprocessing as mp
-    kind, order, N, d, seed = 1, 0, 4096, 8, 20261003 + 1
-    th = synth.default_thetas(kind, d).copy()
-    th[0] = 0.0                                               # evalFnMulti's theta[0] (maxmultimin.c:311)
-    with mp.get_context("spawn").Pool(2) as pool:
-        ra = pool.map_async(_oracle_eval_worker, [(kind, order, N, d, seed, th.tolist())])
-        rb = pool.map_async(_oracle_emulate_worker, [(kind, order, N, d, seed, th.tolist(), 321)])
-        # the device side meanwhile
-        X, y = synth.design(N, d, seed)
-        gpu_ctx.set_model(kind, order, X, y)
-        got = gpu_ctx.loglik(th)
-        gotb = gpu_ctx.loglik_batch(np.array([th, synth.perturbed_thetas(kind, d, 9, 1), th]))
-        gpu_ctx.predict_setup(th)
-        Xq = synth.queries(64, d, 321)
-        m, v = gpu_ctx.predict(Xq)
-        o = ra.get(timeout=850)[0]
-        mo, vo, st, obeta, ologdet = rb.get(timeout=850)[0]
+def _check_full_evaluation(gpu_ctx, kind, order, N, d, seed, th, qseed, o, mo, vo, obeta, ologdet):
+    X, y = synth.design(N, d, seed)
+    gpu_ctx.set_model(kind, order, X, y)
+    got = gpu_ctx.loglik(th)
+    gotb = gpu_ctx.loglik_batch(np.array([th, synth.perturbed_thetas(kind, d, 9, 1), th]))
+    gpu_ctx.predict_setup(th)
+    m, v = gpu_ctx.predict(synth.queries(64, d, qseed))
     assert got["status"] == 0 and o["info"] == 0
     assert got["value"] == pytest.approx(o["value"], rel=RTOL)
     assert got["sigma2"] == pytest.approx(o["sigma2"], rel=RTOL)
@@ -719,6 +704,37 @@ def test_n4096_full_oracle_evaluation_and_predictions(gpu_ctx):
     kappa = np.exp(th[0]) + np.exp(th[1])
     assert np.max(np.abs(m - mo)) < RTOL * max(1.0, np.abs(mo).max())
     assert np.max(np.abs(v - vo)) < RTOL * kappa
+
+
+def test_n3072_full_oracle_evaluation_and_predictions_live(gpu_ctx):
+    """A full oracle evalFnMulti (maxmultimin.c:288-394 restated: fill, unblocked Cholesky, explicit inverse,
+    estimateBeta twice) and 64 oracle emulate_point calls (emulator_struct.c:124-143, emulator.c:672-785) run LIVE next
+    to the device at N = 3072, d = 8, pow-exp -- the largest size the oracle's naive N^3 loops finish in about a
+    minute and a half (two passes side by side on two host cores); N = 4096 itself is the fixture test below."""
+    import multiprocessing as mp
+    kind, order, N, d, seed = 1, 0, 3072, 8, 20261003 + 1
+    th = synth.default_thetas(kind, d).copy()
+    th[0] = 0.0                                               # evalFnMulti's theta[0] (maxmultimin.c:311)
+    with mp.get_context("spawn").Pool(2) as pool:
+        ra = pool.map_async(_oracle_eval_worker, [(kind, order, N, d, seed, th.tolist())])
+        rb = pool.map_async(_oracle_emulate_worker, [(kind, order, N, d, seed, th.tolist(), 321)])
+        o = ra.get(timeout=600)[0]
+        mo, vo, st, obeta, ologdet = rb.get(timeout=600)[0]
+    _check_full_evaluation(gpu_ctx, kind, order, N, d, seed, th, 321, o, mo, vo, obeta, ologdet)
+
+
+def test_n4096_oracle_fixture(gpu_ctx):
+    """BASELINE.json configs[1] (N=4096, d=8, pow-exp): the device against ONE full oracle evaluation + 64 oracle
+    predictions computed offline by tests/golden/make_golden_n4096.py (tens of minutes of host time at this size: the
+    32 KB row stride defeats the caches of the oracle's naive loops) and committed as ~150 numbers; the design is
+    regenerated here from the same seeds."""
+    import os
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_n4096.npz"))
+    kind, order, N, d, seed, qseed = (int(v) for v in f["meta"])
+    o = dict(value=float(f["value"]), sigma2=float(f["sigma2"]), beta=f["beta"], logdet=float(f["logdet"]),
+             quad=float(f["quad"]), info=int(f["info"]))
+    _check_full_evaluation(gpu_ctx, kind, order, N, d, seed, f["thetas"], qseed, o, f["mean"], f["var"], f["emu_beta"],
+                           float(f["emu_logdet"]))
 
 
 # ------------------------------------------------------------------ ragged and extreme shapes

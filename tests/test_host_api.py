@@ -380,6 +380,27 @@ def test_training_with_the_corrected_gradient_converges(driver, tmp_path, cov):
 
 
 @pytest.mark.gpu
+def test_training_at_n4096_where_the_reference_argmax_floor_would_fail(driver, tmp_path):
+    """The reference starts its arg-max over restarts at -2000 (maxmultimin.c:38,60,110): at N = 4096 every
+    log-likelihood of a noisy model is below that and the reference ends with 'maximisation didn't work at all' and
+    thetas = 0.  Here the arg-max starts at -infinity: the search returns its best run, which -- with
+    the exact gradient -- has converged, and the value at the returned thetas is what evalFnMulti says it is."""
+    N, d = 4096, 8
+    X, y = synth.design(N, d, 777)
+    y = y + 0.8 * synth.normal(3, N)
+    f = tmp_path / "train4096.dat"
+    _write_model_file(f, X, y)
+    env = dict(os.environ, GPEMU_SEED="5", GPEMU_JOBS="4", GPEMU_RESTARTS="1", GPEMU_EXACT_GRAD="1", GPEMU_DEVICES="0")
+    res = parse(run([driver, "train", str(f), "1", "0"], env=env))
+    th = np.array(res["thetas"][0])
+    val = res["neglogl"][0][0]
+    runs, conv, noprog, fallbacks, best_gnorm = res["search"][0]
+    assert runs == 4 and np.all(np.isfinite(th)) and np.any(th != 0.0)
+    assert val > 2000.0                      # log-likelihood below the reference's floor of -2000
+    assert conv >= 1 and fallbacks == 0 and 0.0 <= best_gnorm < 0.1
+
+
+@pytest.mark.gpu
 def test_call_eval_lhood_list_without_r():
     """libRbind's batched likelihood entry (rbind.c:626-724): flat .C() signature, column-major arrays"""
     import ctypes as C
