@@ -4,9 +4,11 @@
 N = 4096, d = 8, pow-exp, regression order 0, the seeded design of madaiemulator_amd.synth (seed 20261003 + 1):
   * orc_evalFnMulti  (maxmultimin.c:288-394 restated: fill, unblocked Cholesky, explicit inverse, estimateBeta twice)
   * orc_emulator_setup + 64 x orc_emulate_points (emulator_struct.c:13-37,124-143; emulator.c:672-785)
-The two passes are ~N^3 each through the oracle's naive row-major loops; at N = 4096 the 32 KB row stride makes them
-cache-hostile and they take tens of minutes of one core each -- too long for a test, so the run is done here, once,
-and its ~150 numbers are committed as a fixture (the inputs are regenerated from the seeds wherever the test runs).
+The two passes are ~N^3 each through the oracle's naive row-major loops: 250 s and 220 s of one core each when they
+have the machine to themselves (measured here), several times that next to other work (32 KB row stride: they live
+on the cache) -- too close to the GPU box's "no output for 7 minutes = hung" rule for a test, so the run is done here,
+once, and its ~150 numbers are committed as a fixture (the inputs are regenerated from the seeds wherever the test
+runs).
 tests/test_gpu_parity.py::test_n4096_oracle_fixture compares the HIP path with them; the same test runs the oracle
 live at N = 3072 (two host cores, ~1.5 minutes).
 

@@ -725,9 +725,9 @@ def test_n3072_full_oracle_evaluation_and_predictions_live(gpu_ctx):
 
 def test_n4096_oracle_fixture(gpu_ctx):
     """BASELINE.json configs[1] (N=4096, d=8, pow-exp): the device against ONE full oracle evaluation + 64 oracle
-    predictions computed offline by tests/golden/make_golden_n4096.py (tens of minutes of host time at this size: the
-    32 KB row stride defeats the caches of the oracle's naive loops) and committed as ~150 numbers; the design is
-    regenerated here from the same seeds."""
+    predictions computed offline by tests/golden/make_golden_n4096.py (two passes of 4 minutes of one core each when
+    alone on the machine, much longer under load) and committed as ~150 numbers; the design is regenerated here from
+    the same seeds."""
     import os
     f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_n4096.npz"))
     kind, order, N, d, seed, qseed = (int(v) for v in f["meta"])
