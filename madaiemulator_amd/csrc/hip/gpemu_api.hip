@@ -1719,6 +1719,7 @@ extern "C" int gpemu_test_gemm_bench(gpemu_ctx *ctx, int m, int n, int k, int ld
 	memset(&g, 0, sizeof g);
 	g.C = dc; g.A = da; g.B = da; g.ldc = ld; g.lda = ld; g.ldb = ld; g.m = m; g.n = n; g.k0 = 0; g.k1 = k;
 	g.alpha = -1.0; g.beta = beta; g.tri = tri;
+	if (getenv("GPEMU_BENCH_LD0")) { g.lda = 0; g.ldb = 0; }   // every operand row aliases row 0: staging loads always hit L1/L2
 	if (ctx->dTrace) {
 		ctx->trace_next = 0; ctx->trace_tag.clear();
 		HIPCHK(ctx, hipMemsetAsync(ctx->dTrace, 0, (size_t)ctx->trace_cap * 64, ctx->stream));

@@ -69,7 +69,11 @@ __device__ __forceinline__ void trace_end(unsigned long long *t, TraceT0 t0)
 // written to LDS at its end.  2 (two register stages, for the 64x64 tiles that have the registers to spare): requested
 // two steps ahead -- the short-K panel updates are chains of dependent HBM round trips, one per k-step, and this halves
 // the chain.
-template <int BM, int BN, int MINW, int WGM = 2, int WGN = 2, int PF = 1>
+// L2PF = 1: every thread also touches one 64-byte sector of the chunk AFTER the next one (a 4-byte load whose value is
+// never used): the real 16-byte loads of that chunk, issued a k-step later, then find their lines in the XCD's L2
+// instead of paying the fabric / HBM round trip inside their own k-step -- a prefetch distance of two k-steps for one
+// VGPR, where a second register stage (PF = 2) would cost 16 and drop the 128x128 tiles to one workgroup per CU.
+template <int BM, int BN, int MINW, int WGM = 2, int WGN = 2, int PF = 1, int L2PF = 0>
 __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs g)
 {
 	constexpr int NT = 64 * WGM * WGN;              // threads: WGM x WGN waves
@@ -169,6 +173,27 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 		bg[it] = g.B + (long)br * g.ldb + 2 * seg;
 		lofs_b[it] = row * LDS_S + 2 * seg;
 	}
+
+	// L2 prefetch map: thread -> (row of the A|B tile rows, 64-byte half of its 128-byte k-chunk)
+	// (a buffer descriptor on the wave-uniform first row of the tile's operand rows + a 32-bit byte offset per lane;
+	// the k advance is the scalar offset of the load: no vector address arithmetic, one VGPR besides the target)
+	__amdgpu_buffer_rsrc_t pf_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(g.A), 0, 0, 0x00020000);
+	unsigned pf_off = 0;
+	if (L2PF) {
+		const int prow = (tid >> 1) % (BM + BN), half = tid & 1;
+		const bool isA = __builtin_amdgcn_readfirstlane(prow < BM ? 1 : 0) != 0;      // whole waves take A rows or B rows
+		static_assert(!L2PF || (BM % 32 == 0 && BN % 32 == 0), "a wave's 32 prefetch rows lie in one operand");
+		const double *base = isA ? g.A : g.B;
+		const long ldx = isA ? g.lda : g.ldb;
+		const int lim = (isA ? g.m : g.n) - 1;
+		int r = isA ? tm * BM + prow : tn * BN + (prow - BM);
+		if (r > lim) r = lim;
+		int r0 = isA ? tm * BM : tn * BN;
+		if (r0 > lim) r0 = lim;
+		pf_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(base + (long)r0 * ldx), 0, -1, 0x00020000);
+		pf_off = (unsigned)((long)(r - r0) * ldx * 8 + 64 * half);
+	}
+	int pfv = 0;
 
 	// The accumulators start from the C tile itself (scaled by beta/alpha, alpha = +-1 when beta is set: exact), so
 	// the read half of the read-modify-write overlaps the operand prologue and the epilogue is stores only.  (Read
@@ -275,13 +300,23 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 		if (g.trace && tr0.wall) atomicAdd(g.trace + 5, (unsigned long long)clock64() - tr0.clk);   // prologue
 
 		int cur = 0;
-		for (int k = kb; k < ke; k += GEMM_BK) {
+		int step = 0;
+		for (int k = kb; k < ke; k += GEMM_BK, step++) {
 			const bool more = (k + GEMM_BK) < ke;
 			if (more) {
 #pragma unroll
 				for (int it = 0; it < AIT; it++) ra[it] = *reinterpret_cast<const d2_t *>(ag[it] + k + GEMM_BK);
 #pragma unroll
 				for (int it = 0; it < BIT; it++) rb[it] = *reinterpret_cast<const d2_t *>(bg[it] + k + GEMM_BK);
+			}
+			if (L2PF) {
+				// touch the chunk after the next one.  Issued AFTER the real loads (they are not held up behind it) and
+				// unconditionally (every thread, the k offset clamped at the tail): only then can the compiler count it
+				// and wait for the real loads with vmcnt(1) instead of vmcnt(0)
+				static_assert(!L2PF || NT == 2 * (BM + BN), "one 64-byte sector per thread");
+				int kp = k + 2 * GEMM_BK;
+				if (kp > ke - GEMM_BK) kp = ke - GEMM_BK;
+				pfv = __builtin_amdgcn_raw_buffer_load_b32(pf_rsrc, pf_off, kp * 8, 0);
 			}
 			const double *as = As[cur];
 			const double *bs = Bs[cur];
@@ -309,6 +344,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 			__syncthreads();
 			cur ^= 1;
 		}
+		if (L2PF) asm volatile("" :: "v"(pfv));                  // the touched values are never used
 	}
 #undef GEMM_LOAD
 #undef GEMM_STORE
@@ -530,9 +566,9 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs &a_in)
 	const int nbatch = a.nbatch > 1 ? a.nbatch : 1;
 	const int cfg = choose_gemm_cfg(a);
 	// tile shapes: 0 128x128 (4 waves), 1 128x64, 2 64x64, 3 128x128 (8 waves), 4 256x128 (8 waves, one workgroup
-	// per CU), 5 256x128 (16 waves), 6 128x256 (8 waves)
-	static const int k_bm[] = {128, 128, 64, 128, 256, 256, 128}, k_bn[] = {128, 64, 64, 128, 128, 128, 256};
-	if (cfg < 0 || cfg > 6) return hipErrorInvalidValue;
+	// per CU), 5 256x128 (16 waves), 6 128x256 (8 waves), 7 = 3 with the L2 prefetch of the chunk after the next
+	static const int k_bm[] = {128, 128, 64, 128, 256, 256, 128, 128}, k_bn[] = {128, 64, 64, 128, 128, 128, 256, 128};
+	if (cfg < 0 || cfg > 7) return hipErrorInvalidValue;
 	const int bm = k_bm[cfg], bn = k_bn[cfg];
 	const int tiles_m = (a.m + bm - 1) / bm, tiles_n = (a.n + bn - 1) / bn;
 	// lower-triangular updates enumerate only their non-empty tiles: square tiles by a closed form, any shape by table
@@ -556,6 +592,7 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs &a_in)
 	case 4: hipLaunchKernelGGL((gemm_nt_kernel<256, 128, 2, 4, 2>), dim3(T, nbatch), dim3(512), 0, s, a); break;
 	case 5: hipLaunchKernelGGL((gemm_nt_kernel<256, 128, 4, 8, 2>), dim3(T, nbatch), dim3(1024), 0, s, a); break;
 	case 6: hipLaunchKernelGGL((gemm_nt_kernel<128, 256, 2, 2, 4>), dim3(T, nbatch), dim3(512), 0, s, a); break;
+	case 7: hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 4, 4, 2, 1, 1>), dim3(T, nbatch), dim3(512), 0, s, a); break;
 	default: hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2, 2>), dim3(T, nbatch), dim3(256), 0, s, a); break;
 	}
 	return hipGetLastError();
