@@ -26,6 +26,7 @@ using namespace gpemu;
 
 static int g_leaf128 = 0;                // 128-column fused leaves (env GPEMU_LEAF128=1); measured 3 % slower than 64
 static int g_lookahead = 0;              // two-stream schedule of the outer panels (env GPEMU_LOOKAHEAD=1); see DESIGN.md
+static int g_factor_ahead = 1;           // the update's tile (0,0) factors the next diagonal block (env GPEMU_FACTOR_AHEAD=0: off)
 static int g_fill_gram = 1;              // MFMA Gram form of the training fill (env GPEMU_FILL_GRAM=0: difference form always)
 static int g_nb_top = 0;            // outer panel width (env GPEMU_NB_TOP); 0 = automatic: 512 for one matrix, 2048 for a lock-step batch
 constexpr int INFO_NONE = 0x7f7f7f7f;   // "no failed pivot": what hipMemsetAsync(.., 0x7f, ..) leaves in *info
@@ -135,6 +136,7 @@ static void read_environment()
 	g_lookahead = geti("GPEMU_LOOKAHEAD", 0) != 0;
 	g_leaf128 = geti("GPEMU_LEAF128", 0) != 0;
 	g_fill_gram = geti("GPEMU_FILL_GRAM", 1) != 0;
+	g_factor_ahead = geti("GPEMU_FACTOR_AHEAD", 1) != 0;
 	v = geti("GPEMU_NB_TOP", 0);
 	g_nb_top = v >= LEAF ? (v / LEAF) * LEAF : 0;
 }
@@ -459,7 +461,10 @@ static int make_cov_params(gpemu_ctx *ctx, const double *thetas, int nthetas, Co
 //   T rows [Np+Rp,Np+Rp+Np)  : identity -> U = L^-T (only with inv)
 // potrf_rec(c0,n) factors the column panel [c0,c0+n) for every row below it.
 // ---------------------------------------------------------------------------
-static hipError_t trailing_update(gpemu_ctx *ctx, int c0, int k, int col_off, int ncols, int inv, hipStream_t stream = nullptr)
+// *fa_done (optional): set when the update ran with the factor-ahead tile, i.e. the 64x64 diagonal block at c0+k is
+// already factored when the update has finished and the next leaf must not factor it again
+static hipError_t trailing_update(gpemu_ctx *ctx, int c0, int k, int col_off, int ncols, int inv, hipStream_t stream = nullptr,
+                                  bool *fa_done = nullptr)
 {
 	// C[rows >= r0, cols r0 .. r0+ncols) -= P P^T with P = the factored panel columns [c0, c0+k) and
 	// r0 = c0 + k + col_off (rows above r0 belong to the upper triangle of those columns)
@@ -478,6 +483,14 @@ static hipError_t trailing_update(gpemu_ctx *ctx, int c0, int k, int col_off, in
 	g.alpha = -1.0; g.beta = 1;
 	g.tri = 1; g.diag_off = 0;
 	g.nbatch = ctx->nb; g.bsC = g.bsA = g.bsB = (long)ctx->T_stride;
+	if (fa_done) {
+		*fa_done = false;
+		g.fa = (g_factor_ahead && !g_leaf128 && col_off == 0 && !stream) ? 1 : 0;
+		g.fa_c0 = r0;
+		g.fa_info = ctx->dInfo;
+		if (g.fa && gemm_factor_ahead_ok(g)) *fa_done = true;
+		else g.fa = 0;
+	}
 	return gemm(ctx, g, stream);
 }
 
@@ -491,7 +504,8 @@ static hipEvent_t next_event(gpemu_ctx *ctx)
 	return ctx->ev_pool[ctx->ev_next++];
 }
 
-static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv)
+// diag_done: the 64x64 diagonal block at (c0,c0) is already factored (by the factor-ahead tile of the update before)
+static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv, bool diag_done = false)
 {
 	const long ld = ctx->Np;
 	const int base_end = ctx->Np + ctx->Rp;
@@ -501,7 +515,7 @@ static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv)
 		unsigned long long *trf = trace_slot(ctx, "leaf_factor c0=%d", c0);
 		unsigned long long *trs = trace_slot(ctx, "leaf_solve c0=%d m=%d", c0, row_end - (c0 + LEAF));
 		return launch_leaf(ctx->stream, ctx->dT, ld, c0, row_end - (c0 + LEAF), ctx->dInfo, trf, trs, ctx->nb,
-		                   (long)ctx->T_stride);
+		                   (long)ctx->T_stride, diag_done);
 	}
 	if (n == 2 * LEAF && g_leaf128) {
 		const int row_end = base_end + (inv ? c0 + 2 * LEAF : 0);
@@ -523,14 +537,16 @@ static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv)
 		const bool profiling = ctx->prof.cls != GPEMU_PROF_NONE && ctx->prof.cls != GPEMU_PROF_POTRF;
 		const bool ahead = g_lookahead && ctx->stream2 && !profiling && c0 == 0 && n == ctx->Np;
 		hipEvent_t ev_bulk_prev = nullptr;
+		bool next_done = diag_done;
 		for (int c = c0; c < c0 + n; c += nb_top) {
 			const int nb = std::min(nb_top, c0 + n - c);
-			hipError_t e = potrf_rec(ctx, c, nb, inv);
+			hipError_t e = potrf_rec(ctx, c, nb, inv, next_done);
+			next_done = false;
 			if (e != hipSuccess) return e;
 			const int rest = c0 + n - (c + nb);
 			if (rest <= 0) continue;
 			if (!ahead) {
-				e = trailing_update(ctx, c, nb, 0, rest, inv);
+				e = trailing_update(ctx, c, nb, 0, rest, inv, nullptr, &next_done);
 				if (e != hipSuccess) return e;
 				continue;
 			}
@@ -566,11 +582,12 @@ static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv)
 		return hipSuccess;
 	}
 	const int n1 = ((n / LEAF + 1) / 2) * LEAF;
-	hipError_t e = potrf_rec(ctx, c0, n1, inv);
+	hipError_t e = potrf_rec(ctx, c0, n1, inv, diag_done);
 	if (e != hipSuccess) return e;
-	e = trailing_update(ctx, c0, n1, 0, n - n1, inv);
+	bool right_done = false;
+	e = trailing_update(ctx, c0, n1, 0, n - n1, inv, nullptr, &right_done);
 	if (e != hipSuccess) return e;
-	return potrf_rec(ctx, c0 + n1, n - n1, inv);
+	return potrf_rec(ctx, c0 + n1, n - n1, inv, right_done);
 }
 
 static int run_potrf(gpemu_ctx *ctx, int inv)

@@ -61,6 +61,9 @@ struct GemmArgs {
 	int order_mode;      // 2: dense enumeration of the lower-triangular tiles, 3: tile table (set by launch_gemm)
 	const int *tile_table; // order_mode 3: entry blockIdx.x = (tm << 16) | tn, or -1 for none
 	unsigned long long *trace;   // optional {first start, last end} device timestamps of this launch (GPEMU_TRACE)
+	int fa;              // factor-ahead: the workgroup of tile (0,0) factors its updated 64x64 diagonal block (64x64 tiles only)
+	int fa_c0;           // global column of that block (for the 1-based index of a failed pivot)
+	int *fa_info;        // info words (one per matrix of the batch)
 };
 
 struct ProfState {
@@ -192,7 +195,8 @@ extern int g_gemm_big_tiles, g_gemm_big_cfg, g_gemm_table;
 std::vector<int> build_tile_table(int tiles_m, int tiles_n, int tri, int S, int bm = 128, int bn = 128);
 hipError_t launch_leaf(hipStream_t s, double *T, long ld, int c0, int m_below, int *info,
                        unsigned long long *trace_factor = nullptr, unsigned long long *trace_solve = nullptr,
-                       int nbatch = 1, long bstride = 0);
+                       int nbatch = 1, long bstride = 0, bool skip_factor = false);
+bool gemm_factor_ahead_ok(const GemmArgs &a);
 hipError_t launch_leaf128(hipStream_t s, double *T, long ld, int c0, int m_below, int *info, double *dinv,
                           int nbatch = 1, long bstride = 0);
 hipError_t launch_gram_partials(hipStream_t s, const double *Z, long ld, int Np, int nrhs, int Rp, double *part,

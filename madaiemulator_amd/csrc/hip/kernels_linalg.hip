@@ -65,6 +65,11 @@ __device__ __forceinline__ void trace_end(unsigned long long *t, TraceT0 t0)
 	atomicAdd(t + 4, clk - t0.clk);
 }
 
+// ---- pieces of the 64x64 leaf factorisation used by the factor-ahead GEMM tile (defined further down)
+constexpr int LP = LEAF + 2;
+template <int P, int LD> __device__ __forceinline__ void panel_factor(double *A, int lane, int &bad, int bad_off);
+template <int P, int LD> __device__ __forceinline__ void panel_update(double *A, int wave, int lane);
+
 // PF = global-load prefetch distance in k-steps.  1: the chunk for step k+1 is requested at the top of step k and
 // written to LDS at its end.  2 (two register stages, for the 64x64 tiles that have the registers to spare): requested
 // two steps ahead -- the short-K panel updates are chains of dependent HBM round trips, one per k-step, and this halves
@@ -73,15 +78,23 @@ __device__ __forceinline__ void trace_end(unsigned long long *t, TraceT0 t0)
 // never used): the real 16-byte loads of that chunk, issued a k-step later, then find their lines in the XCD's L2
 // instead of paying the fabric / HBM round trip inside their own k-step -- a prefetch distance of two k-steps for one
 // VGPR, where a second register stage (PF = 2) would cost 16 and drop the 128x128 tiles to one workgroup per CU.
-template <int BM, int BN, int MINW, int WGM = 2, int WGN = 2, int PF = 1, int L2PF = 0>
+// FA = 1 (factor-ahead, 64x64 tiles of a triangular trailing update): the workgroup of tile (0,0) -- the diagonal block
+// the NEXT leaf factorisation starts from -- does not store its updated tile: it keeps it in LDS, factors it there
+// (the leaf_factor_kernel code) and writes L.  The 64 sequential pivots of that block then run beside the other tiles
+// of the update instead of in a launch of their own behind it (one launch and ~10 us less on the critical chain per
+// 64 columns); the arithmetic is the update's and the leaf's, so the bits do not change.
+template <int BM, int BN, int MINW, int WGM = 2, int WGN = 2, int PF = 1, int L2PF = 0, int FA = 0>
 __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs g)
 {
 	constexpr int NT = 64 * WGM * WGN;              // threads: WGM x WGN waves
 	constexpr int WM = BM / WGM, WN = BN / WGN;
 	constexpr int TM = WM / 16, TN = WN / 16;
 	constexpr int AIT = BM * 8 / NT, BIT = BN * 8 / NT;
-	__shared__ double As[2][BM * LDS_S];
-	__shared__ double Bs[2][BN * LDS_S];
+	constexpr int SMEM_GEMM = 2 * (BM + BN) * LDS_S;
+	constexpr int SMEM = (FA && LEAF * LP > SMEM_GEMM) ? LEAF * LP : SMEM_GEMM;
+	__shared__ double smem[SMEM];
+	double (*As)[BM * LDS_S] = reinterpret_cast<double (*)[BM * LDS_S]>(smem);
+	double (*Bs)[BN * LDS_S] = reinterpret_cast<double (*)[BN * LDS_S]>(smem + 2 * BM * LDS_S);
 
 	// batch of independent problems (lock-step factorisations): blockIdx.y selects the matrix
 	g.C += (long)blockIdx.y * g.bsC;
@@ -353,6 +366,43 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 	// epilogue
 	unsigned long long clk_loop_end = 0;
 	if (g.trace && tr0.wall) clk_loop_end = clock64();
+	if (FA && g.fa && tm == 0 && tn == 0) {
+		static_assert(!FA || (BM == LEAF && BN == LEAF && WGM == 2 && WGN == 2), "factor-ahead is for the 64x64 tiles, 4 waves");
+		// the updated diagonal block goes to LDS instead of memory (every wave is past its last read of the operand
+		// buffers: the k-loop ends with a barrier), is factored there and leaves as L
+		double *A = smem;
+#pragma unroll
+		for (int i = 0; i < TM; i++)
+#pragma unroll
+			for (int r = 0; r < 4; r++)
+#pragma unroll
+				for (int j = 0; j < TN; j++)
+					A[(wm * WM + i * 16 + (lane >> 4) + 4 * r) * LP + wn * WN + j * 16 + (lane & 15)] = g.alpha * acc[i][j][r];
+		__syncthreads();
+		int bad = 0;
+		if (wave == 0) panel_factor<0, LP>(A, lane, bad, 0);
+		__syncthreads();
+		panel_update<0, LP>(A, wave, lane);
+		__syncthreads();
+		if (wave == 0) panel_factor<1, LP>(A, lane, bad, 0);
+		__syncthreads();
+		panel_update<1, LP>(A, wave, lane);
+		__syncthreads();
+		if (wave == 0) panel_factor<2, LP>(A, lane, bad, 0);
+		__syncthreads();
+		panel_update<2, LP>(A, wave, lane);
+		__syncthreads();
+		if (wave == 0) panel_factor<3, LP>(A, lane, bad, 0);
+		__syncthreads();
+		if (tid == 0 && bad) atomicMin(g.fa_info + blockIdx.y, g.fa_c0 + bad);
+#pragma unroll
+		for (int u = 0; u < 16; u++) {
+			const int r = wave + 4 * u;
+			if (lane <= r) g.C[(long)r * g.ldc + lane] = A[r * LP + lane];
+		}
+		trace_end(g.trace, tr0);
+		return;
+	}
 	if (full_tile) {
 #pragma unroll
 		for (int i = 0; i < TM; i++)
@@ -483,6 +533,14 @@ int g_gemm_table = 8;          // XCD-blocked tile order from a table for launch
 int g_gemm_big_cfg = 3;        // tile configuration of the big launches (3: 128x128 8 waves, 0: 128x128 4 waves)
 int g_gemm_big_tiles = 2048;   // 128x128 tiles (8 waves) once a launch has this many of them, else 64x64
 
+// would launch_gemm run this update with the factor-ahead tile?  (the caller then skips the next leaf factorisation)
+bool gemm_factor_ahead_ok(const GemmArgs &a)
+{
+	int choose_gemm_cfg(const GemmArgs &a);
+	return a.fa && a.tri && a.diag_off == 0 && a.m >= LEAF && a.n >= LEAF && a.beta == 1 && a.alpha == -1.0 && !a.kstart_mode &&
+	       !a.kend_mode && a.ksplit <= 1 && choose_gemm_cfg(a) == 2;
+}
+
 int choose_gemm_cfg(const GemmArgs &a)
 {
 	if (g_gemm_force_cfg >= 0) return g_gemm_force_cfg;
@@ -565,6 +623,7 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs &a_in)
 	}
 	const int nbatch = a.nbatch > 1 ? a.nbatch : 1;
 	const int cfg = choose_gemm_cfg(a);
+	if (cfg != 2) a.fa = 0;                                               // factor-ahead lives in the 64x64 tiles only
 	// tile shapes: 0 128x128 (4 waves), 1 128x64, 2 64x64, 3 128x128 (8 waves), 4 256x128 (8 waves, one workgroup
 	// per CU), 5 256x128 (16 waves), 6 128x256 (8 waves), 7 = 3 with the L2 prefetch of the chunk after the next
 	static const int k_bm[] = {128, 128, 64, 128, 256, 256, 128, 128}, k_bn[] = {128, 64, 64, 128, 128, 128, 256, 128};
@@ -593,7 +652,10 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs &a_in)
 	case 5: hipLaunchKernelGGL((gemm_nt_kernel<256, 128, 4, 8, 2>), dim3(T, nbatch), dim3(1024), 0, s, a); break;
 	case 6: hipLaunchKernelGGL((gemm_nt_kernel<128, 256, 2, 2, 4>), dim3(T, nbatch), dim3(512), 0, s, a); break;
 	case 7: hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 4, 4, 2, 1, 1>), dim3(T, nbatch), dim3(512), 0, s, a); break;
-	default: hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2, 2>), dim3(T, nbatch), dim3(256), 0, s, a); break;
+	default:
+		if (a.fa) hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2, 2, 0, 1>), dim3(T, nbatch), dim3(256), 0, s, a);
+		else hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2, 2>), dim3(T, nbatch), dim3(256), 0, s, a);
+		break;
 	}
 	return hipGetLastError();
 }
@@ -618,8 +680,6 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs &a_in)
 //    registers.
 // (One fused kernel with the old row-per-lane solve made hipcc spill ~2000 VGPRs.)
 // ---------------------------------------------------------------------------
-constexpr int LP = LEAF + 2;
-
 __device__ __forceinline__ double bcast_lane(double v, int srclane)
 {
 	// wave-wide broadcast of lane `srclane` (compile-time constant after unrolling) through SGPRs
@@ -1118,10 +1178,11 @@ hipError_t launch_leaf128(hipStream_t s, double *T, long ld, int c0, int m_below
 }
 
 hipError_t launch_leaf(hipStream_t s, double *T, long ld, int c0, int m_below, int *info, unsigned long long *trf,
-                       unsigned long long *trs, int nbatch, long bstride)
+                       unsigned long long *trs, int nbatch, long bstride, bool skip_factor)
 {
 	if (nbatch < 1) nbatch = 1;
-	hipLaunchKernelGGL(leaf_factor_kernel, dim3(1, nbatch), dim3(256), 0, s, T, ld, c0, info, trf, bstride);
+	if (!skip_factor)                    // (skipped: the diagonal block was factored by the update before, factor-ahead)
+		hipLaunchKernelGGL(leaf_factor_kernel, dim3(1, nbatch), dim3(256), 0, s, T, ld, c0, info, trf, bstride);
 	if (m_below > 0)
 		hipLaunchKernelGGL(leaf_solve_kernel, dim3((m_below + 63) / 64, nbatch), dim3(256), 0, s, T, ld, c0, m_below,
 		                   trs, bstride);
