@@ -67,6 +67,28 @@ def _cpu_eval_worker(args):
     return time.perf_counter() - t
 
 
+def usable_cores():
+    """host cores this process may really use: the scheduler affinity, cut down to the cgroup CPU quota when there is one
+    (the GPU box shows 256 CPUs and grants 16: `cpu.max` = 1600000 100000)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = int(q) / int(p)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
 def cpu_baseline(kind, order, N, d, seed):
     """Reference-faithful CPU restatement (oracle/, kind "port") on the host cores: one independent evaluation
     per core, the reference's own parallelisation (estimate_threaded.c:97,172).  Bounded samples at N_s < N
@@ -74,14 +96,16 @@ def cpu_baseline(kind, order, N, d, seed):
     largest one (the path is N^3: unblocked Cholesky + explicit inverse) as the reported value."""
     from oracle import oracle as O
     O.build()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores, quota = usable_cores()
     sizes = [1024, 1536, 2048]
     t0 = time.perf_counter()
     per = {}
     with mp.get_context("spawn").Pool(cores) as pool:
         alone = pool.map(_cpu_eval_worker, [(kind, order, sizes[1], d, seed, 0)])[0]      # one core, the others idle
+        print(f"[bench] cpu baseline: one evaluation alone at N={sizes[1]}: {alone:.1f} s", file=sys.stderr, flush=True)
         for Ns in sizes:
             per[Ns] = float(np.mean(pool.map(_cpu_eval_worker, [(kind, order, Ns, d, seed, i) for i in range(cores)])))
+            print(f"[bench] cpu baseline: {cores} concurrent at N={Ns}: {per[Ns]:.1f} s each", file=sys.stderr, flush=True)
     wall = time.perf_counter() - t0
     Ns = sizes[-1]
     per_eval = per[Ns]
@@ -100,7 +124,8 @@ def cpu_baseline(kind, order, N, d, seed):
     per_q = (time.perf_counter() - tq) / 4
     preds_per_s = cores / (per_q * (N / Ns) ** 2)
     return {
-        "value": evals_per_s, "unit": "likelihood-evals/s", "cores": cores, "nproc": os.cpu_count(), "kind": "port",
+        "value": evals_per_s, "unit": "likelihood-evals/s", "cores": cores, "nproc": os.cpu_count(),
+        "cgroup_cpu_quota": quota, "kind": "port",
         "sample": (f"{cores} concurrent oracle evaluations (one per core) at N={sizes}, d={d}: "
                    f"{', '.join('%.2f' % per[n] for n in sizes)} s each ({wall:.1f} s wall in all); one alone at N={sizes[1]}: "
                    f"{alone:.2f} s; value = N={Ns} sample extrapolated to N={N} by (N/{Ns})^3; power-law fit over the three "
@@ -224,6 +249,11 @@ def main():
             gate[f"N{Ng}"] = gn
             g.close()
 
+    def note(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+    note("parity gate done" if gate is not None else "start")
+
     # ---- region A: likelihood evaluations
     # the K independent evaluations (each at its own fresh theta) are cut into lock-step batches of B and the
     # batches dealt round-robin to the contexts: every kernel of a factorisation handles its B matrices at once,
@@ -269,6 +299,7 @@ def main():
         rows = shard.all_gather_rows(np.concatenate([[last["value"]], theta(K * B - 1)])[None, :], 1 + len(theta(0)))
         assert len(rows) == world_size
     evals_per_s = ngpus * K * B / tA
+    note(f"region A: {evals_per_s:.1f} evaluations/s")
 
     # one evaluation at a time on one context (the shape of a sequential caller: one BFGS run, alloc_emulator_struct;
     # emulator_struct.c:28-32): host call to host result, i.e. `--batch 1 --streams 1`
@@ -317,6 +348,7 @@ def main():
         pred = {"value": ngpus * nb * per / tB, "unit": "predictions/s", "points_per_rank": nb * per,
                 "distinct_points": True, "batches": nb, "ms_per_batch": tB / nb * 1e3}
 
+    note("region B (predictions) done")
     # ---- region C: value + gradient (evalFnGradMulti, maxmultimin.c:615-618 -- what estimate_thetas calls per BFGS
     #      step), lock-step batches of Bg on a pow-exp model of the same N and d (own context, own HBM workspace)
     vg = None
@@ -355,6 +387,7 @@ def main():
                                    "reductions, host finishing) against N^3 algorithmic flops per evaluation"}}
         gctx.close()
 
+    note("region C (value+gradient) done")
     # ---- roofline of the dominant kernel (fp64 MFMA GEMM of the Cholesky trailing updates), HIP events on the
     #      ctx stream around every launch; rank 0 only
     roof, roof_other = None, {}
@@ -406,6 +439,7 @@ def main():
                                           "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS,
                                           "flops_per_prediction": p["flops"] / per}
 
+    note("roofline sections done")
     cpu = None
     if rank == 0 and ngpus == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(kind, order, N, d, seed)
