@@ -27,6 +27,7 @@ using namespace gpemu;
 static int g_leaf128 = 0;                // 128-column fused leaves (env GPEMU_LEAF128=1); measured 3 % slower than 64
 static int g_lookahead = 0;              // two-stream schedule of the outer panels (env GPEMU_LOOKAHEAD=1); see DESIGN.md
 static int g_factor_ahead = 1;           // the update's tile (0,0) factors the next diagonal block (env GPEMU_FACTOR_AHEAD=0: off)
+static int g_solve_ahead = 1;            // one matrix per launch: tile column 0 of the update also solves its rows (env GPEMU_SOLVE_AHEAD=0: off)
 static int g_fill_gram = 1;              // MFMA Gram form of the training fill (env GPEMU_FILL_GRAM=0: difference form always)
 static int g_nb_top = 0;            // outer panel width (env GPEMU_NB_TOP); 0 = automatic: 512 for one matrix, 2048 for a lock-step batch
 constexpr int INFO_NONE = 0x7f7f7f7f;   // "no failed pivot": what hipMemsetAsync(.., 0x7f, ..) leaves in *info
@@ -137,6 +138,7 @@ static void read_environment()
 	g_leaf128 = geti("GPEMU_LEAF128", 0) != 0;
 	g_fill_gram = geti("GPEMU_FILL_GRAM", 1) != 0;
 	g_factor_ahead = geti("GPEMU_FACTOR_AHEAD", 1) != 0;
+	g_solve_ahead = geti("GPEMU_SOLVE_AHEAD", 1) != 0;
 	v = geti("GPEMU_NB_TOP", 0);
 	g_nb_top = v >= LEAF ? (v / LEAF) * LEAF : 0;
 }
@@ -234,6 +236,7 @@ extern "C" void gpemu_ctx_destroy(gpemu_ctx *ctx)
 	free_model(ctx);
 	for (auto e : ctx->prof.ev) hipEventDestroy(e);
 	if (ctx->dInfo) hipFree(ctx->dInfo);
+	if (ctx->dFlags) hipFree(ctx->dFlags);
 	if (ctx->dTrace) hipFree(ctx->dTrace);
 	if (ctx->dParams) hipFree(ctx->dParams);
 	if (ctx->hParams) hipHostFree(ctx->hParams);
@@ -464,7 +467,7 @@ static int make_cov_params(gpemu_ctx *ctx, const double *thetas, int nthetas, Co
 // *fa_done (optional): set when the update ran with the factor-ahead tile, i.e. the 64x64 diagonal block at c0+k is
 // already factored when the update has finished and the next leaf must not factor it again
 static hipError_t trailing_update(gpemu_ctx *ctx, int c0, int k, int col_off, int ncols, int inv, hipStream_t stream = nullptr,
-                                  bool *fa_done = nullptr)
+                                  bool *fa_done = nullptr, bool *sa_done = nullptr)
 {
 	// C[rows >= r0, cols r0 .. r0+ncols) -= P P^T with P = the factored panel columns [c0, c0+k) and
 	// r0 = c0 + k + col_off (rows above r0 belong to the upper triangle of those columns)
@@ -490,6 +493,16 @@ static hipError_t trailing_update(gpemu_ctx *ctx, int c0, int k, int col_off, in
 		g.fa_info = ctx->dInfo;
 		if (g.fa && gemm_factor_ahead_ok(g)) *fa_done = true;
 		else g.fa = 0;
+		if (sa_done) {
+			*sa_done = false;
+			const int blk = r0 / LEAF;
+			// (not with the inverse rows: the next leaf's row range then reaches 64 identity rows beyond this update's)
+			if (g.fa && g_solve_ahead && ctx->nb <= 1 && !inv && ctx->dFlags && blk < ctx->flags_len && ncols >= LEAF && g.m % LEAF == 0) {
+				g.sa = 1;
+				g.sa_flag = ctx->dFlags + blk;
+				*sa_done = true;
+			}
+		}
 	}
 	return gemm(ctx, g, stream);
 }
@@ -505,7 +518,8 @@ static hipEvent_t next_event(gpemu_ctx *ctx)
 }
 
 // diag_done: the 64x64 diagonal block at (c0,c0) is already factored (by the factor-ahead tile of the update before)
-static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv, bool diag_done = false)
+// solve_done: the rows under that block are solved as well (solve-ahead tiles of the same update)
+static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv, bool diag_done = false, bool solve_done = false)
 {
 	const long ld = ctx->Np;
 	const int base_end = ctx->Np + ctx->Rp;
@@ -515,7 +529,7 @@ static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv, bool diag_do
 		unsigned long long *trf = trace_slot(ctx, "leaf_factor c0=%d", c0);
 		unsigned long long *trs = trace_slot(ctx, "leaf_solve c0=%d m=%d", c0, row_end - (c0 + LEAF));
 		return launch_leaf(ctx->stream, ctx->dT, ld, c0, row_end - (c0 + LEAF), ctx->dInfo, trf, trs, ctx->nb,
-		                   (long)ctx->T_stride, diag_done);
+		                   (long)ctx->T_stride, diag_done, diag_done && solve_done);
 	}
 	if (n == 2 * LEAF && g_leaf128) {
 		const int row_end = base_end + (inv ? c0 + 2 * LEAF : 0);
@@ -537,16 +551,16 @@ static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv, bool diag_do
 		const bool profiling = ctx->prof.cls != GPEMU_PROF_NONE && ctx->prof.cls != GPEMU_PROF_POTRF;
 		const bool ahead = g_lookahead && ctx->stream2 && !profiling && c0 == 0 && n == ctx->Np;
 		hipEvent_t ev_bulk_prev = nullptr;
-		bool next_done = diag_done;
+		bool next_done = diag_done, next_solved = solve_done;
 		for (int c = c0; c < c0 + n; c += nb_top) {
 			const int nb = std::min(nb_top, c0 + n - c);
-			hipError_t e = potrf_rec(ctx, c, nb, inv, next_done);
-			next_done = false;
+			hipError_t e = potrf_rec(ctx, c, nb, inv, next_done, next_solved);
+			next_done = false; next_solved = false;
 			if (e != hipSuccess) return e;
 			const int rest = c0 + n - (c + nb);
 			if (rest <= 0) continue;
 			if (!ahead) {
-				e = trailing_update(ctx, c, nb, 0, rest, inv, nullptr, &next_done);
+				e = trailing_update(ctx, c, nb, 0, rest, inv, nullptr, &next_done, &next_solved);
 				if (e != hipSuccess) return e;
 				continue;
 			}
@@ -582,12 +596,12 @@ static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv, bool diag_do
 		return hipSuccess;
 	}
 	const int n1 = ((n / LEAF + 1) / 2) * LEAF;
-	hipError_t e = potrf_rec(ctx, c0, n1, inv, diag_done);
+	hipError_t e = potrf_rec(ctx, c0, n1, inv, diag_done, solve_done);
 	if (e != hipSuccess) return e;
-	bool right_done = false;
-	e = trailing_update(ctx, c0, n1, 0, n - n1, inv, nullptr, &right_done);
+	bool right_done = false, right_solved = false;
+	e = trailing_update(ctx, c0, n1, 0, n - n1, inv, nullptr, &right_done, &right_solved);
 	if (e != hipSuccess) return e;
-	return potrf_rec(ctx, c0 + n1, n - n1, inv, right_done);
+	return potrf_rec(ctx, c0 + n1, n - n1, inv, right_done, right_solved);
 }
 
 static int run_potrf(gpemu_ctx *ctx, int inv)
@@ -667,6 +681,16 @@ static int stage_matrices(gpemu_ctx *ctx, const CovParams *ps, int nb, int inv)
 	if (inv)
 		HIPCHK(ctx, launch_set_identity_rows(ctx->stream, ctx->dT + (size_t)(Np + Rp) * Np, Np, Np, nb, (long)ctx->T_stride));
 	HIPCHK(ctx, hipMemsetAsync(ctx->dInfo, 0x7f, (size_t)nb * sizeof(int), ctx->stream));
+	// solve-ahead flags (one per 64-column block), zero before every factorisation
+	if (ctx->flags_len < Np / LEAF + 1) {
+		HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+		free_graphs(ctx);
+		if (ctx->dFlags) hipFree(ctx->dFlags);
+		ctx->dFlags = nullptr; ctx->flags_len = 0;
+		HIPCHK(ctx, hipMalloc(&ctx->dFlags, (size_t)(Np / LEAF + 1) * sizeof(int)));
+		ctx->flags_len = Np / LEAF + 1;
+	}
+	HIPCHK(ctx, hipMemsetAsync(ctx->dFlags, 0, (size_t)ctx->flags_len * sizeof(int), ctx->stream));
 	return GPEMU_OK;
 }
 
@@ -793,6 +817,7 @@ static int collect_one(gpemu_ctx *ctx, int b, double *neg_loglik, double *sigma2
 {
 	const int inf = (ctx->hInfo[b] >= INFO_NONE) ? 0 : ctx->hInfo[b];
 	if (info) *info = inf;
+	if (inf < 0) return fail(ctx, GPEMU_ERR_HIP, "device: a solve-ahead tile gave up waiting for its diagonal block");
 	if (inf != 0) {
 		if (neg_loglik) *neg_loglik = NAN;
 		if (sigma2) *sigma2 = NAN;
@@ -950,6 +975,7 @@ static int factor_with_inverse(gpemu_ctx *ctx, const double *thetas, int nthetas
 	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 	const int inf = (*ctx->hInfo >= INFO_NONE) ? 0 : *ctx->hInfo;
 	if (info) *info = inf;
+	if (inf < 0) return fail(ctx, GPEMU_ERR_HIP, "device: a solve-ahead tile gave up waiting for its diagonal block");
 	if (inf) return fail(ctx, GPEMU_ERR_NOT_PD, "covariance matrix is not positive definite");
 	return GPEMU_OK;
 }

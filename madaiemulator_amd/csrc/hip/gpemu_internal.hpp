@@ -64,6 +64,8 @@ struct GemmArgs {
 	int fa;              // factor-ahead: the workgroup of tile (0,0) factors its updated 64x64 diagonal block (64x64 tiles only)
 	int fa_c0;           // global column of that block (for the 1-based index of a failed pivot)
 	int *fa_info;        // info words (one per matrix of the batch)
+	int sa;              // solve-ahead (with fa, ONE matrix per launch): the tiles of tile column 0 wait for that L and solve their rows
+	int *sa_flag;        // zero before the launch; set by tile (0,0) once L is visible
 };
 
 struct ProfState {
@@ -101,6 +103,8 @@ struct gpemu_ctx {
 	size_t T_stride = 0;         // elements between consecutive matrices of the batch
 	int batch_cap = 0;           // allocated per-matrix result slots (dInfo, dGramPart, dRes, hRes, hInfo)
 	int *dInfo = nullptr;
+	int *dFlags = nullptr;       // solve-ahead flags, one per 64-column block (zeroed before every factorisation)
+	int flags_len = 0;
 	double *dDiagInv = nullptr;  // eight inverted 16x16 diagonal blocks of the current 128-column leaf
 	double *dGramPart = nullptr; // [Np/128][Rp*Rp]
 	double *dRes = nullptr;      // Rp*Rp gram + logdet + spare
@@ -195,7 +199,7 @@ extern int g_gemm_big_tiles, g_gemm_big_cfg, g_gemm_table;
 std::vector<int> build_tile_table(int tiles_m, int tiles_n, int tri, int S, int bm = 128, int bn = 128);
 hipError_t launch_leaf(hipStream_t s, double *T, long ld, int c0, int m_below, int *info,
                        unsigned long long *trace_factor = nullptr, unsigned long long *trace_solve = nullptr,
-                       int nbatch = 1, long bstride = 0, bool skip_factor = false);
+                       int nbatch = 1, long bstride = 0, bool skip_factor = false, bool skip_solve = false);
 bool gemm_factor_ahead_ok(const GemmArgs &a);
 hipError_t launch_leaf128(hipStream_t s, double *T, long ld, int c0, int m_below, int *info, double *dinv,
                           int nbatch = 1, long bstride = 0);

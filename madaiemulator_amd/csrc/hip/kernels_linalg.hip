@@ -69,6 +69,7 @@ __device__ __forceinline__ void trace_end(unsigned long long *t, TraceT0 t0)
 constexpr int LP = LEAF + 2;
 template <int P, int LD> __device__ __forceinline__ void panel_factor(double *A, int lane, int &bad, int bad_off);
 template <int P, int LD> __device__ __forceinline__ void panel_update(double *A, int wave, int lane);
+__device__ __forceinline__ void tri_inverse16(double *M, int o, double *tile, int lane);
 
 // PF = global-load prefetch distance in k-steps.  1: the chunk for step k+1 is requested at the top of step k and
 // written to LDS at its end.  2 (two register stages, for the 64x64 tiles that have the registers to spare): requested
@@ -400,6 +401,88 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 			const int r = wave + 4 * u;
 			if (lane <= r) g.C[(long)r * g.ldc + lane] = A[r * LP + lane];
 		}
+		if (g.sa) {
+			// solve-ahead: publish L to the workgroups of tile column 0 (MI355X_MICROARCH.md, inter-workgroup visibility:
+			// every storing wave drains its stores, barrier, one lane releases at agent scope, then the flag)
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__syncthreads();
+			if (tid == 0) {
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				__hip_atomic_store(g.sa_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
+		trace_end(g.trace, tr0);
+		return;
+	}
+	if (FA && g.sa && tn == 0 && tm > 0) {
+		// Solve-ahead (one matrix per launch only): this tile holds 64 rows of the block column whose diagonal block
+		// tile (0,0) is factoring right now.  Instead of storing the updated rows and leaving X L^T = B to a launch of
+		// its own, wait for L and solve here (the leaf_solve_kernel arithmetic on the same values: same bits).
+		// At most (rows below)/64 <= a few hundred workgroups wait, tile (0,0) never waits for anything and is the first
+		// workgroup of the grid: no waiting workgroup can keep it off the chip.  The wait is bounded all the same.
+		double *M = smem;
+#pragma unroll
+		for (int i = 0; i < TM; i++)
+#pragma unroll
+			for (int r = 0; r < 4; r++)
+#pragma unroll
+				for (int j = 0; j < TN; j++)
+					M[(wm * WM + i * 16 + (lane >> 4) + 4 * r) * LP + wn * WN + j * 16 + (lane & 15)] = g.alpha * acc[i][j][r];
+		__syncthreads();
+		const int q = lane & 15, gq = lane >> 4;
+		d4_t R[4];                         // wave w: rows 16w .. 16w+15 in the solve's layout (lane (q,g): row q, columns 16j + g + 4r)
+#pragma unroll
+		for (int j = 0; j < 4; j++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) R[j][r] = M[(16 * wave + q) * LP + 16 * j + gq + 4 * r];
+		__syncthreads();
+		if (tid == 0) {
+			long spins = 0;
+			while (__hip_atomic_load(g.sa_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+				__builtin_amdgcn_s_sleep(8);
+				if (++spins > 400000L) { atomicMin(g.fa_info, -1); break; }       // (~0.3 s; never seen) reported as a device failure
+			}
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		}
+		__syncthreads();
+		{
+			const double *D = g.C;                                  // the diagonal block (tile (0,0)), L in its lower triangle
+			double v[16];
+#pragma unroll
+			for (int u = 0; u < 16; u++) v[u] = D[(long)(wave + 4 * u) * g.ldc + lane];
+#pragma unroll
+			for (int u = 0; u < 16; u++) M[(wave + 4 * u) * LP + lane] = v[u];
+		}
+		__syncthreads();
+		{
+			const int sr = (wave == 3) ? 0 : wave, sc = (wave == 3) ? 3 : wave + 1;
+			tri_inverse16(M, 16 * wave, M + 16 * sr * LP + 16 * sc, lane);
+		}
+		__syncthreads();
+		double *bp = g.C + (long)(tm * BM + 16 * wave + q) * g.ldc;
+		d4_t X[4];
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			d4_t a4 = R[j];
+#pragma unroll
+			for (int i = 0; i < j; i++)
+#pragma unroll
+				for (int r = 0; r < 4; r++) {
+					const double a = -M[(16 * j + q) * LP + 16 * i + gq + 4 * r];
+					a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[i][r], a4, 0, 0, 0);
+				}
+			d4_t xj = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+			for (int r = 0; r < 4; r++) {
+				const double a = M[(16 * j + q) * LP + 16 * j + gq + 4 * r];
+				xj = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a4[r], xj, 0, 0, 0);
+			}
+			X[j] = xj;
+#pragma unroll
+			for (int r = 0; r < 4; r++) bp[16 * j + gq + 4 * r] = xj[r];
+		}
 		trace_end(g.trace, tr0);
 		return;
 	}
@@ -624,6 +707,7 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs &a_in)
 	const int nbatch = a.nbatch > 1 ? a.nbatch : 1;
 	const int cfg = choose_gemm_cfg(a);
 	if (cfg != 2) a.fa = 0;                                               // factor-ahead lives in the 64x64 tiles only
+	if (!a.fa || nbatch > 1 || !a.sa_flag) a.sa = 0;
 	// tile shapes: 0 128x128 (4 waves), 1 128x64, 2 64x64, 3 128x128 (8 waves), 4 256x128 (8 waves, one workgroup
 	// per CU), 5 256x128 (16 waves), 6 128x256 (8 waves), 7 = 3 with the L2 prefetch of the chunk after the next
 	static const int k_bm[] = {128, 128, 64, 128, 256, 256, 128, 128}, k_bn[] = {128, 64, 64, 128, 128, 128, 256, 128};
@@ -1178,12 +1262,12 @@ hipError_t launch_leaf128(hipStream_t s, double *T, long ld, int c0, int m_below
 }
 
 hipError_t launch_leaf(hipStream_t s, double *T, long ld, int c0, int m_below, int *info, unsigned long long *trf,
-                       unsigned long long *trs, int nbatch, long bstride, bool skip_factor)
+                       unsigned long long *trs, int nbatch, long bstride, bool skip_factor, bool skip_solve)
 {
 	if (nbatch < 1) nbatch = 1;
 	if (!skip_factor)                    // (skipped: the diagonal block was factored by the update before, factor-ahead)
 		hipLaunchKernelGGL(leaf_factor_kernel, dim3(1, nbatch), dim3(256), 0, s, T, ld, c0, info, trf, bstride);
-	if (m_below > 0)
+	if (m_below > 0 && !skip_solve)      // (skipped: the rows were solved by the update before, solve-ahead)
 		hipLaunchKernelGGL(leaf_solve_kernel, dim3((m_below + 63) / 64, nbatch), dim3(256), 0, s, T, ld, c0, m_below,
 		                   trs, bstride);
 	return hipGetLastError();
