@@ -392,7 +392,9 @@ def main():
     #      ctx stream around every launch; rank 0 only
     roof, roof_other = None, {}
     if rank == 0:
-        ctx.prof_begin(abi.PROF_GEMM)
+        # the dominant kernel = gemm_nt_kernel<128,128,4,4,2> (128x128 tiles, 8 waves): the big trailing updates of a
+        # lock-step batch, 91 % of its flops and 80 % of the GPU time of this bench (profiles/r02_rocprofv3_kernel_stats_*)
+        ctx.prof_begin(abi.PROF_GEMM_BIG)
         ctx.loglik_batch_enqueue(np.array([theta(2000 + i) for i in range(B)]))     # one lock-step batch, as timed above
         p = ctx.prof_end()
         ach = p["flops"] / (p["ms"] * 1e-3) / 1e12
@@ -402,19 +404,24 @@ def main():
         # (profiles/r01_pmc_fetch_calibration.txt), so the whole raw fetch is doubled; WRITE_SIZE is exact.  Infinity-
         # Cache hits are included in both, i.e. this is fabric traffic, an upper bound on HBM traffic.
         traffic = None
-        tpath = None
-        for cand in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic_v7_nb2048.json"):      # newest first
-            if os.path.exists(os.path.join(ROOT, "profiles", cand)):
-                tpath = os.path.join(ROOT, "profiles", cand)
-                break
-        if args.workload == "c3" and B == 16 and tpath:      # measured for batches of 16
-            tj = json.load(open(tpath))["gemm_nt_kernel"]
+        tpath = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
+        if args.workload == "c3" and B == 16 and os.path.exists(tpath):      # measured for batches of 16
+            tj = json.load(open(tpath))["gemm_nt_kernel_128x128_8waves"]
             traffic = (2.0 * tj["fetch_bytes_raw"] + tj["write_bytes"]) / tj["launches"]
-        roof = {"bound": "mfma", "kernel": "gemm_nt_kernel (potrf trailing update, v_mfma_f64_16x16x4_f64)",
+        roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<128,128,4,4,2> (potrf trailing updates on 128x128 tiles, v_mfma_f64_16x16x4_f64)",
                 "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS,
                 "traffic": traffic, "traffic_source": os.path.basename(tpath) if (traffic is not None) else None,
                 "launches": p["n"], "avg_launch_us": p["ms"] * 1e3 / max(p["n"], 1),
-                "flops_per_eval": p["flops"] / B, "evaluations_per_launch": B}
+                "flops_per_launch": p["flops"] / max(p["n"], 1), "evaluations_per_launch": B}
+        # every GEMM launch of the batch (the narrow K <= 256 updates on 64x64 tiles included; with factor-ahead their
+        # tile (0,0) also factors the next diagonal block, so their durations contain ~10 us of pivots each)
+        ctx.prof_begin(abi.PROF_GEMM)
+        ctx.loglik_batch_enqueue(np.array([theta(2500 + i) for i in range(B)]))
+        p = ctx.prof_end()
+        ach = p["flops"] / (p["ms"] * 1e-3) / 1e12
+        roof_other["gemm_all_launches"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                           "frac": ach / PEAK_FP64_MFMA_TFLOPS, "launches": p["n"],
+                                           "avg_launch_us": p["ms"] * 1e3 / max(p["n"], 1), "flops_per_eval": p["flops"] / B}
         ctx.prof_begin(abi.PROF_POTRF)
         ctx.loglik_batch_enqueue(np.array([theta(3000 + i) for i in range(B)]))
         p = ctx.prof_end()

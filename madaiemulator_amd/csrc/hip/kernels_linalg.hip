@@ -616,6 +616,12 @@ int g_gemm_table = 8;          // XCD-blocked tile order from a table for launch
 int g_gemm_big_cfg = 3;        // tile configuration of the big launches (3: 128x128 8 waves, 0: 128x128 4 waves)
 int g_gemm_big_tiles = 2048;   // 128x128 tiles (8 waves) once a launch has this many of them, else 64x64
 
+bool gemm_uses_big_tiles(const GemmArgs &a)
+{
+	int choose_gemm_cfg(const GemmArgs &a);
+	return choose_gemm_cfg(a) == 3;
+}
+
 // would launch_gemm run this update with the factor-ahead tile?  (the caller then skips the next leaf factorisation)
 bool gemm_factor_ahead_ok(const GemmArgs &a)
 {
