@@ -396,21 +396,26 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 		if (wave == 0) panel_factor<3, LP>(A, lane, bad, 0);
 		__syncthreads();
 		if (tid == 0 && bad) atomicMin(g.fa_info + blockIdx.y, g.fa_c0 + bad);
+		if (!g.sa) {
 #pragma unroll
-		for (int u = 0; u < 16; u++) {
-			const int r = wave + 4 * u;
-			if (lane <= r) g.C[(long)r * g.ldc + lane] = A[r * LP + lane];
-		}
-		if (g.sa) {
-			// solve-ahead: publish L to the workgroups of tile column 0 (MI355X_MICROARCH.md, inter-workgroup visibility:
-			// every storing wave drains its stores, barrier, one lane releases at agent scope, then the flag)
+			for (int u = 0; u < 16; u++) {
+				const int r = wave + 4 * u;
+				if (lane <= r) g.C[(long)r * g.ldc + lane] = A[r * LP + lane];
+			}
+		} else {
+			// solve-ahead: L goes out by write-through (sc1) stores and is published to the workgroups of tile column 0
+			// by a flag (MI355X_MICROARCH.md, inter-workgroup visibility, the form without fences: every byte handed
+			// over is stored sc1, every storing wave drains its stores, barrier, one lane stores the flag; the readers
+			// load those bytes sc1).  An agent-scope release fence instead would write back every dirty line of this
+			// XCD's L2 -- the other tiles' output of this very update -- and cost more than the launch it saves.
+#pragma unroll
+			for (int u = 0; u < 16; u++) {
+				const int r = wave + 4 * u;
+				if (lane <= r) __hip_atomic_store(&g.C[(long)r * g.ldc + lane], A[r * LP + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			__syncthreads();
-			if (tid == 0) {
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-				__hip_atomic_store(g.sa_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			}
+			if (tid == 0) __hip_atomic_store(g.sa_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 		trace_end(g.trace, tr0);
 		return;
@@ -443,15 +448,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 				__builtin_amdgcn_s_sleep(8);
 				if (++spins > 400000L) { atomicMin(g.fa_info, -1); break; }       // (~0.3 s; never seen) reported as a device failure
 			}
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		}
 		__syncthreads();
 		{
-			const double *D = g.C;                                  // the diagonal block (tile (0,0)), L in its lower triangle
+			// L (lower triangle of the diagonal block, tile (0,0)) by sc1 loads; the strict upper part is scratch for the
+			// 16x16 inversions and is not read from memory
+			const double *D = g.C;
 			double v[16];
 #pragma unroll
-			for (int u = 0; u < 16; u++) v[u] = D[(long)(wave + 4 * u) * g.ldc + lane];
+			for (int u = 0; u < 16; u++) {
+				const int r = wave + 4 * u;
+				v[u] = (lane <= r) ? __hip_atomic_load(&D[(long)r * g.ldc + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+			}
 #pragma unroll
 			for (int u = 0; u < 16; u++) M[(wave + 4 * u) * LP + lane] = v[u];
 		}
