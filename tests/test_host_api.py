@@ -113,6 +113,28 @@ def test_host_logic_without_gpu(tmp_path):
     assert not np.allclose(dd[0], dd[0].T)               # path dependent: not even symmetric
 
 
+def test_device_slots_from_the_environment():
+    """GPEMU_DEVICES parsing and the slot -> device map of the host layer (device_bridge.c "devices"): host logic, no GPU"""
+    import sys
+    code = ("import ctypes as C, sys\n"
+            f"C.CDLL({build.HIP_LIB!r}, mode=C.RTLD_GLOBAL); L = C.CDLL({build.HOST_LIB!r})\n"
+            "n = L.gpemu_host_device_slots()\n"
+            "print(n, [L.gpemu_host_slot_device(i) for i in range(n + 2)], L.gpemu_host_device())\n"
+            "L.gpemu_host_thread_device(5); print(L.gpemu_host_device(), L.gpemu_host_thread_device_get())\n"
+            "L.gpemu_host_thread_device(-1); print(L.gpemu_host_device())\n")
+    build.build_all()
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GPEMU_DEVICES="3,1,1"), capture_output=True,
+                         text=True, timeout=60)
+    assert out.returncode == 0, out.stderr[-1000:]
+    lines = out.stdout.strip().splitlines()
+    assert lines[0] == "3 [3, 1, 1, 3, 1] 3"          # three slots, wrapping, slot 0 is the calling thread's default
+    assert lines[1] == "5 5" and lines[2] == "3"      # a thread working for a slot declares its device; -1: back to slot 0
+    env = dict(os.environ)
+    env.pop("GPEMU_DEVICES", None)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and int(out.stdout.split()[0]) >= 1      # every visible device, at least one slot
+
+
 G6SNAP = os.path.join(ROOT, "tests", "golden", "g6_multi_snapshot.txt")
 
 
