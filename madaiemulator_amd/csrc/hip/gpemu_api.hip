@@ -28,6 +28,7 @@ static int g_leaf128 = 0;                // 128-column fused leaves (env GPEMU_L
 static int g_lookahead = 0;              // two-stream schedule of the outer panels (env GPEMU_LOOKAHEAD=1); see DESIGN.md
 static int g_factor_ahead = 1;           // the update's tile (0,0) factors the next diagonal block (env GPEMU_FACTOR_AHEAD=0: off)
 static int g_solve_ahead = 1;            // one matrix per launch: tile column 0 of the update also solves its rows (env GPEMU_SOLVE_AHEAD=0: off)
+static int g_panel_trsm = 512;           // diag-first panels of up to this many columns + one panel_trsm pass (env GPEMU_PANEL_TRSM; 0: off)
 static int g_fill_gram = 1;              // MFMA Gram form of the training fill (env GPEMU_FILL_GRAM=0: difference form always)
 static int g_nb_top = 0;            // outer panel width (env GPEMU_NB_TOP); 0 = automatic: 512 for one matrix, 2048 for a lock-step batch
 constexpr int INFO_NONE = 0x7f7f7f7f;   // "no failed pivot": what hipMemsetAsync(.., 0x7f, ..) leaves in *info
@@ -142,6 +143,8 @@ static void read_environment()
 	g_fill_gram = geti("GPEMU_FILL_GRAM", 1) != 0;
 	g_factor_ahead = geti("GPEMU_FACTOR_AHEAD", 1) != 0;
 	g_solve_ahead = geti("GPEMU_SOLVE_AHEAD", 1) != 0;
+	v = geti("GPEMU_PANEL_TRSM", 512);
+	g_panel_trsm = (v >= 2 * LEAF && v <= 2048) ? (v / LEAF) * LEAF : 0;
 	v = geti("GPEMU_NB_TOP", 0);
 	g_nb_top = v >= LEAF ? (v / LEAF) * LEAF : 0;
 }
@@ -470,13 +473,14 @@ static int make_cov_params(gpemu_ctx *ctx, const double *thetas, int nthetas, Co
 // *fa_done (optional): set when the update ran with the factor-ahead tile, i.e. the 64x64 diagonal block at c0+k is
 // already factored when the update has finished and the next leaf must not factor it again
 static hipError_t trailing_update(gpemu_ctx *ctx, int c0, int k, int col_off, int ncols, int inv, hipStream_t stream = nullptr,
-                                  bool *fa_done = nullptr, bool *sa_done = nullptr)
+                                  bool *fa_done = nullptr, bool *sa_done = nullptr, int row_limit = INT_MAX)
 {
 	// C[rows >= r0, cols r0 .. r0+ncols) -= P P^T with P = the factored panel columns [c0, c0+k) and
 	// r0 = c0 + k + col_off (rows above r0 belong to the upper triangle of those columns)
 	const long ld = ctx->Np;
 	const int r0 = c0 + k + col_off;
-	const int row_end = ctx->Np + ctx->Rp + (inv ? c0 + k : 0);   // identity rows < c0+k have fill-in in the panel
+	const int row_end = std::min(ctx->Np + ctx->Rp + (inv ? c0 + k : 0), row_limit);   // identity rows < c0+k have fill-in in the panel
+	if (row_end <= r0) { if (fa_done) *fa_done = false; if (sa_done) *sa_done = false; return hipSuccess; }
 	GemmArgs g;
 	memset(&g, 0, sizeof g);
 	g.C = ctx->dT + (long)r0 * ld + r0;
@@ -522,12 +526,27 @@ static hipEvent_t next_event(gpemu_ctx *ctx)
 
 // diag_done: the 64x64 diagonal block at (c0,c0) is already factored (by the factor-ahead tile of the update before)
 // solve_done: the rows under that block are solved as well (solve-ahead tiles of the same update)
-static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv, bool diag_done = false, bool solve_done = false)
+// row_limit: rows at or beyond it are not touched (the diagonal-block phase of a diag-first panel)
+static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv, bool diag_done = false, bool solve_done = false,
+                            int row_limit = INT_MAX)
 {
 	const long ld = ctx->Np;
 	const int base_end = ctx->Np + ctx->Rp;
+	if (n > LEAF && n <= g_panel_trsm && row_limit == INT_MAX && !g_leaf128 && !(g_lookahead && ctx->stream2)) {
+		// Diag-first panel: factor the n x n diagonal block with the recursion below restricted to its own rows (small,
+		// cache-resident launches), then solve ALL rows under it against the whole block in one pass
+		// (panel_trsm_kernel: one read-modify-write of the panel instead of the recursion's log2(n/64) levels + n/64
+		// leaf solves over every row).  Same arithmetic in the same order per element: same bits.
+		hipError_t e = potrf_rec(ctx, c0, n, inv, diag_done, solve_done, c0 + n);
+		if (e != hipSuccess) return e;
+		const int row_end = base_end + (inv ? c0 + n : 0);
+		ProfScope ps(ctx, GPEMU_PROF_LEAF, 0.0, 0.0);
+		unsigned long long *tr = trace_slot(ctx, "panel_trsm c0=%d n=%d m=%d", c0, n, row_end - (c0 + n));
+		return launch_panel_trsm(ctx->stream, ctx->dT, ld, c0, n, (diag_done && solve_done) ? 1 : 0, c0 + n, row_end - (c0 + n),
+		                         ctx->nb, (long)ctx->T_stride, tr);
+	}
 	if (n <= LEAF) {
-		const int row_end = base_end + (inv ? c0 + LEAF : 0);
+		const int row_end = std::min(base_end + (inv ? c0 + LEAF : 0), row_limit);
 		ProfScope ps(ctx, GPEMU_PROF_LEAF, 0.0, 0.0);
 		unsigned long long *trf = trace_slot(ctx, "leaf_factor c0=%d", c0);
 		unsigned long long *trs = trace_slot(ctx, "leaf_solve c0=%d m=%d", c0, row_end - (c0 + LEAF));
@@ -557,13 +576,13 @@ static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv, bool diag_do
 		bool next_done = diag_done, next_solved = solve_done;
 		for (int c = c0; c < c0 + n; c += nb_top) {
 			const int nb = std::min(nb_top, c0 + n - c);
-			hipError_t e = potrf_rec(ctx, c, nb, inv, next_done, next_solved);
+			hipError_t e = potrf_rec(ctx, c, nb, inv, next_done, next_solved, row_limit);
 			next_done = false; next_solved = false;
 			if (e != hipSuccess) return e;
 			const int rest = c0 + n - (c + nb);
 			if (rest <= 0) continue;
 			if (!ahead) {
-				e = trailing_update(ctx, c, nb, 0, rest, inv, nullptr, &next_done, &next_solved);
+				e = trailing_update(ctx, c, nb, 0, rest, inv, nullptr, &next_done, &next_solved, row_limit);
 				if (e != hipSuccess) return e;
 				continue;
 			}
@@ -599,12 +618,12 @@ static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv, bool diag_do
 		return hipSuccess;
 	}
 	const int n1 = ((n / LEAF + 1) / 2) * LEAF;
-	hipError_t e = potrf_rec(ctx, c0, n1, inv, diag_done, solve_done);
+	hipError_t e = potrf_rec(ctx, c0, n1, inv, diag_done, solve_done, row_limit);
 	if (e != hipSuccess) return e;
 	bool right_done = false, right_solved = false;
-	e = trailing_update(ctx, c0, n1, 0, n - n1, inv, nullptr, &right_done, &right_solved);
+	e = trailing_update(ctx, c0, n1, 0, n - n1, inv, nullptr, &right_done, &right_solved, row_limit);
 	if (e != hipSuccess) return e;
-	return potrf_rec(ctx, c0 + n1, n - n1, inv, right_done, right_solved);
+	return potrf_rec(ctx, c0 + n1, n - n1, inv, right_done, right_solved, row_limit);
 }
 
 static int run_potrf(gpemu_ctx *ctx, int inv)

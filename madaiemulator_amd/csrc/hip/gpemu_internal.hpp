@@ -201,6 +201,8 @@ hipError_t launch_leaf(hipStream_t s, double *T, long ld, int c0, int m_below, i
                        unsigned long long *trace_factor = nullptr, unsigned long long *trace_solve = nullptr,
                        int nbatch = 1, long bstride = 0, bool skip_factor = false, bool skip_solve = false);
 bool gemm_factor_ahead_ok(const GemmArgs &a);
+hipError_t launch_panel_trsm(hipStream_t s, double *T, long ld, int c0, int n, int j0, int row0, int m, int nbatch, long bstride,
+                             unsigned long long *trace = nullptr);
 bool gemm_uses_big_tiles(const GemmArgs &a);
 hipError_t launch_leaf128(hipStream_t s, double *T, long ld, int c0, int m_below, int *info, double *dinv,
                           int nbatch = 1, long bstride = 0);

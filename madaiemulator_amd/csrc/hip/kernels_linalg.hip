@@ -1046,6 +1046,204 @@ __global__ __launch_bounds__(256) void leaf_solve_kernel(double *T, long ld, int
 }
 
 // ---------------------------------------------------------------------------
+// Panel solve X L^T = B against a whole factored n x n diagonal block (n = 128 ... 512, a multiple of 64) for the rows
+// below it: ONE read-modify-write of the panel.
+//
+// The recursion above would reach the same rows log2(n/64) times with updates of K = 64, 128, 256 (each level reads
+// half the panel and read-modify-writes the other half) and once per 64 columns with the leaf solve: 6.5 panel volumes
+// for n = 512, all of it from HBM when a lock-step batch of 16 sub-panels (16 x 29 MB) is in flight -- those launches
+// run at 4-7 TB/s, i.e. AT the HBM roofline, and at 21-52 TFLOP/s.  Here a workgroup owns 64 rows and walks the
+// n/64 column blocks itself:  X_j = (B_j - sum_{i<j} X_i L_ji^T) L_jj^-T.  B_j comes from HBM once and X_j goes back
+// once; the X_i it re-reads are its own earlier output (L2; read with sc1 loads so that a stale L1 copy of the line from
+// before the store cannot be served) and the L blocks are shared by every workgroup (L2 / Infinity Cache).
+//
+// The arithmetic is the recursion's, element for element: an update is the k-ordered chain of MFMA accumulations
+// that starts from the stored C value (gemm_nt_kernel), the recursion applies the levels to a block column in
+// ascending k, and the solve of a 64-column block is leaf_solve_kernel's.  So the bits do not change.
+// grid (rows/64, nbatch), 256 threads = 4 waves as 2x2 over a 64x64 tile, LDS 40 KB (4 workgroups per CU).
+// ---------------------------------------------------------------------------
+typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256, 3) void panel_trsm_kernel(double *T, long ld, int c0, int n, int j0, int row0, long bstride,
+                                                            unsigned long long *trace)
+{
+	constexpr int BM = 64, BN = 64, WM = 32, WN = 32, TM = 2, TN = 2, AIT = 2, BIT = 2;
+	__shared__ double smem[2 * (BM + BN) * LDS_S];
+	double (*As)[BM * LDS_S] = reinterpret_cast<double (*)[BM * LDS_S]>(smem);
+	double (*Bs)[BN * LDS_S] = reinterpret_cast<double (*)[BN * LDS_S]>(smem + 2 * BM * LDS_S);
+	T += (long)blockIdx.y * bstride;
+	const TraceT0 tr0 = trace_begin(trace);
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int wm = wave >> 1, wn = wave & 1;
+	const int q = lane & 15, gq = lane >> 4;
+	const long rbase = (long)row0 + 64L * blockIdx.x;             // this workgroup's 64 panel rows
+	double *P = T + rbase * ld + c0;                              // their first panel column
+	// A operand = this workgroup's own rows (X_i, written by this very workgroup): 16-byte sc1 buffer loads
+	const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(P, 0, -1, 0x00020000);
+	unsigned a_off[AIT];
+	int lofs[AIT];
+#pragma unroll
+	for (int it = 0; it < AIT; it++) {
+		const int idx = tid + 256 * it, row = idx >> 3, seg = idx & 7;
+		a_off[it] = (unsigned)((long)row * ld * 8 + 16 * seg);
+		lofs[it] = row * LDS_S + 2 * seg;
+	}
+	const int a_base = (wm * WM + q) * LDS_S + 2 * gq;
+	const int b_base = (wn * WN + q) * LDS_S + 2 * gq;
+	const int nblk = n / 64;
+#pragma unroll 1
+	for (int j = j0; j < nblk; j++) {        // (blocks < j0 were solved by the solve-ahead tiles of the update before)
+		// (the per-row addresses of this iteration are derived from bases the compiler cannot see through: hoisted out
+		// of the j loop as loop invariants they cost ~60 VGPRs of 64-bit row pointers and the kernel spilled)
+		double *Pj = P + 64 * j;
+		const double *Lj = T + (long)(c0 + 64 * j) * ld + c0;         // row 64j of L, first panel column
+		long ldj = ld;
+		asm volatile("" : "+s"(Pj), "+s"(Lj), "+s"(ldj));
+		// accumulators start from -B_j (the update is C -= A B^T: alpha = -1, the chain runs on C / alpha)
+		d4_t acc[TM][TN];
+		{
+			// (row pointers by successive additions of a scalar stride: nothing for the compiler to pre-compute per row)
+			const double *crow = Pj + (long)(wm * WM + gq) * ldj + wn * WN + q;
+#pragma unroll
+			for (int i = 0; i < TM; i++)
+#pragma unroll
+				for (int r = 0; r < 4; r++) {
+#pragma unroll
+					for (int jj = 0; jj < TN; jj++) acc[i][jj][r] = -1.0 * crow[jj * 16];
+					crow += (r == 3) ? 4 * ldj : 4 * ldj;
+				}
+		}
+		const int ke = 64 * j;
+		if (ke > 0) {
+			// B operand = rows 64j .. 64j+63 of L (the diagonal block's own rows), columns [0, 64j)
+			const double *bg[BIT];
+			bg[0] = Lj + (long)(tid >> 3) * ldj + 2 * (tid & 7);
+			bg[1] = bg[0] + 32 * ldj;
+#define TRSM_LOAD(RA, RB, kk)                                                                                      \
+			do {                                                                                                   \
+				_Pragma("unroll") for (int it = 0; it < AIT; it++) {                                                \
+					const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[it], (kk) * 8, 16 /* sc1 */); \
+					RA[it] = __builtin_bit_cast(d2_t, v);                                                           \
+				}                                                                                                  \
+				_Pragma("unroll") for (int it = 0; it < BIT; it++) RB[it] = *reinterpret_cast<const d2_t *>(bg[it] + (kk)); \
+			} while (0)
+#define TRSM_STORE(RA, RB, buf)                                                                                    \
+			do {                                                                                                   \
+				_Pragma("unroll") for (int it = 0; it < AIT; it++) *reinterpret_cast<d2_t *>(&As[buf][lofs[it]]) = RA[it]; \
+				_Pragma("unroll") for (int it = 0; it < BIT; it++) *reinterpret_cast<d2_t *>(&Bs[buf][lofs[it]]) = RB[it]; \
+			} while (0)
+#define TRSM_STEP(buf)                                                                                             \
+			do {                                                                                                   \
+				const double *as = As[buf];                                                                        \
+				const double *bs = Bs[buf];                                                                        \
+				_Pragma("unroll") for (int t = 0; t < GEMM_BK / 8; t++) {                                           \
+					d2_t a[TM], b[TN];                                                                             \
+					_Pragma("unroll") for (int i = 0; i < TM; i++)                                                  \
+						a[i] = *reinterpret_cast<const d2_t *>(&as[a_base + i * 16 * LDS_S + 8 * t]);               \
+					_Pragma("unroll") for (int jj = 0; jj < TN; jj++)                                               \
+						b[jj] = *reinterpret_cast<const d2_t *>(&bs[b_base + jj * 16 * LDS_S + 8 * t]);             \
+					_Pragma("unroll") for (int h = 0; h < 2; h++)                                                   \
+						_Pragma("unroll") for (int i = 0; i < TM; i++)                                              \
+							_Pragma("unroll") for (int jj = 0; jj < TN; jj++)                                       \
+								acc[i][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][h], b[jj][h], acc[i][jj], 0, 0, 0); \
+				}                                                                                                  \
+			} while (0)
+			d2_t r0a[AIT], r0b[BIT], r1a[AIT], r1b[BIT];
+			TRSM_LOAD(r0a, r0b, 0);
+			if (GEMM_BK < ke) TRSM_LOAD(r1a, r1b, GEMM_BK);
+			TRSM_STORE(r0a, r0b, 0);
+			__syncthreads();
+			int cur = 0;
+#pragma unroll 1
+			for (int k = 0; k < ke; k += 2 * GEMM_BK) {
+				if (k + 2 * GEMM_BK < ke) TRSM_LOAD(r0a, r0b, k + 2 * GEMM_BK);
+				TRSM_STEP(cur);
+				if (k + GEMM_BK < ke) TRSM_STORE(r1a, r1b, cur ^ 1);
+				__syncthreads();
+				cur ^= 1;
+				if (k + GEMM_BK >= ke) break;
+				if (k + 3 * GEMM_BK < ke) TRSM_LOAD(r1a, r1b, k + 3 * GEMM_BK);
+				TRSM_STEP(cur);
+				if (k + 2 * GEMM_BK < ke) TRSM_STORE(r0a, r0b, cur ^ 1);
+				__syncthreads();
+				cur ^= 1;
+			}
+#undef TRSM_LOAD
+#undef TRSM_STORE
+#undef TRSM_STEP
+		}
+		// the updated B_j -> LDS (what the update would have stored: alpha * acc), then leaf_solve_kernel's solve
+		double *M = smem;
+#pragma unroll
+		for (int i = 0; i < TM; i++)
+#pragma unroll
+			for (int r = 0; r < 4; r++)
+#pragma unroll
+				for (int jj = 0; jj < TN; jj++)
+					M[(wm * WM + i * 16 + gq + 4 * r) * LP + wn * WN + jj * 16 + q] = -1.0 * acc[i][jj][r];
+		__syncthreads();
+		d4_t R[4];
+#pragma unroll
+		for (int jj = 0; jj < 4; jj++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) R[jj][r] = M[(16 * wave + q) * LP + 16 * jj + gq + 4 * r];
+		__syncthreads();
+		{
+			const double *D = Lj + 64 * j;                                    // L_jj
+			double v[16];
+			const double *dp = D + (long)wave * ldj + lane;
+#pragma unroll
+			for (int u = 0; u < 16; u++) { v[u] = *dp; dp += 4 * ldj; }
+#pragma unroll
+			for (int u = 0; u < 16; u++) M[(wave + 4 * u) * LP + lane] = v[u];
+		}
+		__syncthreads();
+		{
+			const int sr = (wave == 3) ? 0 : wave, sc = (wave == 3) ? 3 : wave + 1;
+			tri_inverse16(M, 16 * wave, M + 16 * sr * LP + 16 * sc, lane);
+		}
+		__syncthreads();
+		double *bp = Pj + (long)(16 * wave + q) * ldj;
+		d4_t X[4];
+#pragma unroll
+		for (int jj = 0; jj < 4; jj++) {
+			d4_t a4 = R[jj];
+#pragma unroll
+			for (int i = 0; i < jj; i++)
+#pragma unroll
+				for (int r = 0; r < 4; r++) {
+					const double a = -M[(16 * jj + q) * LP + 16 * i + gq + 4 * r];
+					a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[i][r], a4, 0, 0, 0);
+				}
+			d4_t xj = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+			for (int r = 0; r < 4; r++) {
+				const double a = M[(16 * jj + q) * LP + 16 * jj + gq + 4 * r];
+				xj = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a4[r], xj, 0, 0, 0);
+			}
+			X[jj] = xj;
+#pragma unroll
+			for (int r = 0; r < 4; r++) bp[16 * jj + gq + 4 * r] = xj[r];
+		}
+		// X_j must have reached the L2 before any wave of this workgroup loads it as an A operand (and the LDS is reused)
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+	}
+	trace_end(trace, tr0);
+}
+
+// rows [row0, row0 + m) of the panel columns [c0, c0 + n): m a multiple of 64, n a multiple of 64
+hipError_t launch_panel_trsm(hipStream_t s, double *T, long ld, int c0, int n, int j0, int row0, int m, int nbatch, long bstride,
+                             unsigned long long *trace)
+{
+	if (m <= 0 || j0 >= n / 64) return hipSuccess;
+	if (m % 64 || n % 64 || n < 64 || (long)64 * ld * 8 + 16 * 8 > 0x7fffffffL) return hipErrorInvalidValue;
+	if (nbatch < 1) nbatch = 1;
+	hipLaunchKernelGGL(panel_trsm_kernel, dim3(m / 64, nbatch), dim3(256), 0, s, T, ld, c0, n, j0, row0, bstride, trace);
+	return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // 128-column leaf: the same two steps on a 128x128 diagonal block, one launch each instead of five
 // (factor, solve, K=64 update, factor, solve on 64-column halves) -- the chain of small dependent
 // kernels is the critical path of the factorisation, so fewer, fatter links win.

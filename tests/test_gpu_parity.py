@@ -859,7 +859,7 @@ def test_chol_inverse_and_symm_apply_on_host_matrices(gpu_ctx, n):
 
 
 @pytest.mark.parametrize("env", [{"GPEMU_LEAF128": "1"}, {"GPEMU_LOOKAHEAD": "1"}, {"GPEMU_NO_GRAPH": "1"}, {"GPEMU_FACTOR_AHEAD": "0"},
-                                 {"GPEMU_SOLVE_AHEAD": "0"}, {"GPEMU_FILL_GRAM": "0"},
+                                 {"GPEMU_SOLVE_AHEAD": "0"}, {"GPEMU_PANEL_TRSM": "0"}, {"GPEMU_PANEL_TRSM": "256"}, {"GPEMU_FILL_GRAM": "0"},
                                  {"GPEMU_NB_TOP": "256"}, {"GPEMU_NB_TOP": "2048"}, {"GPEMU_GEMM_BIG_CFG": "0", "GPEMU_GEMM_BIG_TILES": "1"},
                                  {"GPEMU_GEMM_BIG_TILES": "1"}, {"GPEMU_GEMM_BIG_TILES": "1000000"}])
 def test_schedule_switches_keep_parity(monkeypatch, env):
@@ -888,8 +888,9 @@ def test_schedule_switches_keep_parity(monkeypatch, env):
     assert got[0]["sigma2"] == pytest.approx(base[0]["sigma2"], rel=1e-10)
     assert np.allclose(got[2]["value"], base[2]["value"], rtol=1e-11, atol=0)
     assert np.allclose(got[4]["grad"], base[4]["grad"], rtol=1e-8, atol=1e-9 * np.max(np.abs(base[4]["grad"])))
-    if "GPEMU_FACTOR_AHEAD" in env or "GPEMU_SOLVE_AHEAD" in env:
-        # the factor-ahead / solve-ahead tiles run the update's and the leaf's own arithmetic: not a single bit moves
+    if "GPEMU_FACTOR_AHEAD" in env or "GPEMU_SOLVE_AHEAD" in env or "GPEMU_PANEL_TRSM" in env:
+        # the factor-ahead / solve-ahead tiles and the one-pass panel solve run the update's and the leaf's own
+        # arithmetic in the same order per element: not a single bit moves
         assert got[0]["value"] == base[0]["value"] and np.array_equal(got[2]["value"], base[2]["value"])
         assert np.array_equal(got[2]["beta"], base[2]["beta"]) and np.array_equal(got[4]["grad"], base[4]["grad"])
     e = O.Emulator(1, 1, X, y, th)
