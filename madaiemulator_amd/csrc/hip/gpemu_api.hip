@@ -27,7 +27,8 @@ using namespace gpemu;
 static int g_leaf128 = 0;                // 128-column fused leaves (env GPEMU_LEAF128=1); measured 3 % slower than 64
 static int g_lookahead = 0;              // two-stream schedule of the outer panels (env GPEMU_LOOKAHEAD=1); see DESIGN.md
 static int g_factor_ahead = 1;           // the update's tile (0,0) factors the next diagonal block (env GPEMU_FACTOR_AHEAD=0: off)
-static int g_solve_ahead = 1;            // one matrix per launch: tile column 0 of the update also solves its rows (env GPEMU_SOLVE_AHEAD=0: off)
+static int g_solve_ahead = 0;            // one matrix per launch: tile column 0 of the update also solves its rows (env GPEMU_SOLVE_AHEAD=1: on;
+                                         // off by default: it is the one place where workgroups wait for each other, and it buys 3 %)
 static int g_panel_trsm = 512;           // diag-first panels of up to this many columns + one panel_trsm pass (env GPEMU_PANEL_TRSM; 0: off)
 static int g_fill_gram = 1;              // MFMA Gram form of the training fill (env GPEMU_FILL_GRAM=0: difference form always)
 static int g_nb_top = 0;            // outer panel width (env GPEMU_NB_TOP); 0 = automatic: 512 for one matrix, 2048 for a lock-step batch
@@ -142,7 +143,7 @@ static void read_environment()
 	g_leaf128 = geti("GPEMU_LEAF128", 0) != 0;
 	g_fill_gram = geti("GPEMU_FILL_GRAM", 1) != 0;
 	g_factor_ahead = geti("GPEMU_FACTOR_AHEAD", 1) != 0;
-	g_solve_ahead = geti("GPEMU_SOLVE_AHEAD", 1) != 0;
+	g_solve_ahead = geti("GPEMU_SOLVE_AHEAD", 0) != 0;
 	v = geti("GPEMU_PANEL_TRSM", 512);
 	g_panel_trsm = (v >= 2 * LEAF && v <= 2048) ? (v / LEAF) * LEAF : 0;
 	v = geti("GPEMU_NB_TOP", 0);
@@ -495,7 +496,7 @@ static hipError_t trailing_update(gpemu_ctx *ctx, int c0, int k, int col_off, in
 	g.nbatch = ctx->nb; g.bsC = g.bsA = g.bsB = (long)ctx->T_stride;
 	if (fa_done) {
 		*fa_done = false;
-		g.fa = (g_factor_ahead && !g_leaf128 && col_off == 0 && !stream) ? 1 : 0;
+		g.fa = (g_factor_ahead && !g_leaf128 && !g_lookahead && col_off == 0 && !stream) ? 1 : 0;
 		g.fa_c0 = r0;
 		g.fa_info = ctx->dInfo;
 		if (g.fa && gemm_factor_ahead_ok(g)) *fa_done = true;

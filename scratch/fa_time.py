@@ -7,7 +7,7 @@ N, d, B = 8192, 8, 16
 X, y = synth.design(N, d, 5)
 ths = np.array([synth.perturbed_thetas(3, d, 7, i) for i in range(B)])
 for rnd in range(2):
-    for fa, sa, pt in (("1", "1", "512"), ("1", "1", "256"), ("1", "1", "0"), ("0", "0", "0")):
+    for fa, sa, pt in (("1", "0", "512"), ("1", "1", "512"), ("1", "0", "256"), ("1", "0", "0"), ("0", "0", "0")):
         os.environ["GPEMU_FACTOR_AHEAD"] = fa
         os.environ["GPEMU_SOLVE_AHEAD"] = sa
         os.environ["GPEMU_PANEL_TRSM"] = pt
