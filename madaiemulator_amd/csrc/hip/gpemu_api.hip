@@ -29,7 +29,8 @@ static int g_lookahead = 0;              // two-stream schedule of the outer pan
 static int g_factor_ahead = 1;           // the update's tile (0,0) factors the next diagonal block (env GPEMU_FACTOR_AHEAD=0: off)
 static int g_solve_ahead = 0;            // one matrix per launch: tile column 0 of the update also solves its rows (env GPEMU_SOLVE_AHEAD=1: on;
                                          // off by default: it is the one place where workgroups wait for each other, and it buys 3 %)
-static int g_panel_trsm = 512;           // diag-first panels of up to this many columns + one panel_trsm pass (env GPEMU_PANEL_TRSM; 0: off)
+static int g_panel_trsm = 0;             // diag-first panels of up to this many columns + one panel_trsm pass (env GPEMU_PANEL_TRSM=512;
+                                         // 0 = off, the default: bit-identical and measured slower)
 static int g_fill_gram = 1;              // MFMA Gram form of the training fill (env GPEMU_FILL_GRAM=0: difference form always)
 static int g_nb_top = 0;            // outer panel width (env GPEMU_NB_TOP); 0 = automatic: 512 for one matrix, 2048 for a lock-step batch
 constexpr int INFO_NONE = 0x7f7f7f7f;   // "no failed pivot": what hipMemsetAsync(.., 0x7f, ..) leaves in *info
@@ -144,7 +145,7 @@ static void read_environment()
 	g_fill_gram = geti("GPEMU_FILL_GRAM", 1) != 0;
 	g_factor_ahead = geti("GPEMU_FACTOR_AHEAD", 1) != 0;
 	g_solve_ahead = geti("GPEMU_SOLVE_AHEAD", 0) != 0;
-	v = geti("GPEMU_PANEL_TRSM", 512);
+	v = geti("GPEMU_PANEL_TRSM", 0);
 	g_panel_trsm = (v >= 2 * LEAF && v <= 2048) ? (v / LEAF) * LEAF : 0;
 	v = geti("GPEMU_NB_TOP", 0);
 	g_nb_top = v >= LEAF ? (v / LEAF) * LEAF : 0;

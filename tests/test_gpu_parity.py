@@ -859,7 +859,7 @@ def test_chol_inverse_and_symm_apply_on_host_matrices(gpu_ctx, n):
 
 
 @pytest.mark.parametrize("env", [{"GPEMU_LEAF128": "1"}, {"GPEMU_LOOKAHEAD": "1"}, {"GPEMU_NO_GRAPH": "1"}, {"GPEMU_FACTOR_AHEAD": "0"},
-                                 {"GPEMU_SOLVE_AHEAD": "1"}, {"GPEMU_PANEL_TRSM": "0"}, {"GPEMU_PANEL_TRSM": "256"}, {"GPEMU_FILL_GRAM": "0"},
+                                 {"GPEMU_SOLVE_AHEAD": "1"}, {"GPEMU_PANEL_TRSM": "512"}, {"GPEMU_PANEL_TRSM": "256"}, {"GPEMU_FILL_GRAM": "0"},
                                  {"GPEMU_NB_TOP": "256"}, {"GPEMU_NB_TOP": "2048"}, {"GPEMU_GEMM_BIG_CFG": "0", "GPEMU_GEMM_BIG_TILES": "1"},
                                  {"GPEMU_GEMM_BIG_TILES": "1"}, {"GPEMU_GEMM_BIG_TILES": "1000000"}])
 def test_schedule_switches_keep_parity(monkeypatch, env):
