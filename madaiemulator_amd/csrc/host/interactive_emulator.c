@@ -225,6 +225,8 @@ static struct cmdLineOpts *global_opt_parse(int argc, char **argv)
 		{"regression_order", required_argument, NULL, 'r'}, {"covariance_fn", required_argument, NULL, 'c'},
 		{"pca_variance", required_argument, NULL, 'v'},      {"pca_output", no_argument, NULL, 'z'},
 		{"quiet", no_argument, NULL, 'q'},                    {"help", no_argument, NULL, 'h'},
+		/* not in the reference: the corrected forms of gpemu.h (same as GPEMU_EXACT_GRAD=1 / GPEMU_MATERN_FIXED=1) */
+		{"exact_gradient", no_argument, NULL, 1001},          {"matern_fixed", no_argument, NULL, 1002},
 		{NULL, no_argument, NULL, 0}};
 	struct cmdLineOpts *o = (struct cmdLineOpts *)calloc(1, sizeof *o);
 	o->pca_variance = 0.99;
@@ -244,6 +246,8 @@ static struct cmdLineOpts *global_opt_parse(int argc, char **argv)
 			/* fall through (as the reference does) */
 		case 'z': o->pcaOutputFlag = 1; /* fall through */
 		case 'q': o->quietFlag = 1; break;
+		case 1001: setenv("GPEMU_EXACT_GRAD", "1", 1); break;
+		case 1002: setenv("GPEMU_MATERN_FIXED", "1", 1); break;
 		case 'h':
 		case '?': exit(perr(useage));
 		default: break;

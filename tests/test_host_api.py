@@ -284,6 +284,47 @@ def test_cli_train_snapshot_predict_end_to_end(driver, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_trains_a_matern_model_with_the_corrected_forms(driver, tmp_path):
+    """The reference cannot train a Matern model (amplitude zeroed and read raw -> C = theta_1 I -> exit).
+    With --matern_fixed --exact_gradient the CLI trains test/uni-simple with the Matern 5/2 kernel; the snapshot holds
+    log-scale amplitude and nugget, and interactive_mode --matern_fixed predicts from it what the oracle's literal
+    kernel predicts at (e^theta0, e^theta1, theta2)."""
+    cli = build.CLI_BIN
+    snap = tmp_path / "matern_snapshot"
+    env = dict(os.environ, GPEMU_SEED="31", GPEMU_RESTARTS="4")
+    run([cli, "estimate_thetas", UNI, str(snap), "--regression_order=1", "--covariance_fn=3", "--matern_fixed",
+         "--exact_gradient"], env=env)
+    toks = snap.read_text().split()
+    nt, nr, d, N, cov, order = (int(t) for t in toks[:6])
+    assert (nt, nr, d, N, cov, order) == (1, 1, 1, 34, 3, 1)
+    pos = 6 + N * d + N * nt + nr + nt * nr + N * nr
+    nthetas = int(toks[pos])
+    blk = pos + 10 + 2 * nthetas + N * d
+    z = np.array(toks[blk:blk + N], float)
+    thetas = np.array(toks[blk + N:blk + N + nthetas], float)
+    assert nthetas == 3 and np.all(np.isfinite(thetas)) and np.any(thetas != 0.0)
+    X, Y = synth.read_input_model_file(UNI)
+    qpath = os.path.join(INP, "uni-simple.sample_locations.dat")
+    out = run([cli, "interactive_mode", str(snap), "-q", "--matern_fixed"], stdin=open(qpath))
+    vals = np.array(out.split(), float).reshape(-1, 2)
+    Q = np.array(open(qpath).read().split(), float).reshape(-1, 1)
+    th_raw = np.array([np.exp(thetas[0]), np.exp(thetas[1]), thetas[2]])
+    e = O.Emulator(3, 1, X, z, th_raw)
+    m, v, _ = e.emulate(Q)
+    lam = float(toks[6 + N * d + N * nt])
+    u = float(toks[6 + N * d + N * nt + nr])
+    mean = Y[:, 0].mean() + u * np.sqrt(lam) * m
+    var = u * u * lam * v
+    assert np.max(np.abs(vals[:, 0] - mean)) < 1e-7 * max(1.0, np.abs(mean).max())
+    assert np.max(np.abs(vals[:, 1] - var)) < 1e-7 * max(1e-3, np.abs(var).max())
+    # the trained emulator reproduces the training outputs (nugget-level error)
+    out2 = run([cli, "interactive_mode", str(snap), "-q", "--matern_fixed"],
+               input="\n".join(repr(float(x)) for x in X[:5, 0]) + "\n")
+    got = np.array(out2.split(), float).reshape(-1, 2)
+    assert np.max(np.abs(got[:, 0] - Y[:5, 0])) < 0.05
+
+
+@pytest.mark.gpu
 def test_training_in_lockstep_group_matches_per_thread_scheme(driver, tmp_path):
     """estimate_thetas_threaded: the restarts as a lock-step group (their likelihood/gradient requests batched on the
     device) find the same optimum as one sequential BFGS run after the other, and its value agrees with the oracle.
