@@ -135,9 +135,9 @@ extern "C" int gpemu_device_count(void)
 static void read_environment()
 {
 	auto geti = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
-	int v = geti("GPEMU_GEMM_BIG_TILES", 2048);
-	gpemu::g_gemm_big_tiles = v > 0 ? v : 2048;
-	gpemu::g_gemm_big_cfg = geti("GPEMU_GEMM_BIG_CFG", 3);
+	int v = geti("GPEMU_GEMM_BIG_TILES", 1024);
+	gpemu::g_gemm_big_tiles = v > 0 ? v : 1024;
+	gpemu::g_gemm_big_cfg = geti("GPEMU_GEMM_BIG_CFG", 8);
 	v = geti("GPEMU_GEMM_TABLE", 8);
 	gpemu::g_gemm_table = v >= 0 && v <= 64 ? v : 8;
 	g_lookahead = geti("GPEMU_LOOKAHEAD", 0) != 0;

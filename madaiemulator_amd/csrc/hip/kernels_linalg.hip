@@ -84,13 +84,21 @@ __device__ __forceinline__ void tri_inverse16(double *M, int o, double *tile, in
 // (the leaf_factor_kernel code) and writes L.  The 64 sequential pivots of that block then run beside the other tiles
 // of the update instead of in a launch of their own behind it (one launch and ~10 us less on the critical chain per
 // 64 columns); the arithmetic is the update's and the leaf's, so the bits do not change.
-template <int BM, int BN, int MINW, int WGM = 2, int WGN = 2, int PF = 1, int L2PF = 0, int FA = 0>
+// DMA = 1 (128x128 tiles, 8 waves): the operand chunks go global -> LDS directly (buffer_load ... lds, 1 KB per
+// wave-instruction, no staging registers, no ds_write pass) into an unpadded image whose 16-byte slots are XOR-swizzled
+// through the SOURCE address (the destination of an LDS-DMA is lane-linear); the 40 VGPRs this frees hold a second set
+// of MFMA fragments, so the LDS reads of one half k-step are issued a whole block of 16 MFMAs before their use, and the
+// one barrier of a k-step sits between the two blocks: after it the next chunk's DMA starts (a full k-step to land) and
+// the first fragments of the next chunk are read under the second block.  Same MFMA sequence per accumulator as the
+// register-staged loop: the bits do not change.
+template <int BM, int BN, int MINW, int WGM = 2, int WGN = 2, int PF = 1, int L2PF = 0, int FA = 0, int DMA = 0>
 __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs g)
 {
 	constexpr int NT = 64 * WGM * WGN;              // threads: WGM x WGN waves
 	constexpr int WM = BM / WGM, WN = BN / WGN;
 	constexpr int TM = WM / 16, TN = WN / 16;
 	constexpr int AIT = BM * 8 / NT, BIT = BN * 8 / NT;
+	constexpr int NPA = BM / 64, NPB = BN / 64;      // LDS-DMA pieces per wave (DMA = 1)
 	constexpr int SMEM_GEMM = 2 * (BM + BN) * LDS_S;
 	constexpr int SMEM = (FA && LEAF * LP > SMEM_GEMM) ? LEAF * LP : SMEM_GEMM;
 	__shared__ double smem[SMEM];
@@ -277,6 +285,96 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 						acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][h], b[j][h], acc[i][j], 0, 0, 0);    \
 		}                                                                                                         \
 	} while (0)
+	if (DMA) {
+		static_assert(!DMA || (BM % 64 == 0 && BN % 64 == 0 && WGM * WGN == 8 && GEMM_BK == 16 && WM % 16 == 0 && WN % 16 == 0),
+		              "LDS-DMA loop: 8 waves, 16-deep chunks, 64-row pieces");
+		if (kb < ke) {
+			// LDS image (bytes): buffer b at b * BUFB; operand row R (A rows 0..BM-1, then the B rows) at R * 128; its 16-byte
+			// segment s (doubles 2s, 2s+1 of the chunk) in slot s ^ f(R), f(R) = (R & 7) ^ ((R >> 3) & 1): the 16 rows a
+			// ds_read_b128 fragment read touches per lane group then fall into 16 different slots modulo 256 bytes (and the 8
+			// rows of either half into 8 different slots modulo 128 bytes)
+			constexpr int BUFB = (BM + BN) * GEMM_BK * 8;
+			char *lds = reinterpret_cast<char *>(smem);
+			// DMA pieces: wave w moves rows 64 p + 8 w .. + 7 of the image for p = 0 .. NPA+NPB-1 (the first NPA: A rows),
+			// lane l -> row + (l >> 3), slot l & 7
+			const int uw = __builtin_amdgcn_readfirstlane(wave);
+			const int prow = 8 * uw + (lane >> 3);
+			const int pseg = (lane & 7) ^ ((prow & 7) ^ ((prow >> 3) & 1));
+			int ra0 = tm * BM; if (ra0 > g.m - 1) ra0 = g.m - 1;
+			int rb0 = tn * BN; if (rb0 > g.n - 1) rb0 = g.n - 1;
+			const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(g.A + (long)ra0 * g.lda), 0, -1, 0x00020000);
+			const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(g.B + (long)rb0 * g.ldb), 0, -1, 0x00020000);
+			unsigned vo[8];                                   // (a size that depends on the template arguments loses the host stubs with this hipcc)
+#pragma unroll
+			for (int p = 0; p < NPA; p++) {
+				int ar = tm * BM + 64 * p + prow; if (ar > g.m - 1) ar = g.m - 1;
+				vo[p] = (unsigned)((long)(ar - ra0) * g.lda * 8 + 16 * pseg);
+			}
+#pragma unroll
+			for (int p = 0; p < NPB; p++) {
+				int br = tn * BN + 64 * p + prow; if (br > g.n - 1) br = g.n - 1;
+				vo[NPA + p] = (unsigned)((long)(br - rb0) * g.ldb * 8 + 16 * pseg);
+			}
+			typedef __attribute__((address_space(3))) void *lds_ptr_t;
+#define GEMM_DMA1(rs, d, p, kk) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)((d) + 8192 * (p)), 16, vo[p], (kk) * 8, 0, 0)
+#define GEMM_DMA(buf, kk)                                                                                         \
+			do {                                                                                                      \
+				char *d = lds + (buf) * BUFB + uw * 1024;                                                              \
+				GEMM_DMA1(rsA, d, 0, kk);                                                                              \
+				if constexpr (NPA > 1) GEMM_DMA1(rsA, d, 1, kk);                                                       \
+				if constexpr (NPA > 2) GEMM_DMA1(rsA, d, 2, kk);                                                       \
+				if constexpr (NPA > 3) GEMM_DMA1(rsA, d, 3, kk);                                                       \
+				GEMM_DMA1(rsB, d, NPA, kk);                                                                            \
+				if constexpr (NPB > 1) GEMM_DMA1(rsB, d, NPA + 1, kk);                                                 \
+				if constexpr (NPB > 2) GEMM_DMA1(rsB, d, NPA + 2, kk);                                                 \
+				if constexpr (NPB > 3) GEMM_DMA1(rsB, d, NPA + 3, kk);                                                 \
+			} while (0)
+			// fragment addresses: lane (q, gq) reads row q of its 16-row group, logical segment 4 t + gq
+			const int q = lane & 15, gq = lane >> 4;
+			const int fsw = (q & 7) ^ (q >> 3);
+			const int fa0 = (wm * WM + q) * 128 + 16 * (gq ^ fsw);
+			const int fb0 = (BM + wn * WN + q) * 128 + 16 * (gq ^ fsw);
+#define GEMM_FRAGS(FA_, FB_, buf, t)                                                                              \
+			do {                                                                                                      \
+				const char *pa = lds + (buf) * BUFB + (fa0 ^ (64 * (t)));                                              \
+				const char *pb = lds + (buf) * BUFB + (fb0 ^ (64 * (t)));                                              \
+				_Pragma("unroll") for (int i = 0; i < TM; i++) FA_[i] = *reinterpret_cast<const d2_t *>(pa + i * 2048); \
+				_Pragma("unroll") for (int j = 0; j < TN; j++) FB_[j] = *reinterpret_cast<const d2_t *>(pb + j * 2048); \
+			} while (0)
+#define GEMM_BLOCK(FA_, FB_)                                                                                      \
+			do {                                                                                                      \
+				_Pragma("unroll") for (int h = 0; h < 2; h++)                                                          \
+					_Pragma("unroll") for (int i = 0; i < TM; i++)                                                     \
+						_Pragma("unroll") for (int j = 0; j < TN; j++)                                                 \
+							acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA_[i][h], FB_[j][h], acc[i][j], 0, 0, 0); \
+			} while (0)
+			d2_t xa[TM], xb[TN], ya[TM], yb[TN];
+			GEMM_DMA(0, kb);
+			__syncthreads();
+			if (kb + GEMM_BK < ke) GEMM_DMA(1, kb + GEMM_BK);
+			GEMM_FRAGS(xa, xb, 0, 0);
+			if (g.trace && tr0.wall) atomicAdd(g.trace + 5, (unsigned long long)clock64() - tr0.clk);   // prologue
+			int cur = 0;
+			for (int k = kb; k < ke; k += GEMM_BK) {
+				GEMM_FRAGS(ya, yb, cur, 1);
+				__builtin_amdgcn_sched_barrier(0);
+				GEMM_BLOCK(xa, xb);
+				__builtin_amdgcn_sched_barrier(0);
+				// chunk k+1 (requested a k-step ago) has landed for every wave; every wave has read the last of chunk k
+				__syncthreads();
+				if (k + 2 * GEMM_BK < ke) GEMM_DMA(cur, k + 2 * GEMM_BK);
+				if (k + GEMM_BK < ke) GEMM_FRAGS(xa, xb, cur ^ 1, 0);
+				__builtin_amdgcn_sched_barrier(0);
+				GEMM_BLOCK(ya, yb);
+				__builtin_amdgcn_sched_barrier(0);
+				cur ^= 1;
+			}
+#undef GEMM_DMA
+#undef GEMM_DMA1
+#undef GEMM_FRAGS
+#undef GEMM_BLOCK
+		}
+	} else
 	if (PF == 2 && kb < ke) {
 		d2_t r0a[AIT], r0b[BIT], r1a[AIT], r1b[BIT];
 		GEMM_LOAD(r0a, r0b, kb);
@@ -621,13 +719,13 @@ int g_gemm_force_cfg = -1;   // test/bench hook: 0 = 128x128, 1 = 128x64, 2 = 64
 // 64x64 shape is never slower (more workgroups for 256 CUs, 4 resident per CU) and up to 3x faster on the
 // narrow K<=256 updates of the factorisation.
 int g_gemm_table = 8;          // XCD-blocked tile order from a table for launches of >= 512 tiles: side of the super-blocks (GPEMU_GEMM_TABLE; 0: off)
-int g_gemm_big_cfg = 3;        // tile configuration of the big launches (3: 128x128 8 waves, 0: 128x128 4 waves)
-int g_gemm_big_tiles = 2048;   // 128x128 tiles (8 waves) once a launch has this many of them, else 64x64
+int g_gemm_big_cfg = 8;        // tile configuration of the big launches (8: 128x128 8 waves by LDS-DMA, 3: the same tiles register-staged, 0: 4 waves)
+int g_gemm_big_tiles = 1024;   // 128x128 tiles (8 waves) once a launch has this many of them, else 64x64 (2048 with the register-staged tiles of configuration 3)
 
 bool gemm_uses_big_tiles(const GemmArgs &a)
 {
 	int choose_gemm_cfg(const GemmArgs &a);
-	return choose_gemm_cfg(a) == 3;
+	return choose_gemm_cfg(a) != 2;
 }
 
 // would launch_gemm run this update with the factor-ahead tile?  (the caller then skips the next leaf factorisation)
@@ -724,8 +822,9 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs &a_in)
 	if (!a.fa || nbatch > 1 || !a.sa_flag) a.sa = 0;
 	// tile shapes: 0 128x128 (4 waves), 1 128x64, 2 64x64, 3 128x128 (8 waves), 4 256x128 (8 waves, one workgroup
 	// per CU), 5 256x128 (16 waves), 6 128x256 (8 waves), 7 = 3 with the L2 prefetch of the chunk after the next
-	static const int k_bm[] = {128, 128, 64, 128, 256, 256, 128, 128}, k_bn[] = {128, 64, 64, 128, 128, 128, 256, 128};
-	if (cfg < 0 || cfg > 7) return hipErrorInvalidValue;
+	// 8 = 3 with LDS-DMA staging and a second fragment set; 9, 10 = 256x128 / 128x256 in that form (one workgroup per CU)
+	static const int k_bm[] = {128, 128, 64, 128, 256, 256, 128, 128, 128, 256, 128}, k_bn[] = {128, 64, 64, 128, 128, 128, 256, 128, 128, 128, 256};
+	if (cfg < 0 || cfg > 10) return hipErrorInvalidValue;
 	const int bm = k_bm[cfg], bn = k_bn[cfg];
 	const int tiles_m = (a.m + bm - 1) / bm, tiles_n = (a.n + bn - 1) / bn;
 	// lower-triangular updates enumerate only their non-empty tiles: square tiles by a closed form, any shape by table
@@ -750,6 +849,9 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs &a_in)
 	case 5: hipLaunchKernelGGL((gemm_nt_kernel<256, 128, 4, 8, 2>), dim3(T, nbatch), dim3(1024), 0, s, a); break;
 	case 6: hipLaunchKernelGGL((gemm_nt_kernel<128, 256, 2, 2, 4>), dim3(T, nbatch), dim3(512), 0, s, a); break;
 	case 7: hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 4, 4, 2, 1, 1>), dim3(T, nbatch), dim3(512), 0, s, a); break;
+	case 8: hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 4, 4, 2, 1, 0, 0, 1>), dim3(T, nbatch), dim3(512), 0, s, a); break;
+	case 9: hipLaunchKernelGGL((gemm_nt_kernel<256, 128, 2, 4, 2, 1, 0, 0, 1>), dim3(T, nbatch), dim3(512), 0, s, a); break;
+	case 10: hipLaunchKernelGGL((gemm_nt_kernel<128, 256, 2, 2, 4, 1, 0, 0, 1>), dim3(T, nbatch), dim3(512), 0, s, a); break;
 	default:
 		if (a.fa) hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2, 2, 0, 1>), dim3(T, nbatch), dim3(256), 0, s, a);
 		else hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2, 2>), dim3(T, nbatch), dim3(256), 0, s, a);

@@ -37,6 +37,27 @@ def test_gemm_nt_asymmetric(gpu_ctx, m, n, k):
     assert relerr(got, A @ B.T) < 1e-13
 
 
+@pytest.mark.parametrize("m,n,k", [(128, 128, 16), (128, 128, 32), (200, 72, 64), (129, 257, 48), (384, 256, 256), (2050, 1601, 112)])
+def test_gemm_lds_dma_tiles_bit_identical(monkeypatch, m, n, k):
+    """tile configuration 8 (operands by LDS-DMA into an XOR-swizzled image, two fragment sets, the barrier between the two
+    MFMA blocks of a k-step) issues the MFMA sequence of configuration 3 per accumulator: same bits, ragged edges included"""
+    rng = np.random.default_rng(m * 11 + n + k)
+    A, B, C0 = rng.standard_normal((m, k)), rng.standard_normal((n, k)), rng.standard_normal((m, n))
+    out = {}
+    monkeypatch.setenv("GPEMU_GEMM_BIG_TILES", "1")
+    for cfg in ("3", "8", "9", "10"):
+        monkeypatch.setenv("GPEMU_GEMM_BIG_CFG", cfg)
+        c = abi.Context(0)
+        out[cfg] = (c.test_gemm_nt(A, B, C0, alpha=-1.0, beta=1), c.test_gemm_nt(A, B, C0, alpha=1.0, beta=0))
+        c.close()
+    monkeypatch.delenv("GPEMU_GEMM_BIG_TILES")
+    monkeypatch.delenv("GPEMU_GEMM_BIG_CFG")
+    abi.Context(0).close()
+    assert relerr(out["8"][0], C0 - A @ B.T) < 1e-13 and relerr(out["8"][1], A @ B.T) < 1e-13
+    for cfg in ("8", "9", "10"):                      # 9, 10: the same loop on 256x128 / 128x256 tiles
+        assert np.array_equal(out["3"][0], out[cfg][0]) and np.array_equal(out["3"][1], out[cfg][1])
+
+
 def test_gemm_identity_asymmetric_exact(gpu_ctx):
     # A = I against an asymmetric integer B: any row/col or k-slot mix-up of the MFMA maps shows up exactly
     n = 128
@@ -861,6 +882,7 @@ def test_chol_inverse_and_symm_apply_on_host_matrices(gpu_ctx, n):
 @pytest.mark.parametrize("env", [{"GPEMU_LEAF128": "1"}, {"GPEMU_LOOKAHEAD": "1"}, {"GPEMU_NO_GRAPH": "1"}, {"GPEMU_FACTOR_AHEAD": "0"},
                                  {"GPEMU_SOLVE_AHEAD": "1"}, {"GPEMU_PANEL_TRSM": "512"}, {"GPEMU_PANEL_TRSM": "256"}, {"GPEMU_FILL_GRAM": "0"},
                                  {"GPEMU_NB_TOP": "256"}, {"GPEMU_NB_TOP": "2048"}, {"GPEMU_GEMM_BIG_CFG": "0", "GPEMU_GEMM_BIG_TILES": "1"},
+                                 {"GPEMU_GEMM_BIG_CFG": "8", "GPEMU_GEMM_BIG_TILES": "1"}, {"GPEMU_GEMM_BIG_CFG": "3", "GPEMU_GEMM_BIG_TILES": "1"},
                                  {"GPEMU_GEMM_BIG_TILES": "1"}, {"GPEMU_GEMM_BIG_TILES": "1000000"}])
 def test_schedule_switches_keep_parity(monkeypatch, env):
     """the measurement switches of INTEGRATION.md (alternative leaves, look-ahead, panel widths, tile shapes, no graph)
