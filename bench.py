@@ -392,12 +392,13 @@ def main():
     #      ctx stream around every launch; rank 0 only
     roof, roof_other = None, {}
     if rank == 0:
-        # the dominant kernel = gemm_nt_kernel<128,128,4,4,2> (128x128 tiles, 8 waves): the big trailing updates of a
-        # lock-step batch, 91 % of its flops and 80 % of the GPU time of this bench (profiles/r02_rocprofv3_kernel_stats_*)
+        # the dominant kernel = gemm_nt_kernel<128,128,4,4,2,1,0,0,1> (128x128 tiles, 8 waves, operands by LDS-DMA): every
+        # update of a lock-step batch with >= 1024 such tiles (contraction lengths 256 .. 2048), 95 % of its flops and
+        # 80 % of the GPU time of this bench (profiles/r02_rocprofv3_kernel_stats_*)
         ctx.prof_begin(abi.PROF_GEMM_BIG)
         ctx.loglik_batch_enqueue(np.array([theta(2000 + i) for i in range(B)]))     # one lock-step batch, as timed above
         p = ctx.prof_end()
-        ach = p["flops"] / (p["ms"] * 1e-3) / 1e12
+        ach = p["flops"] / (p["ms"] * 1e-3) / 1e12 if p["ms"] > 0 else 0.0
         # memory-side bytes per launch from the PMC passes committed under profiles/ (separate rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE runs of the same evaluation).  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE counts half the bytes of
         # 16-B-per-lane reads; the 8-B-per-lane C-tile reads of this kernel calibrate to the same half
@@ -406,9 +407,10 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
         if args.workload == "c3" and B == 16 and os.path.exists(tpath):      # measured for batches of 16
-            tj = json.load(open(tpath))["gemm_nt_kernel_128x128_8waves"]
-            traffic = (2.0 * tj["fetch_bytes_raw"] + tj["write_bytes"]) / tj["launches"]
-        roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<128,128,4,4,2> (potrf trailing updates on 128x128 tiles, v_mfma_f64_16x16x4_f64)",
+            tj = json.load(open(tpath)).get("gemm_nt_kernel_128x128_8waves_dma")
+            if tj:
+                traffic = (2.0 * tj["fetch_bytes_raw"] + tj["write_bytes"]) / tj["launches"]
+        roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<128,128,4,4,2,1,0,0,1> (potrf trailing updates on 128x128 tiles, LDS-DMA staging, v_mfma_f64_16x16x4_f64)",
                 "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS,
                 "traffic": traffic, "traffic_source": os.path.basename(tpath) if (traffic is not None) else None,
                 "launches": p["n"], "avg_launch_us": p["ms"] * 1e3 / max(p["n"], 1),
@@ -422,6 +424,15 @@ def main():
         roof_other["gemm_all_launches"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                                            "frac": ach / PEAK_FP64_MFMA_TFLOPS, "launches": p["n"],
                                            "avg_launch_us": p["ms"] * 1e3 / max(p["n"], 1), "flops_per_eval": p["flops"] / B}
+        # the compute-bound part: launches with a contraction length of 512 or more
+        ctx.prof_begin(abi.PROF_GEMM_K512)
+        ctx.loglik_batch_enqueue(np.array([theta(2700 + i) for i in range(B)]))
+        p = ctx.prof_end()
+        if p["n"] and p["ms"] > 0:
+            ach = p["flops"] / (p["ms"] * 1e-3) / 1e12
+            roof_other["gemm_k512_and_longer"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                                  "frac": ach / PEAK_FP64_MFMA_TFLOPS, "launches": p["n"],
+                                                  "avg_launch_us": p["ms"] * 1e3 / max(p["n"], 1), "flops_per_eval": p["flops"] / B}
         ctx.prof_begin(abi.PROF_POTRF)
         ctx.loglik_batch_enqueue(np.array([theta(3000 + i) for i in range(B)]))
         p = ctx.prof_end()

@@ -200,6 +200,7 @@ int gpemu_sync(gpemu_ctx *ctx);
 #define GPEMU_PROF_LEAF    3   /* diagonal-block factor + panel solve */
 #define GPEMU_PROF_POTRF   4   /* whole factorisation (graph launch) */
 #define GPEMU_PROF_GEMM_BIG 5  /* only the GEMM launches on the 128x128 8-wave kernel (the dominant kernel of a batch) */
+#define GPEMU_PROF_GEMM_K512 6 /* only the GEMM launches with a contraction length >= 512 */
 int gpemu_prof_begin(gpemu_ctx *ctx, int kernel_class);
 int gpemu_prof_end(gpemu_ctx *ctx, int *nlaunches, double *total_ms, double *flops, double *bytes);
 

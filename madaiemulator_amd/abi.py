@@ -14,7 +14,7 @@ from . import build as _build
 POWEREXP, MATERN32, MATERN52 = 1, 2, 3
 
 OK, ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_PD, ERR_REGRESSION, ERR_STATE = range(7)
-PROF_NONE, PROF_GEMM, PROF_FILL, PROF_LEAF, PROF_POTRF, PROF_GEMM_BIG = range(6)
+PROF_NONE, PROF_GEMM, PROF_FILL, PROF_LEAF, PROF_POTRF, PROF_GEMM_BIG, PROF_GEMM_K512 = range(7)
 MODE_EXACT_GRAD, MODE_MATERN_LOG = 1, 2
 RESULT_RING = 4
 

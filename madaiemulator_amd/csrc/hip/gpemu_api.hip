@@ -106,8 +106,10 @@ static hipError_t gemm(gpemu_ctx *ctx, const GemmArgs &a_in, hipStream_t stream 
 	GemmArgs a = a_in;
 	a.trace = trace_slot(ctx, "gemm m=%d n=%d k=%d", a.m, a.n, a.k1 - a.k0);
 	// GPEMU_PROF_GEMM: every GEMM launch; GPEMU_PROF_GEMM_BIG: only the launches that run the 128x128 8-wave kernel
-	// (gemm_nt_kernel<128,128,4,4,2>, the dominant kernel of a batched factorisation)
-	const int cls = (prof_on(ctx, GPEMU_PROF_GEMM_BIG) && gemm_uses_big_tiles(a)) ? GPEMU_PROF_GEMM_BIG : GPEMU_PROF_GEMM;
+	// (gemm_nt_kernel<128,128,4,4,2,1,0,0,1>, the dominant kernel of a batched factorisation); GPEMU_PROF_GEMM_K512: only
+	// those with a contraction length of 512 or more (the compute-bound updates)
+	const int cls = (prof_on(ctx, GPEMU_PROF_GEMM_BIG) && gemm_uses_big_tiles(a)) ? GPEMU_PROF_GEMM_BIG :
+	                (prof_on(ctx, GPEMU_PROF_GEMM_K512) && a.k1 - a.k0 >= 512) ? GPEMU_PROF_GEMM_K512 : GPEMU_PROF_GEMM;
 	const double fl = prof_on(ctx, cls) ? gemm_flops(a) * (a.nbatch > 1 ? a.nbatch : 1) : 0.0;
 	ProfScope ps(ctx, cls, fl, 0.0);
 	if (ps.on) {
@@ -631,7 +633,8 @@ static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv, bool diag_do
 static int run_potrf(gpemu_ctx *ctx, int inv)
 {
 	ctx->ev_next = 0;
-	const bool profiling = ctx->prof.cls == GPEMU_PROF_GEMM || ctx->prof.cls == GPEMU_PROF_LEAF || ctx->prof.cls == GPEMU_PROF_GEMM_BIG;
+	const bool profiling = ctx->prof.cls == GPEMU_PROF_GEMM || ctx->prof.cls == GPEMU_PROF_LEAF || ctx->prof.cls == GPEMU_PROF_GEMM_BIG ||
+	                       ctx->prof.cls == GPEMU_PROF_GEMM_K512;
 	if (ctx->dTrace) {
 		HIPCHK(ctx, hipMemsetAsync(ctx->dTrace, 0, (size_t)ctx->trace_cap * 64, ctx->stream));   // fresh slots
 	}
