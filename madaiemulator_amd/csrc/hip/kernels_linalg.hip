@@ -720,7 +720,7 @@ int g_gemm_force_cfg = -1;   // test/bench hook: 0 = 128x128, 1 = 128x64, 2 = 64
 // narrow K<=256 updates of the factorisation.
 int g_gemm_table = 8;          // XCD-blocked tile order from a table for launches of >= 512 tiles: side of the super-blocks (GPEMU_GEMM_TABLE; 0: off)
 int g_gemm_big_cfg = 8;        // tile configuration of the big launches (8: 128x128 8 waves by LDS-DMA, 3: the same tiles register-staged, 0: 4 waves)
-int g_gemm_big_tiles = 1024;   // 128x128 tiles (8 waves) once a launch has this many of them, else 64x64 (2048 with the register-staged tiles of configuration 3)
+int g_gemm_big_tiles = 1024;   // 128x128 tiles (8 waves) once a lock-step launch has this many of them (twice as many for one matrix), else 64x64
 
 bool gemm_uses_big_tiles(const GemmArgs &a)
 {
@@ -739,7 +739,10 @@ bool gemm_factor_ahead_ok(const GemmArgs &a)
 int choose_gemm_cfg(const GemmArgs &a)
 {
 	if (g_gemm_force_cfg >= 0) return g_gemm_force_cfg;
-	return count_tiles(a, 128, 128) * (a.nbatch > 1 ? a.nbatch : 1) >= g_gemm_big_tiles ? g_gemm_big_cfg : 2;
+	// one matrix per launch: twice the threshold -- 1000-2000 tiles on the 512 resident workgroups of the chip are 2-4
+	// rounds, and the partly filled last one costs more than the faster tile gains (6.3 against 6.2 ms per evaluation)
+	const long thr = (a.nbatch > 1 || g_gemm_big_tiles < 64) ? g_gemm_big_tiles : 2L * g_gemm_big_tiles;   // (< 64: test settings, taken literally)
+	return count_tiles(a, 128, 128) * (a.nbatch > 1 ? a.nbatch : 1) >= thr ? g_gemm_big_cfg : 2;
 }
 
 
