@@ -140,6 +140,7 @@ static void read_environment()
 	int v = geti("GPEMU_GEMM_BIG_TILES", 1024);
 	gpemu::g_gemm_big_tiles = v > 0 ? v : 1024;
 	gpemu::g_gemm_big_cfg = geti("GPEMU_GEMM_BIG_CFG", 8);
+	gpemu::g_gemm_small_dma = geti("GPEMU_GEMM_SMALL_DMA", 1) != 0;
 	v = geti("GPEMU_GEMM_TABLE", 8);
 	gpemu::g_gemm_table = v >= 0 && v <= 64 ? v : 8;
 	g_lookahead = geti("GPEMU_LOOKAHEAD", 0) != 0;

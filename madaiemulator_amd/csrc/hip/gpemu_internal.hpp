@@ -195,7 +195,7 @@ hipError_t launch_trace_product(hipStream_t s, const double *A, const double *B,
 hipError_t launch_gemm(hipStream_t s, const GemmArgs &a);
 hipError_t launch_skinny_nt(hipStream_t s, const double *Kq, long ldk, const double *L, long ldl, double *Vp, long ldv,
                             long sstride, int tq, int ntot, int K, int ntri, int nslice, int klen);
-extern int g_gemm_big_tiles, g_gemm_big_cfg, g_gemm_table;
+extern int g_gemm_big_tiles, g_gemm_big_cfg, g_gemm_table, g_gemm_small_dma;
 std::vector<int> build_tile_table(int tiles_m, int tiles_n, int tri, int S, int bm = 128, int bn = 128);
 hipError_t launch_leaf(hipStream_t s, double *T, long ld, int c0, int m_below, int *info,
                        unsigned long long *trace_factor = nullptr, unsigned long long *trace_solve = nullptr,

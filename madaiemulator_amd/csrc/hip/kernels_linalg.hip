@@ -98,8 +98,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 	constexpr int WM = BM / WGM, WN = BN / WGN;
 	constexpr int TM = WM / 16, TN = WN / 16;
 	constexpr int AIT = BM * 8 / NT, BIT = BN * 8 / NT;
-	constexpr int NPA = BM / 64, NPB = BN / 64;      // LDS-DMA pieces per wave (DMA = 1)
-	constexpr int SMEM_GEMM = 2 * (BM + BN) * LDS_S;
+	constexpr int NW = WGM * WGN;                       // waves
+	constexpr int NPA = BM / (8 * NW), NPB = BN / (8 * NW);      // LDS-DMA pieces (8 rows x 128 B) per wave and operand (DMA = 1)
+	constexpr int SMEM_GEMM = 2 * (BM + BN) * (DMA ? GEMM_BK : LDS_S);      // the LDS-DMA image has no padding
 	constexpr int SMEM = (FA && LEAF * LP > SMEM_GEMM) ? LEAF * LP : SMEM_GEMM;
 	__shared__ double smem[SMEM];
 	double (*As)[BM * LDS_S] = reinterpret_cast<double (*)[BM * LDS_S]>(smem);
@@ -286,8 +287,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 		}                                                                                                         \
 	} while (0)
 	if (DMA) {
-		static_assert(!DMA || (BM % 64 == 0 && BN % 64 == 0 && WGM * WGN == 8 && GEMM_BK == 16 && WM % 16 == 0 && WN % 16 == 0),
-		              "LDS-DMA loop: 8 waves, 16-deep chunks, 64-row pieces");
+		static_assert(!DMA || (BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && NW % 2 == 0 && NPA + NPB <= 8 && GEMM_BK == 16 && WM % 16 == 0 && WN % 16 == 0),
+		              "LDS-DMA loop: 16-deep chunks, 8-row pieces dealt to the waves in turn");
 		if (kb < ke) {
 			// LDS image (bytes): buffer b at b * BUFB; operand row R (A rows 0..BM-1, then the B rows) at R * 128; its 16-byte
 			// segment s (doubles 2s, 2s+1 of the chunk) in slot s ^ f(R), f(R) = (R & 7) ^ ((R >> 3) & 1): the 16 rows a
@@ -295,8 +296,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 			// rows of either half into 8 different slots modulo 128 bytes)
 			constexpr int BUFB = (BM + BN) * GEMM_BK * 8;
 			char *lds = reinterpret_cast<char *>(smem);
-			// DMA pieces: wave w moves rows 64 p + 8 w .. + 7 of the image for p = 0 .. NPA+NPB-1 (the first NPA: A rows),
-			// lane l -> row + (l >> 3), slot l & 7
+			// DMA pieces: wave w moves rows 8 NW p + 8 w .. + 7 of the image for p = 0 .. NPA+NPB-1 (the first NPA: A rows),
+			// lane l -> row + (l >> 3), slot l & 7 (8 NW is a multiple of 16: f does not depend on p)
 			const int uw = __builtin_amdgcn_readfirstlane(wave);
 			const int prow = 8 * uw + (lane >> 3);
 			const int pseg = (lane & 7) ^ ((prow & 7) ^ ((prow >> 3) & 1));
@@ -307,16 +308,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 			unsigned vo[8];                                   // (a size that depends on the template arguments loses the host stubs with this hipcc)
 #pragma unroll
 			for (int p = 0; p < NPA; p++) {
-				int ar = tm * BM + 64 * p + prow; if (ar > g.m - 1) ar = g.m - 1;
+				int ar = tm * BM + 8 * NW * p + prow; if (ar > g.m - 1) ar = g.m - 1;
 				vo[p] = (unsigned)((long)(ar - ra0) * g.lda * 8 + 16 * pseg);
 			}
 #pragma unroll
 			for (int p = 0; p < NPB; p++) {
-				int br = tn * BN + 64 * p + prow; if (br > g.n - 1) br = g.n - 1;
+				int br = tn * BN + 8 * NW * p + prow; if (br > g.n - 1) br = g.n - 1;
 				vo[NPA + p] = (unsigned)((long)(br - rb0) * g.ldb * 8 + 16 * pseg);
 			}
 			typedef __attribute__((address_space(3))) void *lds_ptr_t;
-#define GEMM_DMA1(rs, d, p, kk) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)((d) + 8192 * (p)), 16, vo[p], (kk) * 8, 0, 0)
+#define GEMM_DMA1(rs, d, p, kk) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)((d) + 1024 * NW * (p)), 16, vo[p], (kk) * 8, 0, 0)
 #define GEMM_DMA(buf, kk)                                                                                         \
 			do {                                                                                                      \
 				char *d = lds + (buf) * BUFB + uw * 1024;                                                              \
@@ -712,6 +713,7 @@ static long count_tiles(const GemmArgs &a, int BM, int BN)
 	return c;
 }
 
+int g_gemm_small_dma = 1;      // 64x64 tiles by the LDS-DMA loop too (GPEMU_GEMM_SMALL_DMA=0: register-staged, two k-steps ahead)
 int g_gemm_force_cfg = -1;   // test/bench hook: 0 = 128x128, 1 = 128x64, 2 = 64x64
 
 // Tile shape per call (measured on MI355X, profiles/r01_gemm_tile_sweep.txt): with thousands of 128x128 tiles
@@ -856,8 +858,13 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs &a_in)
 	case 9: hipLaunchKernelGGL((gemm_nt_kernel<256, 128, 2, 4, 2, 1, 0, 0, 1>), dim3(T, nbatch), dim3(512), 0, s, a); break;
 	case 10: hipLaunchKernelGGL((gemm_nt_kernel<128, 256, 2, 2, 4, 1, 0, 0, 1>), dim3(T, nbatch), dim3(512), 0, s, a); break;
 	default:
-		if (a.fa) hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2, 2, 0, 1>), dim3(T, nbatch), dim3(256), 0, s, a);
-		else hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2, 2>), dim3(T, nbatch), dim3(256), 0, s, a);
+		if (g_gemm_small_dma) {
+			if (a.fa) hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2, 1, 0, 1, 1>), dim3(T, nbatch), dim3(256), 0, s, a);
+			else hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2, 1, 0, 0, 1>), dim3(T, nbatch), dim3(256), 0, s, a);
+		} else {
+			if (a.fa) hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2, 2, 0, 1>), dim3(T, nbatch), dim3(256), 0, s, a);
+			else hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2, 2>), dim3(T, nbatch), dim3(256), 0, s, a);
+		}
 		break;
 	}
 	return hipGetLastError();
