@@ -1,0 +1,36 @@
+# round 2, final state (LDS-DMA loop on the 128x128 and the 64x64 tiles): everything profiles/ quotes, one box
+set -e
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r02d
+mkdir -p $O
+timeout -k 10 600 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
+tail -c 200 $O/bench.json
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/kst /tmp/kst1 /tmp/kst2
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -f csv rocpd -d /tmp/kst -o r -- python3 $R/bench.py --no-cpu-baseline > $O/bench_rocprof.json 2> $O/rocprof.err
+find /tmp/kst -name '*kernel_stats.csv' -exec cp {} $O/kernel_stats.csv \;
+python3 $R/tools/rocpd_summary.py $(find /tmp/kst -name '*.db') > $O/kernel_stats_all.txt || true
+python3 $R/tools/rocpd_summary.py $(find /tmp/kst -name '*.db') --grid-y 16 > $O/kernel_stats_batch16.txt || true
+echo "two-context profile done"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -f csv rocpd -d /tmp/kst1 -o r -- python3 $R/bench.py --no-cpu-baseline --streams 1 > $O/bench_rocprof_streams1.json 2> $O/rocprof1.err
+find /tmp/kst1 -name '*kernel_stats.csv' -exec cp {} $O/kernel_stats_streams1.csv \;
+python3 $R/tools/rocpd_summary.py $(find /tmp/kst1 -name '*.db') --grid-y 16 > $O/kernel_stats_streams1_batch16.txt
+echo "one-context profile done"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -f csv rocpd -d /tmp/kst2 -o r -- python3 $R/bench.py --no-cpu-baseline --streams 1 --no-grad --no-predict --no-single > $O/bench_rocprof_lik_only.json 2> $O/rocprof2.err
+find /tmp/kst2 -name '*kernel_stats.csv' -exec cp {} $O/kernel_stats_lik_only_streams1.csv \;
+python3 $R/tools/rocpd_summary.py $(find /tmp/kst2 -name '*.db') --grid-y 16 > $O/kernel_stats_lik_only_streams1_batch16.txt
+head -8 $O/kernel_stats_lik_only_streams1_batch16.txt
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmf_$c
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmf_$c -o r -- python3 $R/scratch/one_batch.py > /tmp/logf_$c.txt 2>&1
+done
+python3 $R/tools/rocpd_pmc.py $(find /tmp/pmf_FETCH_SIZE -name '*.db') $(find /tmp/pmf_WRITE_SIZE -name '*.db') > $O/pmc_traffic.txt
+rm -rf /tmp/pmsq
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d /tmp/pmsq -o r -- python3 $R/scratch/one_batch.py > /tmp/logsq.txt 2>&1
+python3 $R/tools/rocpd_pmc.py $(find /tmp/pmsq -name '*.db') > $O/pmc_sq.txt
+echo "pmc done"
+cd $R
+timeout -k 10 300 python3 bench.py --workload c2 --no-cpu-baseline > $O/bench_c2.json 2> $O/bench_c2.err
+timeout -k 10 400 python3 bench.py --workload c5 --no-cpu-baseline > $O/bench_c5.json 2> $O/bench_c5.err
+timeout -k 10 200 python3 scratch/gemm_insitu_table.py > $O/gemm_insitu_by_K.txt 2>&1
+echo all done
