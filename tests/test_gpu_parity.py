@@ -897,10 +897,12 @@ ths = np.array([synth.perturbed_thetas(1, d, 3, i) for i in range(3)])
 c = abi.Context(0)
 c.set_model(1, 1, X, y)
 out = [c.loglik(th), c.loglik(th), c.loglik_batch(ths), c.loglik_batch(ths), c.loglik_grad(th)]
+c.predict_setup(th)
+pm, pv = c.predict(synth.design(700, d, 99)[0])
 c.close()
 enc = lambda v: [float(x).hex() for x in np.atleast_1d(np.asarray(v, float)).ravel()]
 print("RESULT " + json.dumps({"v0": enc(out[0]["value"]), "v1": enc(out[1]["value"]), "s2": enc(out[0]["sigma2"]), "b2": enc(out[2]["value"]),
-                              "b3": enc(out[3]["value"]), "beta2": enc(out[2]["beta"]), "grad": enc(out[4]["grad"])}))
+                              "b3": enc(out[3]["value"]), "beta2": enc(out[2]["beta"]), "grad": enc(out[4]["grad"]), "pm": enc(pm), "pv": enc(pv)}))
 """
 _schedule_cache = {}
 
@@ -946,12 +948,16 @@ def test_schedule_switches_keep_parity(env):
     assert got["s2"][0] == pytest.approx(base["s2"][0], rel=1e-10)
     assert np.allclose(got["b2"], base["b2"], rtol=1e-11, atol=0)
     assert np.allclose(got["grad"], base["grad"], rtol=1e-8, atol=1e-9 * np.max(np.abs(base["grad"])))
+    # 700 predictions (triangular-operand products, k-ranges per tile) through the same switches
+    assert np.max(np.abs(got["pm"] - base["pm"])) < 1e-9 * max(1.0, np.max(np.abs(base["pm"])))
+    assert np.max(np.abs(got["pv"] - base["pv"])) < 1e-9 * max(1e-3, np.max(np.abs(base["pv"])))
     if "GPEMU_FACTOR_AHEAD" in env or "GPEMU_SOLVE_AHEAD" in env or "GPEMU_PANEL_TRSM" in env or env.get("GPEMU_GEMM_BIG_CFG") in ("3", "8") or "GPEMU_GEMM_SMALL_DMA" in env:
         # the factor-ahead / solve-ahead tiles and the one-pass panel solve run the update's and the leaf's own arithmetic
         # in the same order per element, and every GEMM tile shape issues the same MFMA sequence per accumulator: not a
         # single bit moves
         assert np.array_equal(got["v0"], base["v0"]) and np.array_equal(got["b2"], base["b2"])
         assert np.array_equal(got["beta2"], base["beta2"]) and np.array_equal(got["grad"], base["grad"])
+        assert np.array_equal(got["pm"], base["pm"]) and np.array_equal(got["pv"], base["pv"])
     e = O.Emulator(1, 1, X, y, th)
     r = y - e.H @ e.beta
     ref = -(-0.5 * e.logdet - N / 2.0 * 1.83788 - 0.5 * (r @ e.cinverse @ r))
