@@ -144,6 +144,7 @@ static void read_environment()
 	v = geti("GPEMU_GEMM_TABLE", 8);
 	gpemu::g_gemm_table = v >= 0 && v <= 64 ? v : 8;
 	g_lookahead = geti("GPEMU_LOOKAHEAD", 0) != 0;
+	gpemu::g_la_bulk_cfg = geti("GPEMU_LA_BULK_CFG", 8);
 	g_leaf128 = geti("GPEMU_LEAF128", 0) != 0;
 	g_fill_gram = geti("GPEMU_FILL_GRAM", 1) != 0;
 	g_factor_ahead = geti("GPEMU_FACTOR_AHEAD", 1) != 0;
@@ -171,10 +172,11 @@ extern "C" int gpemu_ctx_create(gpemu_ctx **out, int device)
 	if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = 0; greatest = 0; }
 	bool ok = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, greatest) == hipSuccess;
 	if (ok && g_lookahead) {
-		// Only the look-ahead schedule uses a second stream.  It is kept off a slice of the chip (GPEMU_RESERVE_CUS,
-		// default 32 of 256 CUs) so that the latency-bound panel kernels of the critical stream do not share MFMA
-		// pipes with the bulk trailing update (measured: sharing slows the 64x64 factor kernel 5x).
-		int reserve = 32, ncu = 256;
+		// Only the look-ahead schedule uses a second stream (lowest priority: the bulk of a trailing update).  The chain
+		// kernels on the critical stream get their share of a CU through wave priority (s_setprio) and through the half
+		// occupancy of the bulk launches (GemmArgs.half_occ), not through a partition of the chip; GPEMU_RESERVE_CUS > 0
+		// (an experiment of round 2: CU-masked second stream) still exists behind its variable.
+		int reserve = 0, ncu = 256;
 		const char *rs = getenv("GPEMU_RESERVE_CUS");
 		if (rs) reserve = atoi(rs);
 		hipDeviceProp_t prop;
@@ -500,7 +502,7 @@ static hipError_t trailing_update(gpemu_ctx *ctx, int c0, int k, int col_off, in
 	g.nbatch = ctx->nb; g.bsC = g.bsA = g.bsB = (long)ctx->T_stride;
 	if (fa_done) {
 		*fa_done = false;
-		g.fa = (g_factor_ahead && !g_leaf128 && !g_lookahead && col_off == 0 && !stream) ? 1 : 0;
+		g.fa = (g_factor_ahead && !g_leaf128 && col_off == 0 && !stream) ? 1 : 0;
 		g.fa_c0 = r0;
 		g.fa_info = ctx->dInfo;
 		if (g.fa && gemm_factor_ahead_ok(g)) *fa_done = true;
@@ -516,6 +518,9 @@ static hipError_t trailing_update(gpemu_ctx *ctx, int c0, int k, int col_off, in
 			}
 		}
 	}
+	// look-ahead schedule (one matrix per launch, two streams): the chain's launches raise their wave priority, the bulk
+	// update beside them runs at half occupancy so that a chain workgroup finds registers and LDS on every CU at once
+	if (g_lookahead && ctx->stream2) { g.prio = stream ? 0 : 1; g.half_occ = stream ? 1 : 0; }
 	return gemm(ctx, g, stream);
 }
 
@@ -556,7 +561,7 @@ static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv, bool diag_do
 		unsigned long long *trf = trace_slot(ctx, "leaf_factor c0=%d", c0);
 		unsigned long long *trs = trace_slot(ctx, "leaf_solve c0=%d m=%d", c0, row_end - (c0 + LEAF));
 		return launch_leaf(ctx->stream, ctx->dT, ld, c0, row_end - (c0 + LEAF), ctx->dInfo, trf, trs, ctx->nb,
-		                   (long)ctx->T_stride, diag_done, diag_done && solve_done);
+		                   (long)ctx->T_stride, diag_done, diag_done && solve_done, (g_lookahead && ctx->stream2) ? 1 : 0);
 	}
 	if (n == 2 * LEAF && g_leaf128) {
 		const int row_end = base_end + (inv ? c0 + 2 * LEAF : 0);
@@ -604,7 +609,7 @@ static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv, bool diag_do
 				if (e != hipSuccess) return e;
 				ev_bulk_prev = nullptr;
 			}
-			e = trailing_update(ctx, c, nb, 0, nb_next, inv);
+			e = trailing_update(ctx, c, nb, 0, nb_next, inv, nullptr, &next_done, &next_solved);
 			if (e != hipSuccess) return e;
 			if (rest > nb_next) {
 				e = hipStreamWaitEvent(ctx->stream2, ev_panel, 0);

@@ -66,6 +66,9 @@ struct GemmArgs {
 	int *fa_info;        // info words (one per matrix of the batch)
 	int sa;              // solve-ahead (with fa, ONE matrix per launch): the tiles of tile column 0 wait for that L and solve their rows
 	int *sa_flag;        // zero before the launch; set by tile (0,0) once L is visible
+	int prio;            // 1: the waves raise their issue priority (s_setprio 3): critical-chain launches of the look-ahead schedule
+	int half_occ;        // 1: launch with an LDS pad that halves the workgroups per CU (bulk update of the look-ahead schedule:
+	                     // leaves registers and LDS for the chain kernels that run beside it)
 };
 
 struct ProfState {
@@ -195,11 +198,11 @@ hipError_t launch_trace_product(hipStream_t s, const double *A, const double *B,
 hipError_t launch_gemm(hipStream_t s, const GemmArgs &a);
 hipError_t launch_skinny_nt(hipStream_t s, const double *Kq, long ldk, const double *L, long ldl, double *Vp, long ldv,
                             long sstride, int tq, int ntot, int K, int ntri, int nslice, int klen);
-extern int g_gemm_big_tiles, g_gemm_big_cfg, g_gemm_table, g_gemm_small_dma;
+extern int g_gemm_big_tiles, g_gemm_big_cfg, g_gemm_table, g_gemm_small_dma, g_la_bulk_cfg;
 std::vector<int> build_tile_table(int tiles_m, int tiles_n, int tri, int S, int bm = 128, int bn = 128);
 hipError_t launch_leaf(hipStream_t s, double *T, long ld, int c0, int m_below, int *info,
                        unsigned long long *trace_factor = nullptr, unsigned long long *trace_solve = nullptr,
-                       int nbatch = 1, long bstride = 0, bool skip_factor = false, bool skip_solve = false);
+                       int nbatch = 1, long bstride = 0, bool skip_factor = false, bool skip_solve = false, int prio = 0);
 bool gemm_factor_ahead_ok(const GemmArgs &a);
 hipError_t launch_panel_trsm(hipStream_t s, double *T, long ld, int c0, int n, int j0, int row0, int m, int nbatch, long bstride,
                              unsigned long long *trace = nullptr);

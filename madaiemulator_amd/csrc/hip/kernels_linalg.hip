@@ -107,6 +107,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 	double (*As)[BM * LDS_S] = reinterpret_cast<double (*)[BM * LDS_S]>(smem);
 	double (*Bs)[BN * LDS_S] = reinterpret_cast<double (*)[BN * LDS_S]>(smem + 2 * BM * LDS_S);
 
+	if (g.prio) __builtin_amdgcn_s_setprio(3);          // a chain launch beside a bulk update: its instructions issue first
 	// batch of independent problems (lock-step factorisations): blockIdx.y selects the matrix
 	g.C += (long)blockIdx.y * g.bsC;
 	g.A += (long)blockIdx.y * g.bsA;
@@ -739,9 +740,11 @@ bool gemm_factor_ahead_ok(const GemmArgs &a)
 	       !a.kend_mode && a.ksplit <= 1 && choose_gemm_cfg(a) == 2;
 }
 
+int g_la_bulk_cfg = 8;          // tile configuration of the look-ahead schedule's bulk updates (GPEMU_LA_BULK_CFG: 8 or 2)
 int choose_gemm_cfg(const GemmArgs &a)
 {
 	if (g_gemm_force_cfg >= 0) return g_gemm_force_cfg;
+	if (a.half_occ) return (g_la_bulk_cfg == 8 && count_tiles(a, 128, 128) >= 256) ? 8 : 2;
 	// one matrix per launch: twice the threshold -- 1000-2000 tiles on the 512 resident workgroups of the chip are 2-4
 	// rounds, and the partly filled last one costs more than the faster tile gains (6.3 against 6.2 ms per evaluation)
 	const long thr = (a.nbatch > 1 || g_gemm_big_tiles < 64) ? g_gemm_big_tiles : 2L * g_gemm_big_tiles;   // (< 64: test settings, taken literally)
@@ -855,13 +858,13 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs &a_in)
 	case 5: hipLaunchKernelGGL((gemm_nt_kernel<256, 128, 4, 8, 2>), dim3(T, nbatch), dim3(1024), 0, s, a); break;
 	case 6: hipLaunchKernelGGL((gemm_nt_kernel<128, 256, 2, 2, 4>), dim3(T, nbatch), dim3(512), 0, s, a); break;
 	case 7: hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 4, 4, 2, 1, 1>), dim3(T, nbatch), dim3(512), 0, s, a); break;
-	case 8: hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 4, 4, 2, 1, 0, 0, 1>), dim3(T, nbatch), dim3(512), 0, s, a); break;
+	case 8: hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 4, 4, 2, 1, 0, 0, 1>), dim3(T, nbatch), dim3(512), a.half_occ ? 32768 : 0, s, a); break;   // 64 + 32 KB: one per CU
 	case 9: hipLaunchKernelGGL((gemm_nt_kernel<256, 128, 2, 4, 2, 1, 0, 0, 1>), dim3(T, nbatch), dim3(512), 0, s, a); break;
 	case 10: hipLaunchKernelGGL((gemm_nt_kernel<128, 256, 2, 2, 4, 1, 0, 0, 1>), dim3(T, nbatch), dim3(512), 0, s, a); break;
 	default:
 		if (g_gemm_small_dma) {
 			if (a.fa) hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2, 1, 0, 1, 1>), dim3(T, nbatch), dim3(256), 0, s, a);
-			else hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2, 1, 0, 0, 1>), dim3(T, nbatch), dim3(256), 0, s, a);
+			else hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2, 1, 0, 0, 1>), dim3(T, nbatch), dim3(256), a.half_occ ? 36864 : 0, s, a);   // 32 + 36 KB: two per CU
 		} else {
 			if (a.fa) hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2, 2, 0, 1>), dim3(T, nbatch), dim3(256), 0, s, a);
 			else hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2, 2>), dim3(T, nbatch), dim3(256), 0, s, a);
@@ -973,8 +976,9 @@ __device__ __forceinline__ void panel_update(double *A, int wave, int lane)
 		}
 }
 
-__global__ __launch_bounds__(256) void leaf_factor_kernel(double *T, long ld, int c0, int *info, unsigned long long *trace, long bstride)
+__global__ __launch_bounds__(256) void leaf_factor_kernel(double *T, long ld, int c0, int *info, unsigned long long *trace, long bstride, int prio)
 {
+	if (prio) __builtin_amdgcn_s_setprio(3);
 	T += (long)blockIdx.y * bstride;     // lock-step batch: one diagonal block per matrix
 	info += blockIdx.y;
 	__shared__ double A[LEAF * LP];
@@ -1097,8 +1101,9 @@ __device__ __forceinline__ void tri_inverse16(double *M, int o, double *tile, in
 	tri_inverse16_to<LP, LP>(M, o, tile, lane, M + o * LP + o, LP);
 }
 
-__global__ __launch_bounds__(256) void leaf_solve_kernel(double *T, long ld, int c0, int m_below, unsigned long long *trace, long bstride)
+__global__ __launch_bounds__(256) void leaf_solve_kernel(double *T, long ld, int c0, int m_below, unsigned long long *trace, long bstride, int prio)
 {
+	if (prio) __builtin_amdgcn_s_setprio(3);
 	T += (long)blockIdx.y * bstride;
 	__shared__ double M[LEAF * LP];        // L; diagonal 16x16 blocks replaced by their inverses
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1587,14 +1592,14 @@ hipError_t launch_leaf128(hipStream_t s, double *T, long ld, int c0, int m_below
 }
 
 hipError_t launch_leaf(hipStream_t s, double *T, long ld, int c0, int m_below, int *info, unsigned long long *trf,
-                       unsigned long long *trs, int nbatch, long bstride, bool skip_factor, bool skip_solve)
+                       unsigned long long *trs, int nbatch, long bstride, bool skip_factor, bool skip_solve, int prio)
 {
 	if (nbatch < 1) nbatch = 1;
 	if (!skip_factor)                    // (skipped: the diagonal block was factored by the update before, factor-ahead)
-		hipLaunchKernelGGL(leaf_factor_kernel, dim3(1, nbatch), dim3(256), 0, s, T, ld, c0, info, trf, bstride);
+		hipLaunchKernelGGL(leaf_factor_kernel, dim3(1, nbatch), dim3(256), 0, s, T, ld, c0, info, trf, bstride, prio);
 	if (m_below > 0 && !skip_solve)      // (skipped: the rows were solved by the update before, solve-ahead)
 		hipLaunchKernelGGL(leaf_solve_kernel, dim3((m_below + 63) / 64, nbatch), dim3(256), 0, s, T, ld, c0, m_below,
-		                   trs, bstride);
+		                   trs, bstride, prio);
 	return hipGetLastError();
 }
 

@@ -928,7 +928,8 @@ def _schedule_run(env):
 
 # (the two-stream look-ahead schedule -- measured slower, off by default, DESIGN.md section 8 -- is only exercised when
 # GPEMU_TEST_LOOKAHEAD=1; see _schedule_run)
-@pytest.mark.parametrize("env", [{"GPEMU_LEAF128": "1"}] + ([{"GPEMU_LOOKAHEAD": "1"}] if os.environ.get("GPEMU_TEST_LOOKAHEAD") else []) +
+@pytest.mark.parametrize("env", [{"GPEMU_LEAF128": "1"}] + ([{"GPEMU_LOOKAHEAD": "1"}, {"GPEMU_LOOKAHEAD": "1", "GPEMU_NO_GRAPH": "1"}, {"GPEMU_LOOKAHEAD": "1", "GPEMU_LA_BULK_CFG": "2"}]
+                                                           if os.environ.get("GPEMU_TEST_LOOKAHEAD") else []) +
                                 [{"GPEMU_NO_GRAPH": "1"}, {"GPEMU_FACTOR_AHEAD": "0"},
                                  {"GPEMU_SOLVE_AHEAD": "1"}, {"GPEMU_PANEL_TRSM": "512"}, {"GPEMU_PANEL_TRSM": "256"}, {"GPEMU_FILL_GRAM": "0"},
                                  {"GPEMU_NB_TOP": "256"}, {"GPEMU_NB_TOP": "2048"}, {"GPEMU_GEMM_BIG_CFG": "0", "GPEMU_GEMM_BIG_TILES": "1"},
@@ -951,7 +952,7 @@ def test_schedule_switches_keep_parity(env):
     # 700 predictions (triangular-operand products, k-ranges per tile) through the same switches
     assert np.max(np.abs(got["pm"] - base["pm"])) < 1e-9 * max(1.0, np.max(np.abs(base["pm"])))
     assert np.max(np.abs(got["pv"] - base["pv"])) < 1e-9 * max(1e-3, np.max(np.abs(base["pv"])))
-    if "GPEMU_FACTOR_AHEAD" in env or "GPEMU_SOLVE_AHEAD" in env or "GPEMU_PANEL_TRSM" in env or env.get("GPEMU_GEMM_BIG_CFG") in ("3", "8") or "GPEMU_GEMM_SMALL_DMA" in env:
+    if "GPEMU_FACTOR_AHEAD" in env or "GPEMU_SOLVE_AHEAD" in env or "GPEMU_PANEL_TRSM" in env or env.get("GPEMU_GEMM_BIG_CFG") in ("3", "8") or "GPEMU_GEMM_SMALL_DMA" in env or "GPEMU_LOOKAHEAD" in env:
         # the factor-ahead / solve-ahead tiles and the one-pass panel solve run the update's and the leaf's own arithmetic
         # in the same order per element, and every GEMM tile shape issues the same MFMA sequence per accumulator: not a
         # single bit moves
