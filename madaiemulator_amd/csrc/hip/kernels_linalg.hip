@@ -228,7 +228,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 	const bool full_tile = (tm * BM + BM <= g.m) && (tn * BN + BN <= g.n);
 	d4_t acc[TM][TN];
 	if (g.beta) {
-		const double cs = g.alpha;       // 1/alpha for alpha = +-1
 		if (full_tile) {
 #pragma unroll
 			for (int i = 0; i < TM; i++)
@@ -236,7 +235,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 				for (int r = 0; r < 4; r++) {
 					const double *crow = g.C + (long)(row0 + i * 16 + 4 * r) * g.ldc + col0;
 #pragma unroll
-					for (int j = 0; j < TN; j++) acc[i][j][r] = cs * crow[j * 16];
+					for (int j = 0; j < TN; j++) acc[i][j][r] = crow[j * 16];
 				}
 		} else {
 #pragma unroll
@@ -248,9 +247,17 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 #pragma unroll
 					for (int j = 0; j < TN; j++) {
 						const int col = col0 + j * 16;
-						acc[i][j][r] = cs * crow[col < g.n ? col : g.n - 1];
+						acc[i][j][r] = crow[col < g.n ? col : g.n - 1];
 					}
 				}
+		}
+		// C / alpha with alpha = +-1 (launch_gemm refuses anything else when beta is set): a sign flip, not 64 fp64
+		// multiplications per lane (same bits; measured neutral)
+		if (g.alpha < 0.0) {
+#pragma unroll
+			for (int i = 0; i < TM; i++)
+#pragma unroll
+				for (int j = 0; j < TN; j++) acc[i][j] = -acc[i][j];
 		}
 	} else {
 #pragma unroll
@@ -465,9 +472,20 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 #undef GEMM_STORE
 #undef GEMM_STEP
 
-	// epilogue
+	// epilogue: alpha * accumulators (a sign flip or nothing for alpha = -+1, see above)
 	unsigned long long clk_loop_end = 0;
 	if (g.trace && tr0.wall) clk_loop_end = clock64();
+	if (g.alpha == -1.0) {
+#pragma unroll
+		for (int i = 0; i < TM; i++)
+#pragma unroll
+			for (int j = 0; j < TN; j++) acc[i][j] = -acc[i][j];
+	} else if (g.alpha != 1.0) {
+#pragma unroll
+		for (int i = 0; i < TM; i++)
+#pragma unroll
+			for (int j = 0; j < TN; j++) acc[i][j] = g.alpha * acc[i][j];
+	}
 	if (FA && g.fa && tm == 0 && tn == 0) {
 		static_assert(!FA || (BM == LEAF && BN == LEAF && WGM == 2 && WGN == 2), "factor-ahead is for the 64x64 tiles, 4 waves");
 		// the updated diagonal block goes to LDS instead of memory (every wave is past its last read of the operand
@@ -479,7 +497,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 			for (int r = 0; r < 4; r++)
 #pragma unroll
 				for (int j = 0; j < TN; j++)
-					A[(wm * WM + i * 16 + (lane >> 4) + 4 * r) * LP + wn * WN + j * 16 + (lane & 15)] = g.alpha * acc[i][j][r];
+					A[(wm * WM + i * 16 + (lane >> 4) + 4 * r) * LP + wn * WN + j * 16 + (lane & 15)] = acc[i][j][r];
 		__syncthreads();
 		int bad = 0;
 		if (wave == 0) panel_factor<0, LP>(A, lane, bad, 0);
@@ -534,7 +552,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 			for (int r = 0; r < 4; r++)
 #pragma unroll
 				for (int j = 0; j < TN; j++)
-					M[(wm * WM + i * 16 + (lane >> 4) + 4 * r) * LP + wn * WN + j * 16 + (lane & 15)] = g.alpha * acc[i][j][r];
+					M[(wm * WM + i * 16 + (lane >> 4) + 4 * r) * LP + wn * WN + j * 16 + (lane & 15)] = acc[i][j][r];
 		__syncthreads();
 		const int q = lane & 15, gq = lane >> 4;
 		d4_t R[4];                         // wave w: rows 16w .. 16w+15 in the solve's layout (lane (q,g): row q, columns 16j + g + 4r)
@@ -602,7 +620,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 			for (int r = 0; r < 4; r++) {
 				double *crow = g.C + (long)(row0 + i * 16 + 4 * r) * g.ldc + col0;
 #pragma unroll
-				for (int j = 0; j < TN; j++) crow[j * 16] = g.alpha * acc[i][j][r];
+				for (int j = 0; j < TN; j++) crow[j * 16] = acc[i][j][r];
 			}
 	} else {
 #pragma unroll
@@ -616,7 +634,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 				for (int j = 0; j < TN; j++) {
 					const int col = col0 + j * 16;
 					if (col >= g.n) continue;
-					crow[col] = g.alpha * acc[i][j][r];
+					crow[col] = acc[i][j][r];
 				}
 			}
 	}
