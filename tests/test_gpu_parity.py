@@ -38,30 +38,34 @@ def test_gemm_nt_asymmetric(gpu_ctx, m, n, k):
     assert relerr(got, A @ B.T) < 1e-13
 
 
-@pytest.mark.parametrize("m,n,k", [(128, 128, 16), (128, 128, 32), (200, 72, 64), (129, 257, 48), (384, 256, 256), (2050, 1601, 112)])
-def test_gemm_lds_dma_tiles_bit_identical(monkeypatch, m, n, k):
+def test_gemm_lds_dma_tiles_bit_identical(monkeypatch):
     """tile configuration 8 (operands by LDS-DMA into an XOR-swizzled image, two fragment sets, the barrier between the two
     MFMA blocks of a k-step) issues the MFMA sequence of configuration 3 per accumulator: same bits, ragged edges included;
-    so do the 256x128 / 128x256 forms (9, 10) and the 64x64 tiles in either loop form (GPEMU_GEMM_SMALL_DMA)"""
-    rng = np.random.default_rng(m * 11 + n + k)
-    A, B, C0 = rng.standard_normal((m, k)), rng.standard_normal((n, k)), rng.standard_normal((m, n))
-    out = {}
+    so do the 256x128 / 128x256 forms (9, 10) and the 64x64 tiles in either loop form (GPEMU_GEMM_SMALL_DMA).
+    One context per variant (the switches are read when a context is created), all shapes through it."""
+    shapes = [(128, 128, 16), (128, 128, 32), (200, 72, 64), (129, 257, 48), (384, 256, 256), (2050, 1601, 112)]
+    data = []
+    for m, n, k in shapes:
+        rng = np.random.default_rng(m * 11 + n + k)
+        data.append((rng.standard_normal((m, k)), rng.standard_normal((n, k)), rng.standard_normal((m, n))))
     variants = {"3": {"GPEMU_GEMM_BIG_TILES": "1", "GPEMU_GEMM_BIG_CFG": "3"}, "8": {"GPEMU_GEMM_BIG_TILES": "1", "GPEMU_GEMM_BIG_CFG": "8"},
                 "9": {"GPEMU_GEMM_BIG_TILES": "1", "GPEMU_GEMM_BIG_CFG": "9"}, "10": {"GPEMU_GEMM_BIG_TILES": "1", "GPEMU_GEMM_BIG_CFG": "10"},
                 "small": {"GPEMU_GEMM_BIG_TILES": "1000000", "GPEMU_GEMM_SMALL_DMA": "0"},
                 "small_dma": {"GPEMU_GEMM_BIG_TILES": "1000000", "GPEMU_GEMM_SMALL_DMA": "1"}}
+    out = {}
     for name, env in variants.items():
         for k_, v in env.items():
             monkeypatch.setenv(k_, v)
         c = abi.Context(0)
-        out[name] = (c.test_gemm_nt(A, B, C0, alpha=-1.0, beta=1), c.test_gemm_nt(A, B, C0, alpha=1.0, beta=0))
+        out[name] = [(c.test_gemm_nt(A, B, C0, alpha=-1.0, beta=1), c.test_gemm_nt(A, B, C0, alpha=1.0, beta=0)) for A, B, C0 in data]
         c.close()
         for k_ in env:
             monkeypatch.delenv(k_)
-    abi.Context(0).close()
-    assert relerr(out["8"][0], C0 - A @ B.T) < 1e-13 and relerr(out["8"][1], A @ B.T) < 1e-13
-    for name in variants:
-        assert np.array_equal(out["3"][0], out[name][0]) and np.array_equal(out["3"][1], out[name][1]), name
+    abi.Context(0).close()                   # the next context re-reads the environment: back to the defaults
+    for i, (A, B, C0) in enumerate(data):
+        assert relerr(out["8"][i][0], C0 - A @ B.T) < 1e-13 and relerr(out["8"][i][1], A @ B.T) < 1e-13, shapes[i]
+        for name in variants:
+            assert np.array_equal(out["3"][i][0], out[name][i][0]) and np.array_equal(out["3"][i][1], out[name][i][1]), (name, shapes[i])
 
 
 def test_gemm_identity_asymmetric_exact(gpu_ctx):
