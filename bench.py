@@ -301,6 +301,70 @@ def main():
     evals_per_s = ngpus * K * B / tA
     note(f"region A: {evals_per_s:.1f} evaluations/s")
 
+    # ---- roofline of the dominant kernel (fp64 MFMA GEMM of the Cholesky trailing updates), HIP events on the
+    #      ctx stream around every launch; rank 0 only.  Taken right behind region A: the same kernels in the state of the
+    #      card region A was timed in (at the end of the whole line, a minute of load later, they read 3 % lower)
+    roof, roof_other = None, {}
+    if rank == 0:
+        # the dominant kernel = gemm_nt_kernel<128,128,4,4,2,1,0,0,1> (128x128 tiles, 8 waves, operands by LDS-DMA): every
+        # update of a lock-step batch with >= 1024 such tiles (contraction lengths 256 .. 2048), 95 % of its flops and
+        # 80 % of the GPU time of this bench (profiles/r02_rocprofv3_kernel_stats_*)
+        ctx.prof_begin(abi.PROF_GEMM_BIG)
+        ctx.loglik_batch_enqueue(np.array([theta(2000 + i) for i in range(B)]))     # one lock-step batch, as timed above
+        p = ctx.prof_end()
+        ach = p["flops"] / (p["ms"] * 1e-3) / 1e12 if p["ms"] > 0 else 0.0
+        # memory-side bytes per launch from the PMC passes committed under profiles/ (separate rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE runs of the same evaluation).  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE counts half the bytes of
+        # 16-B-per-lane reads; the 8-B-per-lane C-tile reads of this kernel calibrate to the same half
+        # (profiles/r01_pmc_fetch_calibration.txt), so the whole raw fetch is doubled; WRITE_SIZE is exact.  Infinity-
+        # Cache hits are included in both, i.e. this is fabric traffic, an upper bound on HBM traffic.
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
+        if args.workload == "c3" and B == 16 and os.path.exists(tpath):      # measured for batches of 16
+            tj = json.load(open(tpath)).get("gemm_nt_kernel_128x128_8waves_dma")
+            if tj:
+                traffic = (2.0 * tj["fetch_bytes_raw"] + tj["write_bytes"]) / tj["launches"]
+        roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<128,128,4,4,2,1,0,0,1> (potrf trailing updates on 128x128 tiles, LDS-DMA staging, v_mfma_f64_16x16x4_f64)",
+                "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS,
+                "traffic": traffic, "traffic_source": os.path.basename(tpath) if (traffic is not None) else None,
+                "launches": p["n"], "avg_launch_us": p["ms"] * 1e3 / max(p["n"], 1),
+                "flops_per_launch": p["flops"] / max(p["n"], 1), "evaluations_per_launch": B}
+        # every GEMM launch of the batch (the narrow K <= 256 updates on 64x64 tiles included; with factor-ahead their
+        # tile (0,0) also factors the next diagonal block, so their durations contain ~10 us of pivots each)
+        ctx.prof_begin(abi.PROF_GEMM)
+        ctx.loglik_batch_enqueue(np.array([theta(2500 + i) for i in range(B)]))
+        p = ctx.prof_end()
+        ach = p["flops"] / (p["ms"] * 1e-3) / 1e12
+        roof_other["gemm_all_launches"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                           "frac": ach / PEAK_FP64_MFMA_TFLOPS, "launches": p["n"],
+                                           "avg_launch_us": p["ms"] * 1e3 / max(p["n"], 1), "flops_per_eval": p["flops"] / B}
+        # the compute-bound part: launches with a contraction length of 512 or more
+        ctx.prof_begin(abi.PROF_GEMM_K512)
+        ctx.loglik_batch_enqueue(np.array([theta(2700 + i) for i in range(B)]))
+        p = ctx.prof_end()
+        if p["n"] and p["ms"] > 0:
+            ach = p["flops"] / (p["ms"] * 1e-3) / 1e12
+            roof_other["gemm_k512_and_longer"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                                  "frac": ach / PEAK_FP64_MFMA_TFLOPS, "launches": p["n"],
+                                                  "avg_launch_us": p["ms"] * 1e3 / max(p["n"], 1), "flops_per_eval": p["flops"] / B}
+        ctx.prof_begin(abi.PROF_POTRF)
+        ctx.loglik_batch_enqueue(np.array([theta(3000 + i) for i in range(B)]))
+        p = ctx.prof_end()
+        roof_other["potrf_whole"] = {"bound": "mfma", "achieved": (N ** 3 / 3.0) * B / (p["ms"] * 1e-3) / 1e12,
+                                     "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "ms_per_eval": p["ms"] / B,
+                                     "evaluations_per_factorisation": B}
+        roof_other["potrf_whole"]["frac"] = roof_other["potrf_whole"]["achieved"] / PEAK_FP64_MFMA_TFLOPS
+        ctx.prof_begin(abi.PROF_FILL)
+        for i in range(3):
+            ctx.loglik_enqueue(theta(4000 + i))
+        p = ctx.prof_end()
+        gbs = p["bytes"] / (p["ms"] * 1e-3) / 1e9
+        roof_other["cov_fill"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                  "frac": gbs / PEAK_HBM_GBS, "avg_launch_us": p["ms"] * 1e3 / max(p["n"], 1)}
+    if rank == 0:
+        ctx.sync()
+    note("likelihood rooflines done")
+
     # one evaluation at a time on one context (the shape of a sequential caller: one BFGS run, alloc_emulator_struct;
     # emulator_struct.c:28-32): host call to host result, i.e. `--batch 1 --streams 1`
     single = None
@@ -388,65 +452,8 @@ def main():
         gctx.close()
 
     note("region C (value+gradient) done")
-    # ---- roofline of the dominant kernel (fp64 MFMA GEMM of the Cholesky trailing updates), HIP events on the
-    #      ctx stream around every launch; rank 0 only
-    roof, roof_other = None, {}
+    # ---- roofline of the prediction GEMM (the likelihood rooflines were taken right behind region A)
     if rank == 0:
-        # the dominant kernel = gemm_nt_kernel<128,128,4,4,2,1,0,0,1> (128x128 tiles, 8 waves, operands by LDS-DMA): every
-        # update of a lock-step batch with >= 1024 such tiles (contraction lengths 256 .. 2048), 95 % of its flops and
-        # 80 % of the GPU time of this bench (profiles/r02_rocprofv3_kernel_stats_*)
-        ctx.prof_begin(abi.PROF_GEMM_BIG)
-        ctx.loglik_batch_enqueue(np.array([theta(2000 + i) for i in range(B)]))     # one lock-step batch, as timed above
-        p = ctx.prof_end()
-        ach = p["flops"] / (p["ms"] * 1e-3) / 1e12 if p["ms"] > 0 else 0.0
-        # memory-side bytes per launch from the PMC passes committed under profiles/ (separate rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE runs of the same evaluation).  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE counts half the bytes of
-        # 16-B-per-lane reads; the 8-B-per-lane C-tile reads of this kernel calibrate to the same half
-        # (profiles/r01_pmc_fetch_calibration.txt), so the whole raw fetch is doubled; WRITE_SIZE is exact.  Infinity-
-        # Cache hits are included in both, i.e. this is fabric traffic, an upper bound on HBM traffic.
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
-        if args.workload == "c3" and B == 16 and os.path.exists(tpath):      # measured for batches of 16
-            tj = json.load(open(tpath)).get("gemm_nt_kernel_128x128_8waves_dma")
-            if tj:
-                traffic = (2.0 * tj["fetch_bytes_raw"] + tj["write_bytes"]) / tj["launches"]
-        roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<128,128,4,4,2,1,0,0,1> (potrf trailing updates on 128x128 tiles, LDS-DMA staging, v_mfma_f64_16x16x4_f64)",
-                "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS,
-                "traffic": traffic, "traffic_source": os.path.basename(tpath) if (traffic is not None) else None,
-                "launches": p["n"], "avg_launch_us": p["ms"] * 1e3 / max(p["n"], 1),
-                "flops_per_launch": p["flops"] / max(p["n"], 1), "evaluations_per_launch": B}
-        # every GEMM launch of the batch (the narrow K <= 256 updates on 64x64 tiles included; with factor-ahead their
-        # tile (0,0) also factors the next diagonal block, so their durations contain ~10 us of pivots each)
-        ctx.prof_begin(abi.PROF_GEMM)
-        ctx.loglik_batch_enqueue(np.array([theta(2500 + i) for i in range(B)]))
-        p = ctx.prof_end()
-        ach = p["flops"] / (p["ms"] * 1e-3) / 1e12
-        roof_other["gemm_all_launches"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                           "frac": ach / PEAK_FP64_MFMA_TFLOPS, "launches": p["n"],
-                                           "avg_launch_us": p["ms"] * 1e3 / max(p["n"], 1), "flops_per_eval": p["flops"] / B}
-        # the compute-bound part: launches with a contraction length of 512 or more
-        ctx.prof_begin(abi.PROF_GEMM_K512)
-        ctx.loglik_batch_enqueue(np.array([theta(2700 + i) for i in range(B)]))
-        p = ctx.prof_end()
-        if p["n"] and p["ms"] > 0:
-            ach = p["flops"] / (p["ms"] * 1e-3) / 1e12
-            roof_other["gemm_k512_and_longer"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                                  "frac": ach / PEAK_FP64_MFMA_TFLOPS, "launches": p["n"],
-                                                  "avg_launch_us": p["ms"] * 1e3 / max(p["n"], 1), "flops_per_eval": p["flops"] / B}
-        ctx.prof_begin(abi.PROF_POTRF)
-        ctx.loglik_batch_enqueue(np.array([theta(3000 + i) for i in range(B)]))
-        p = ctx.prof_end()
-        roof_other["potrf_whole"] = {"bound": "mfma", "achieved": (N ** 3 / 3.0) * B / (p["ms"] * 1e-3) / 1e12,
-                                     "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "ms_per_eval": p["ms"] / B,
-                                     "evaluations_per_factorisation": B}
-        roof_other["potrf_whole"]["frac"] = roof_other["potrf_whole"]["achieved"] / PEAK_FP64_MFMA_TFLOPS
-        ctx.prof_begin(abi.PROF_FILL)
-        for i in range(3):
-            ctx.loglik_enqueue(theta(4000 + i))
-        p = ctx.prof_end()
-        gbs = p["bytes"] / (p["ms"] * 1e-3) / 1e9
-        roof_other["cov_fill"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                  "frac": gbs / PEAK_HBM_GBS, "avg_launch_us": p["ms"] * 1e3 / max(p["n"], 1)}
         if pred is not None:
             ctx.predict_setup(synth.default_thetas(kind, d))
             ctx.prof_begin(abi.PROF_GEMM)
