@@ -307,7 +307,7 @@ def main():
     roof, roof_other = None, {}
     if rank == 0:
         # the dominant kernel = gemm_nt_kernel<128,128,4,4,2,1,0,0,1> (128x128 tiles, 8 waves, operands by LDS-DMA): every
-        # update of a lock-step batch with >= 1024 such tiles (contraction lengths 256 .. 2048), 95 % of its flops and
+        # update of a lock-step batch with >= 1024 such tiles and n >= 256 (contraction lengths 256 .. 2048), 95 % of its flops and
         # 80 % of the GPU time of this bench (profiles/r02_rocprofv3_kernel_stats_*)
         ctx.prof_begin(abi.PROF_GEMM_BIG)
         ctx.loglik_batch_enqueue(np.array([theta(2000 + i) for i in range(B)]))     # one lock-step batch, as timed above

@@ -772,6 +772,10 @@ int choose_gemm_cfg(const GemmArgs &a)
 	// one matrix per launch: twice the threshold -- 1000-2000 tiles on the 512 resident workgroups of the chip are 2-4
 	// rounds, and the partly filled last one costs more than the faster tile gains (6.3 against 6.2 ms per evaluation)
 	const long thr = (a.nbatch > 1 || g_gemm_big_tiles < 64) ? g_gemm_big_tiles : 2L * g_gemm_big_tiles;   // (< 64: test settings, taken literally)
+	// updates narrower than two 128-column tiles stay on 64x64 tiles however many rows they have (the tall matrices of the
+	// gradient path reach any tile count at n = 64): half of a 128-wide tile would be idle there, and only the 64x64
+	// tiles carry the factor-ahead epilogue (value+gradient batch 158.4 -> 155.4 ms)
+	if (a.n < 256 && g_gemm_big_tiles >= 64) return 2;
 	return count_tiles(a, 128, 128) * (a.nbatch > 1 ? a.nbatch : 1) >= thr ? g_gemm_big_cfg : 2;
 }
 
