@@ -143,6 +143,19 @@ int gpemu_loglik_grad(gpemu_ctx *ctx, const double *thetas, int nthetas, double 
 int gpemu_loglik_grad_batch(gpemu_ctx *ctx, int nb, const double *thetas, int nthetas,
                             double *neg_loglik, double *sigma2, double *beta, double *grad,
                             int *info, int *status);
+/* the same in two halves, like gpemu_loglik_batch_enqueue / _collect[_back]: enqueue puts the whole value+gradient
+ * batch on the context's stream (staging, factorisation with inverse rows, C^-1 = U U^T, the gradient reductions, one
+ * small copy into the pinned result ring) and returns without waiting -- no host synchronisation inside; collect waits
+ * for THAT batch only and finishes on the host (the nreg x nreg solve and the reference's scalings, maxmultimin.c:
+ * 503-535).  The ring is shared with the likelihood batches (GPEMU_RESULT_RING entries, `back` counts batches of
+ * either kind; collecting a batch with the entry of the other kind is GPEMU_ERR_STATE).  A restart pool keeps two
+ * contexts busy this way while its host threads do their BFGS arithmetic (estimate_threaded.c:172-188 keeps every
+ * core busy; here: the device).  gpemu_loglik_grad_batch, gpemu_loglik_grad and gpemu_grad are enqueue + collect. */
+int gpemu_loglik_grad_batch_enqueue(gpemu_ctx *ctx, int nb, const double *thetas, int nthetas);
+int gpemu_loglik_grad_batch_collect(gpemu_ctx *ctx, int nb, double *neg_loglik, double *sigma2, double *beta,
+                                    double *grad, int *info, int *status);
+int gpemu_loglik_grad_batch_collect_back(gpemu_ctx *ctx, int back, int nb, double *neg_loglik, double *sigma2,
+                                         double *beta, double *grad, int *info, int *status);
 
 /* ---- a14/a15: chol_inverse_cov_matrix + alloc_emulator_struct -------
  * (libEmu/emulate-fns.c:275-299, emulator_struct.c:13-37)
@@ -173,9 +186,14 @@ int gpemu_chol_inverse(gpemu_ctx *ctx, int n, double *a_inout, int lda, double *
  * (libEmu/regression.c:120-176, estimator-fns.c:38-103, emulator.c:672-785) with C^-1 passed in host memory:
  * out[v*n + i] = sum_j a[i*lda + j] * v_rows[v*n + j] for nvec vectors stored as rows.  The matrix is uploaded when
  * its (pointer, size, 64-bit checksum over ALL its elements) differs from the copy the context holds: callers such as
- * the libRbind loops rewrite one cinverse buffer in place.  gpemu_symm_invalidate drops the cached copy explicitly. */
+ * the libRbind loops rewrite one cinverse buffer in place.  Cost per call with an unchanged matrix: one checksum pass
+ * over its n*n doubles in host memory (0.1 s at n = 8192) -- gpemu_symm_pin(ctx, 1) is the caller's promise that the
+ * buffer stays as it is until gpemu_symm_pin(ctx, 0) / gpemu_symm_invalidate, and removes that pass (the reference's
+ * per-point loops over one cinverse, emulator.c:672-785, are such callers).  gpemu_symm_invalidate drops the cached
+ * copy: the next call uploads without comparing. */
 int gpemu_symm_apply(gpemu_ctx *ctx, int n, const double *a, int lda, int nvec, const double *v_rows, double *out_rows);
 int gpemu_symm_invalidate(gpemu_ctx *ctx);
+int gpemu_symm_pin(gpemu_ctx *ctx, int pinned);
 /* a5 derivative_l_gauss (libEmu/emulator.c:173-209) written out: out[i*ldo + j] = exp(-0.5 e^{-2t} D^2 - 2t) D^2,
  * D = xcol[i] - xcol[j] (the ONE design coordinate the reference's formula looks at), t = theta_len */
 int gpemu_derivative_gauss(gpemu_ctx *ctx, int n, const double *xcol, double theta_len, double *out, int ldo);
@@ -219,9 +237,8 @@ int gpemu_trace_dump(gpemu_ctx *ctx, const char *path);
  * alpha must be +1 or -1 (the accumulators start from C/alpha) */
 int gpemu_test_gemm_nt(gpemu_ctx *ctx, int m, int n, int k, double alpha, int beta,
                        const double *a, const double *b, double *c);
-/* micro-benchmark of one GEMM shape on device-resident random operands: cfg -1 = heuristic, 0 = 128x128 tiles
- * with 4 waves, 1 = 128x64, 2 = 64x64, 3 = 128x128 with 8 waves; tri = lower-trapezoid update as in the
- * factorisation; HIP-event timed. */
+/* micro-benchmark of one GEMM shape on device-resident random operands: cfg 0 = the automatic tile choice, 2 = 64x64
+ * tiles (4 waves), 8 = 128x128 tiles (8 waves); tri = lower-trapezoid update as in the factorisation; HIP-event timed. */
 int gpemu_test_gemm_bench(gpemu_ctx *ctx, int m, int n, int k, int ld, int cfg, int tri, int beta, int reps,
                           double *ms_avg, double *flops);
 /* in-place lower Cholesky of a host n*n matrix (both triangles read as lower);

@@ -42,6 +42,9 @@ SYMBOLS = {
     "gpemu_grad": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _ip]),
     "gpemu_loglik_grad": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _dp, _dp, _dp, _ip]),
     "gpemu_loglik_grad_batch": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, _dp, _dp, _dp, _dp, _ip, _ip]),
+    "gpemu_loglik_grad_batch_enqueue": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int]),
+    "gpemu_loglik_grad_batch_collect": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _ip, _ip]),
+    "gpemu_loglik_grad_batch_collect_back": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _ip, _ip]),
     "gpemu_predict_setup": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _ip]),
     "gpemu_get_cinverse": (C.c_int, [C.c_void_p, _dp]),
     "gpemu_predict_batch": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
@@ -51,6 +54,7 @@ SYMBOLS = {
     "gpemu_chol_inverse": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, _dp, _ip]),
     "gpemu_symm_apply": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp]),
     "gpemu_symm_invalidate": (C.c_int, [C.c_void_p]),
+    "gpemu_symm_pin": (C.c_int, [C.c_void_p, C.c_int]),
     "gpemu_set_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "gpemu_get_mode": (C.c_int, [C.c_void_p]),
     "gpemu_derivative_gauss": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_double, _dp, C.c_int]),
@@ -235,6 +239,28 @@ class Context:
                                                  info.ctypes.data_as(_ip), status.ctypes.data_as(_ip)))
         return dict(value=v, sigma2=s2, beta=beta, grad=g, info=info, status=status)
 
+    def loglik_grad_batch_enqueue(self, thetas):
+        """puts a value+gradient batch on the context's stream and returns at once"""
+        th = _a(thetas).reshape(-1, np.shape(thetas)[-1])
+        self._gnb, self._gnt = th.shape
+        self._chk(self.L.gpemu_loglik_grad_batch_enqueue(self.h, th.shape[0], _p(th), th.shape[1]))
+
+    def loglik_grad_batch_collect_back(self, back, nb=None, nthetas=None):
+        """results of the value+gradient batch enqueued `back` batches before the newest; waits for it only"""
+        nb = self._gnb if nb is None else nb
+        nt = self._gnt if nthetas is None else nthetas
+        v, s2 = np.full(nb, np.nan), np.full(nb, np.nan)
+        beta = np.full((nb, self.nreg), np.nan)
+        g = np.full((nb, nt - 1), np.nan)
+        info = np.zeros(nb, dtype=np.int32)
+        status = np.zeros(nb, dtype=np.int32)
+        self._chk(self.L.gpemu_loglik_grad_batch_collect_back(self.h, back, nb, _p(v), _p(s2), _p(beta), _p(g),
+                                                              info.ctypes.data_as(_ip), status.ctypes.data_as(_ip)))
+        return dict(value=v, sigma2=s2, beta=beta, grad=g, info=info, status=status)
+
+    def loglik_grad_batch_collect(self):
+        return self.loglik_grad_batch_collect_back(0)
+
     # -- a12 ---------------------------------------------------------------
     def grad(self, thetas):
         th = _a(thetas)
@@ -293,6 +319,9 @@ class Context:
 
     def symm_invalidate(self):
         self._chk(self.L.gpemu_symm_invalidate(self.h))
+
+    def symm_pin(self, pinned=True):
+        self._chk(self.L.gpemu_symm_pin(self.h, 1 if pinned else 0))
 
     def derivative_gauss(self, xcol, theta_len):
         xcol = _a(xcol)
@@ -362,7 +391,7 @@ class Context:
     def trace_dump(self, path):
         self._chk(self.L.gpemu_trace_dump(self.h, str(path).encode()))
 
-    def gemm_bench(self, m, n, k, ld=0, cfg=-1, tri=0, beta=1, reps=5):
+    def gemm_bench(self, m, n, k, ld=0, cfg=0, tri=0, beta=1, reps=5):
         ms, fl = C.c_double(0), C.c_double(0)
         self._chk(self.L.gpemu_test_gemm_bench(self.h, m, n, k, ld, cfg, tri, beta, reps, C.byref(ms), C.byref(fl)))
         return ms.value, fl.value

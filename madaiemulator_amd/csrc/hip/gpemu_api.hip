@@ -24,15 +24,6 @@ using namespace gpemu;
 		}                                                                                       \
 	} while (0)
 
-static int g_leaf128 = 0;                // 128-column fused leaves (env GPEMU_LEAF128=1); measured 3 % slower than 64
-static int g_lookahead = 0;              // two-stream schedule of the outer panels (env GPEMU_LOOKAHEAD=1); see DESIGN.md
-static int g_factor_ahead = 1;           // the update's tile (0,0) factors the next diagonal block (env GPEMU_FACTOR_AHEAD=0: off)
-static int g_solve_ahead = 0;            // one matrix per launch: tile column 0 of the update also solves its rows (env GPEMU_SOLVE_AHEAD=1: on;
-                                         // off by default: it is the one place where workgroups wait for each other, and it buys 3 %)
-static int g_panel_trsm = 0;             // diag-first panels of up to this many columns + one panel_trsm pass (env GPEMU_PANEL_TRSM=512;
-                                         // 0 = off, the default: bit-identical and measured slower)
-static int g_fill_gram = 1;              // MFMA Gram form of the training fill (env GPEMU_FILL_GRAM=0: difference form always)
-static int g_nb_top = 0;            // outer panel width (env GPEMU_NB_TOP); 0 = automatic: 512 for one matrix, 2048 for a lock-step batch
 constexpr int INFO_NONE = 0x7f7f7f7f;   // "no failed pivot": what hipMemsetAsync(.., 0x7f, ..) leaves in *info
 
 static int fail(gpemu_ctx *ctx, int code, const char *msg)
@@ -101,12 +92,14 @@ static double gemm_flops(const GemmArgs &a)
 	return fl;
 }
 
-static hipError_t gemm(gpemu_ctx *ctx, const GemmArgs &a_in, hipStream_t stream = nullptr)
+static hipError_t gemm(gpemu_ctx *ctx, const GemmArgs &a_in)
 {
 	GemmArgs a = a_in;
+	a.big_tiles = ctx->sched.gemm_big_tiles;
+	a.table_sb = ctx->sched.gemm_table;
 	a.trace = trace_slot(ctx, "gemm m=%d n=%d k=%d", a.m, a.n, a.k1 - a.k0);
 	// GPEMU_PROF_GEMM: every GEMM launch; GPEMU_PROF_GEMM_BIG: only the launches that run the 128x128 8-wave kernel
-	// (gemm_nt_kernel<128,128,4,4,2,1,0,0,1>, the dominant kernel of a batched factorisation); GPEMU_PROF_GEMM_K512: only
+	// (gemm_nt_kernel<128,128,4,4,2,0>, the dominant kernel of a batched factorisation); GPEMU_PROF_GEMM_K512: only
 	// those with a contraction length of 512 or more (the compute-bound updates)
 	const int cls = (prof_on(ctx, GPEMU_PROF_GEMM_BIG) && gemm_uses_big_tiles(a)) ? GPEMU_PROF_GEMM_BIG :
 	                (prof_on(ctx, GPEMU_PROF_GEMM_K512) && a.k1 - a.k0 >= 512) ? GPEMU_PROF_GEMM_K512 : GPEMU_PROF_GEMM;
@@ -117,7 +110,7 @@ static hipError_t gemm(gpemu_ctx *ctx, const GemmArgs &a_in, hipStream_t stream 
 		snprintf(buf, sizeof buf, "gemm m=%d n=%d k=%d tri=%d flops=%.4g", a.m, a.n, a.k1 - a.k0, a.tri, fl);
 		ctx->prof.tag.push_back(buf);
 	}
-	return launch_gemm(stream ? stream : ctx->stream, a);
+	return launch_gemm(ctx->stream, a);
 }
 
 // ---------------------------------------------------------------------------
@@ -132,27 +125,20 @@ extern "C" int gpemu_device_count(void)
 	return n;
 }
 
-// process-wide tunables, read from the environment every time a context is created (INTEGRATION.md lists them): a
-// variable that is absent or out of range gives the default, so the last context created decides for the process
-static void read_environment()
+// the schedule switches of a new context (gpemu::Sched): a variable that is absent or out of range gives the default
+static Sched read_environment()
 {
 	auto geti = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
+	Sched sc;
 	int v = geti("GPEMU_GEMM_BIG_TILES", 1024);
-	gpemu::g_gemm_big_tiles = v > 0 ? v : 1024;
-	gpemu::g_gemm_big_cfg = geti("GPEMU_GEMM_BIG_CFG", 8);
-	gpemu::g_gemm_small_dma = geti("GPEMU_GEMM_SMALL_DMA", 1) != 0;
+	sc.gemm_big_tiles = v > 0 ? v : 1024;
 	v = geti("GPEMU_GEMM_TABLE", 8);
-	gpemu::g_gemm_table = v >= 0 && v <= 64 ? v : 8;
-	g_lookahead = geti("GPEMU_LOOKAHEAD", 0) != 0;
-	gpemu::g_la_bulk_cfg = geti("GPEMU_LA_BULK_CFG", 8);
-	g_leaf128 = geti("GPEMU_LEAF128", 0) != 0;
-	g_fill_gram = geti("GPEMU_FILL_GRAM", 1) != 0;
-	g_factor_ahead = geti("GPEMU_FACTOR_AHEAD", 1) != 0;
-	g_solve_ahead = geti("GPEMU_SOLVE_AHEAD", 0) != 0;
-	v = geti("GPEMU_PANEL_TRSM", 0);
-	g_panel_trsm = (v >= 2 * LEAF && v <= 2048) ? (v / LEAF) * LEAF : 0;
+	sc.gemm_table = v >= 0 && v <= 64 ? v : 8;
+	sc.fill_gram = geti("GPEMU_FILL_GRAM", 1) != 0;
+	sc.factor_ahead = geti("GPEMU_FACTOR_AHEAD", 1) != 0;
 	v = geti("GPEMU_NB_TOP", 0);
-	g_nb_top = v >= LEAF ? (v / LEAF) * LEAF : 0;
+	sc.nb_top = v >= LEAF ? (v / LEAF) * LEAF : 0;
+	return sc;
 }
 
 extern "C" int gpemu_ctx_create(gpemu_ctx **out, int device)
@@ -163,41 +149,20 @@ extern "C" int gpemu_ctx_create(gpemu_ctx **out, int device)
 	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return GPEMU_ERR_NO_DEVICE;
 	if (device < 0 || device >= n) return GPEMU_ERR_ARG;
 	if (hipSetDevice(device) != hipSuccess) return GPEMU_ERR_HIP;
-	read_environment();
 	gpemu_ctx *ctx = new gpemu_ctx();
+	ctx->sched = read_environment();
 	ctx->device = device;
 	ctx->res_len = 64 * 64 + 8;
 	ctx->batch_cap = 1;
 	int least = 0, greatest = 0;
 	if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = 0; greatest = 0; }
 	bool ok = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, greatest) == hipSuccess;
-	if (ok && g_lookahead) {
-		// Only the look-ahead schedule uses a second stream (lowest priority: the bulk of a trailing update).  The chain
-		// kernels on the critical stream get their share of a CU through wave priority (s_setprio) and through the half
-		// occupancy of the bulk launches (GemmArgs.half_occ), not through a partition of the chip; GPEMU_RESERVE_CUS > 0
-		// (an experiment of round 2: CU-masked second stream) still exists behind its variable.
-		int reserve = 0, ncu = 256;
-		const char *rs = getenv("GPEMU_RESERVE_CUS");
-		if (rs) reserve = atoi(rs);
-		hipDeviceProp_t prop;
-		if (hipGetDeviceProperties(&prop, device) == hipSuccess) ncu = prop.multiProcessorCount;
-		hipError_t e2 = hipErrorUnknown;
-		if (reserve > 0 && reserve < ncu) {
-			std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-			for (int i = 0; i < ncu - reserve; i++) mask[i / 32] |= (1u << (i % 32));
-			e2 = hipExtStreamCreateWithCUMask(&ctx->stream2, (uint32_t)mask.size(), mask.data());
-		}
-		if (e2 != hipSuccess) {
-			(void)hipGetLastError();
-			e2 = hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, least);
-		}
-		ok = e2 == hipSuccess;
-	}
 	ok = ok && hipMalloc(&ctx->dInfo, sizeof(int)) == hipSuccess &&
-	     hipMalloc(&ctx->dDiagInv, (size_t)GPEMU_MAX_BATCH * 8 * 256 * sizeof(double)) == hipSuccess &&
 	     hipMalloc(&ctx->dRes, ctx->res_len * sizeof(double)) == hipSuccess &&
 	     hipHostMalloc((void **)&ctx->hResRing, (size_t)gpemu_ctx::RES_RING * ctx->res_len * sizeof(double)) == hipSuccess &&
-	     hipHostMalloc((void **)&ctx->hInfoRing, (size_t)gpemu_ctx::RES_RING * sizeof(int)) == hipSuccess;
+	     hipHostMalloc((void **)&ctx->hInfoRing, (size_t)gpemu_ctx::RES_RING * sizeof(int)) == hipSuccess &&
+	     hipMalloc(&ctx->dGradSum, (size_t)gpemu_ctx::GRAD_NP_MAX * sizeof(double)) == hipSuccess &&
+	     hipHostMalloc((void **)&ctx->hGradRing, (size_t)gpemu_ctx::RES_RING * gpemu_ctx::GRAD_NP_MAX * sizeof(double)) == hipSuccess;
 	for (int i = 0; ok && i < gpemu_ctx::RES_RING; i++)
 		ok = hipEventCreateWithFlags(&ctx->res_ev[i], hipEventDisableTiming) == hipSuccess;
 	ctx->hRes = ctx->hResRing; ctx->hInfo = ctx->hInfoRing;
@@ -245,26 +210,24 @@ extern "C" void gpemu_ctx_destroy(gpemu_ctx *ctx)
 	if (!ctx) return;
 	hipSetDevice(ctx->device);
 	if (ctx->stream) hipStreamSynchronize(ctx->stream);
-	if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
 	free_model(ctx);
 	for (auto e : ctx->prof.ev) hipEventDestroy(e);
 	if (ctx->dInfo) hipFree(ctx->dInfo);
-	if (ctx->dFlags) hipFree(ctx->dFlags);
 	if (ctx->dTrace) hipFree(ctx->dTrace);
 	if (ctx->dParams) hipFree(ctx->dParams);
 	if (ctx->hParams) hipHostFree(ctx->hParams);
 	for (auto e : ctx->param_ev) if (e) hipEventDestroy(e);
-	if (ctx->dDiagInv) hipFree(ctx->dDiagInv);
 	if (ctx->dSym) hipFree(ctx->dSym);
 	if (ctx->dSymV) hipFree(ctx->dSymV);
 	if (ctx->dSymOut) hipFree(ctx->dSymOut);
 	if (ctx->dRes) hipFree(ctx->dRes);
 	if (ctx->hResRing) hipHostFree(ctx->hResRing);
 	if (ctx->hInfoRing) hipHostFree(ctx->hInfoRing);
+	if (ctx->dGradSum) hipFree(ctx->dGradSum);
+	if (ctx->hGradRing) hipHostFree(ctx->hGradRing);
+	if (ctx->hGph) hipHostFree(ctx->hGph);
 	for (auto e : ctx->res_ev) if (e) hipEventDestroy(e);
 	if (ctx->hStage) hipHostFree(ctx->hStage);
-	for (auto e : ctx->ev_pool) hipEventDestroy(e);
-	if (ctx->stream2) hipStreamDestroy(ctx->stream2);
 	if (ctx->stream) hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -348,6 +311,9 @@ static int ensure_batch_slots(gpemu_ctx *ctx, int nb)
 	if (ctx->hResRing) hipHostFree(ctx->hResRing);
 	if (ctx->hInfoRing) hipHostFree(ctx->hInfoRing);
 	if (ctx->dGramPart) hipFree(ctx->dGramPart);
+	if (ctx->dGradSum) hipFree(ctx->dGradSum);
+	if (ctx->hGradRing) hipHostFree(ctx->hGradRing);
+	ctx->dGradSum = nullptr; ctx->hGradRing = nullptr;
 	ctx->dInfo = nullptr; ctx->dRes = nullptr; ctx->hRes = ctx->hResRing = nullptr; ctx->hInfo = ctx->hInfoRing = nullptr; ctx->dGramPart = nullptr;
 	ctx->res_seq = 0;                      // results still in the old ring are gone with it
 	HIPCHK(ctx, hipMalloc(&ctx->dInfo, (size_t)nb * sizeof(int)));
@@ -356,6 +322,8 @@ static int ensure_batch_slots(gpemu_ctx *ctx, int nb)
 	HIPCHK(ctx, hipHostMalloc((void **)&ctx->hInfoRing, (size_t)gpemu_ctx::RES_RING * nb * sizeof(int)));
 	ctx->hRes = ctx->hResRing; ctx->hInfo = ctx->hInfoRing;
 	HIPCHK(ctx, hipMalloc(&ctx->dGramPart, (size_t)nb * (ctx->Np / 64) * ctx->Rp * ctx->Rp * sizeof(double)));
+	HIPCHK(ctx, hipMalloc(&ctx->dGradSum, (size_t)nb * gpemu_ctx::GRAD_NP_MAX * sizeof(double)));
+	HIPCHK(ctx, hipHostMalloc((void **)&ctx->hGradRing, (size_t)gpemu_ctx::RES_RING * nb * gpemu_ctx::GRAD_NP_MAX * sizeof(double)));
 	ctx->batch_cap = nb;
 	return GPEMU_OK;
 }
@@ -456,7 +424,7 @@ static int make_cov_params(gpemu_ctx *ctx, const double *thetas, int nthetas, Co
 	// Gram form of the training fill (kernels_cov.hip): only while the centred, scaled design stays small -- the
 	// cancellation error of |x'|^2 + |y'|^2 - 2 x'.y' is a few ulp of 2 * norm2
 	p->gram = 0; p->cand_g = 0.0;
-	if (g_fill_gram && ctx->dXg && (int)ctx->xhalf.size() == ctx->d) {
+	if (ctx->sched.fill_gram && ctx->dXg && (int)ctx->xhalf.size() == ctx->d) {
 		double norm2 = 0.0;
 		for (int k = 0; k < ctx->d; k++) {
 			const double t = ctx->xhalf[k] * p->w[ctx->kind == GPEMU_POWEREXP ? k : 0];
@@ -477,17 +445,14 @@ static int make_cov_params(gpemu_ctx *ctx, const double *thetas, int nthetas, Co
 //   T rows [Np+Rp,Np+Rp+Np)  : identity -> U = L^-T (only with inv)
 // potrf_rec(c0,n) factors the column panel [c0,c0+n) for every row below it.
 // ---------------------------------------------------------------------------
-// *fa_done (optional): set when the update ran with the factor-ahead tile, i.e. the 64x64 diagonal block at c0+k is
-// already factored when the update has finished and the next leaf must not factor it again
-static hipError_t trailing_update(gpemu_ctx *ctx, int c0, int k, int col_off, int ncols, int inv, hipStream_t stream = nullptr,
-                                  bool *fa_done = nullptr, bool *sa_done = nullptr, int row_limit = INT_MAX)
+// *fa_done: set when the update ran with the factor-ahead tile, i.e. the 64x64 diagonal block at c0+k is already
+// factored when the update has finished and the next leaf must not factor it again
+static hipError_t trailing_update(gpemu_ctx *ctx, int c0, int k, int ncols, int inv, bool *fa_done)
 {
-	// C[rows >= r0, cols r0 .. r0+ncols) -= P P^T with P = the factored panel columns [c0, c0+k) and
-	// r0 = c0 + k + col_off (rows above r0 belong to the upper triangle of those columns)
+	// C[rows >= r0, cols r0 .. r0+ncols) -= P P^T with P = the factored panel columns [c0, c0+k) and r0 = c0 + k
 	const long ld = ctx->Np;
-	const int r0 = c0 + k + col_off;
-	const int row_end = std::min(ctx->Np + ctx->Rp + (inv ? c0 + k : 0), row_limit);   // identity rows < c0+k have fill-in in the panel
-	if (row_end <= r0) { if (fa_done) *fa_done = false; if (sa_done) *sa_done = false; return hipSuccess; }
+	const int r0 = c0 + k;
+	const int row_end = ctx->Np + ctx->Rp + (inv ? c0 + k : 0);   // identity rows < c0+k have fill-in in the panel
 	GemmArgs g;
 	memset(&g, 0, sizeof g);
 	g.C = ctx->dT + (long)r0 * ld + r0;
@@ -500,74 +465,27 @@ static hipError_t trailing_update(gpemu_ctx *ctx, int c0, int k, int col_off, in
 	g.alpha = -1.0; g.beta = 1;
 	g.tri = 1; g.diag_off = 0;
 	g.nbatch = ctx->nb; g.bsC = g.bsA = g.bsB = (long)ctx->T_stride;
-	if (fa_done) {
-		*fa_done = false;
-		g.fa = (g_factor_ahead && !g_leaf128 && col_off == 0 && !stream) ? 1 : 0;
-		g.fa_c0 = r0;
-		g.fa_info = ctx->dInfo;
-		if (g.fa && gemm_factor_ahead_ok(g)) *fa_done = true;
-		else g.fa = 0;
-		if (sa_done) {
-			*sa_done = false;
-			const int blk = r0 / LEAF;
-			// (not with the inverse rows: the next leaf's row range then reaches 64 identity rows beyond this update's)
-			if (g.fa && g_solve_ahead && ctx->nb <= 1 && !inv && ctx->dFlags && blk < ctx->flags_len && ncols >= LEAF && g.m % LEAF == 0) {
-				g.sa = 1;
-				g.sa_flag = ctx->dFlags + blk;
-				*sa_done = true;
-			}
-		}
-	}
-	// look-ahead schedule (one matrix per launch, two streams): the chain's launches raise their wave priority, the bulk
-	// update beside them runs at half occupancy so that a chain workgroup finds registers and LDS on every CU at once
-	if (g_lookahead && ctx->stream2) { g.prio = stream ? 0 : 1; g.half_occ = stream ? 1 : 0; }
-	return gemm(ctx, g, stream);
-}
-
-static hipEvent_t next_event(gpemu_ctx *ctx)
-{
-	if (ctx->ev_next == ctx->ev_pool.size()) {
-		hipEvent_t e;
-		hipEventCreateWithFlags(&e, hipEventDisableTiming);
-		ctx->ev_pool.push_back(e);
-	}
-	return ctx->ev_pool[ctx->ev_next++];
+	g.big_tiles = ctx->sched.gemm_big_tiles;                      // (gemm() sets these too: needed here for the tile-shape question)
+	g.fa = ctx->sched.factor_ahead ? 1 : 0;
+	g.fa_c0 = r0;
+	g.fa_info = ctx->dInfo;
+	*fa_done = g.fa && gemm_factor_ahead_ok(g);
+	if (!*fa_done) g.fa = 0;
+	return gemm(ctx, g);
 }
 
 // diag_done: the 64x64 diagonal block at (c0,c0) is already factored (by the factor-ahead tile of the update before)
-// solve_done: the rows under that block are solved as well (solve-ahead tiles of the same update)
-// row_limit: rows at or beyond it are not touched (the diagonal-block phase of a diag-first panel)
-static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv, bool diag_done = false, bool solve_done = false,
-                            int row_limit = INT_MAX)
+static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv, bool diag_done = false)
 {
 	const long ld = ctx->Np;
 	const int base_end = ctx->Np + ctx->Rp;
-	if (n > LEAF && n <= g_panel_trsm && row_limit == INT_MAX && !g_leaf128 && !(g_lookahead && ctx->stream2)) {
-		// Diag-first panel: factor the n x n diagonal block with the recursion below restricted to its own rows (small,
-		// cache-resident launches), then solve ALL rows under it against the whole block in one pass
-		// (panel_trsm_kernel: one read-modify-write of the panel instead of the recursion's log2(n/64) levels + n/64
-		// leaf solves over every row).  Same arithmetic in the same order per element: same bits.
-		hipError_t e = potrf_rec(ctx, c0, n, inv, diag_done, solve_done, c0 + n);
-		if (e != hipSuccess) return e;
-		const int row_end = base_end + (inv ? c0 + n : 0);
-		ProfScope ps(ctx, GPEMU_PROF_LEAF, 0.0, 0.0);
-		unsigned long long *tr = trace_slot(ctx, "panel_trsm c0=%d n=%d m=%d", c0, n, row_end - (c0 + n));
-		return launch_panel_trsm(ctx->stream, ctx->dT, ld, c0, n, (diag_done && solve_done) ? 1 : 0, c0 + n, row_end - (c0 + n),
-		                         ctx->nb, (long)ctx->T_stride, tr);
-	}
 	if (n <= LEAF) {
-		const int row_end = std::min(base_end + (inv ? c0 + LEAF : 0), row_limit);
+		const int row_end = base_end + (inv ? c0 + LEAF : 0);
 		ProfScope ps(ctx, GPEMU_PROF_LEAF, 0.0, 0.0);
 		unsigned long long *trf = trace_slot(ctx, "leaf_factor c0=%d", c0);
 		unsigned long long *trs = trace_slot(ctx, "leaf_solve c0=%d m=%d", c0, row_end - (c0 + LEAF));
 		return launch_leaf(ctx->stream, ctx->dT, ld, c0, row_end - (c0 + LEAF), ctx->dInfo, trf, trs, ctx->nb,
-		                   (long)ctx->T_stride, diag_done, diag_done && solve_done, (g_lookahead && ctx->stream2) ? 1 : 0);
-	}
-	if (n == 2 * LEAF && g_leaf128) {
-		const int row_end = base_end + (inv ? c0 + 2 * LEAF : 0);
-		ProfScope ps(ctx, GPEMU_PROF_LEAF, 0.0, 0.0);
-		return launch_leaf128(ctx->stream, ctx->dT, ld, c0, row_end - (c0 + 2 * LEAF), ctx->dInfo, ctx->dDiagInv, ctx->nb,
-		                      (long)ctx->T_stride);
+		                   (long)ctx->T_stride, diag_done);
 	}
 	// automatic outer panel width: a batch has enough tiles per launch to afford the longer panel chain of a wider
 	// panel and gains from the larger K of its trailing updates and the fewer read-modify-write passes over the
@@ -575,70 +493,35 @@ static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv, bool diag_do
 	// epilogue; 3.329 at 1024, 3.302 at 2048, 3.314 at 4096 now; 2048 also wins at N = 4096, 12288, 16384)
 	// With the inverse rows under the matrix (gradient, explicit inverse) 1024 is better again: 10.40 against 10.77 ms
 	// per value+gradient evaluation in batches of 16.
-	const int nb_top = g_nb_top > 0 ? g_nb_top : (ctx->nb >= 2 ? (inv ? 1024 : 2048) : 512);
+	const int nb_top = ctx->sched.nb_top > 0 ? ctx->sched.nb_top : (ctx->nb >= 2 ? (inv ? 1024 : 2048) : 512);
 	if (n > nb_top) {
 		// right-looking over panels of nb_top columns: the trailing update touches the whole remaining
 		// matrix (thousands of tiles, K = panel width), which fills the chip far better than the few huge-K
 		// tiles a pure recursion would produce at the top levels
-		const bool profiling = ctx->prof.cls != GPEMU_PROF_NONE && ctx->prof.cls != GPEMU_PROF_POTRF;
-		const bool ahead = g_lookahead && ctx->stream2 && !profiling && c0 == 0 && n == ctx->Np;
-		hipEvent_t ev_bulk_prev = nullptr;
-		bool next_done = diag_done, next_solved = solve_done;
+		bool next_done = diag_done;
 		for (int c = c0; c < c0 + n; c += nb_top) {
 			const int nb = std::min(nb_top, c0 + n - c);
-			hipError_t e = potrf_rec(ctx, c, nb, inv, next_done, next_solved, row_limit);
-			next_done = false; next_solved = false;
+			hipError_t e = potrf_rec(ctx, c, nb, inv, next_done);
+			next_done = false;
 			if (e != hipSuccess) return e;
 			const int rest = c0 + n - (c + nb);
 			if (rest <= 0) continue;
-			if (!ahead) {
-				e = trailing_update(ctx, c, nb, 0, rest, inv, nullptr, &next_done, &next_solved, row_limit);
-				if (e != hipSuccess) return e;
-				continue;
-			}
-			// look-ahead: the next panel's columns are updated on the critical stream so that its
-			// factorisation (a chain of small latency-bound kernels) can start at once, while the bulk of the
-			// update runs beside it on the second stream.  Both pieces touch disjoint column ranges; the piece
-			// of step j on the critical stream waits for the bulk of step j-1, which updated the same columns.
-			const int nb_next = std::min(nb_top, rest);
-			hipEvent_t ev_panel = next_event(ctx);
-			e = hipEventRecord(ev_panel, ctx->stream);
-			if (e != hipSuccess) return e;
-			if (ev_bulk_prev) {
-				e = hipStreamWaitEvent(ctx->stream, ev_bulk_prev, 0);
-				if (e != hipSuccess) return e;
-				ev_bulk_prev = nullptr;
-			}
-			e = trailing_update(ctx, c, nb, 0, nb_next, inv, nullptr, &next_done, &next_solved);
-			if (e != hipSuccess) return e;
-			if (rest > nb_next) {
-				e = hipStreamWaitEvent(ctx->stream2, ev_panel, 0);
-				if (e != hipSuccess) return e;
-				e = trailing_update(ctx, c, nb, nb_next, rest - nb_next, inv, ctx->stream2);
-				if (e != hipSuccess) return e;
-				ev_bulk_prev = next_event(ctx);
-				e = hipEventRecord(ev_bulk_prev, ctx->stream2);
-				if (e != hipSuccess) return e;
-			}
-		}
-		if (ev_bulk_prev) {
-			hipError_t e = hipStreamWaitEvent(ctx->stream, ev_bulk_prev, 0);
+			e = trailing_update(ctx, c, nb, rest, inv, &next_done);
 			if (e != hipSuccess) return e;
 		}
 		return hipSuccess;
 	}
 	const int n1 = ((n / LEAF + 1) / 2) * LEAF;
-	hipError_t e = potrf_rec(ctx, c0, n1, inv, diag_done, solve_done, row_limit);
+	hipError_t e = potrf_rec(ctx, c0, n1, inv, diag_done);
 	if (e != hipSuccess) return e;
-	bool right_done = false, right_solved = false;
-	e = trailing_update(ctx, c0, n1, 0, n - n1, inv, nullptr, &right_done, &right_solved, row_limit);
+	bool right_done = false;
+	e = trailing_update(ctx, c0, n1, n - n1, inv, &right_done);
 	if (e != hipSuccess) return e;
-	return potrf_rec(ctx, c0 + n1, n - n1, inv, right_done, right_solved, row_limit);
+	return potrf_rec(ctx, c0 + n1, n - n1, inv, right_done);
 }
 
 static int run_potrf(gpemu_ctx *ctx, int inv)
 {
-	ctx->ev_next = 0;
 	const bool profiling = ctx->prof.cls == GPEMU_PROF_GEMM || ctx->prof.cls == GPEMU_PROF_LEAF || ctx->prof.cls == GPEMU_PROF_GEMM_BIG ||
 	                       ctx->prof.cls == GPEMU_PROF_GEMM_K512;
 	if (ctx->dTrace) {
@@ -681,6 +564,8 @@ static int run_potrf(gpemu_ctx *ctx, int inv)
 }
 
 // fill C(theta_b) into matrix b of T (lower tiles only), load the RHS rows, reset the info words
+constexpr unsigned PARAM_RING = 4;
+
 static int stage_matrices(gpemu_ctx *ctx, const CovParams *ps, int nb, int inv)
 {
 	const int Np = ctx->Np, Rp = ctx->Rp;
@@ -691,14 +576,15 @@ static int stage_matrices(gpemu_ctx *ctx, const CovParams *ps, int nb, int inv)
 	// one upload of the nb hyper-parameter sets, one launch for the nb fills and R-row copies.  The upload goes through a
 	// pinned ring of four entries (a pageable source makes hipMemcpyAsync wait for the stream: enqueued batches of small
 	// models then take 6 us per evaluation instead of 2); an entry is reused once its own copy has executed.
-	constexpr unsigned PARAM_RING = 4;
 	if (!ctx->dParams) {
 		HIPCHK(ctx, hipMalloc(&ctx->dParams, (size_t)GPEMU_MAX_BATCH * sizeof(CovParams)));
 		HIPCHK(ctx, hipHostMalloc((void **)&ctx->hParams, (size_t)PARAM_RING * GPEMU_MAX_BATCH * sizeof(CovParams)));
+		HIPCHK(ctx, hipHostMalloc((void **)&ctx->hGph, (size_t)PARAM_RING * GPEMU_MAX_BATCH * GPEMU_MAX_PARAMS * sizeof(double)));
 		for (unsigned i = 0; i < PARAM_RING; i++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->param_ev[i], hipEventDisableTiming));
 	}
 	{
 		const unsigned slot = ctx->param_next++ % PARAM_RING;
+		ctx->param_slot = slot;
 		HIPCHK(ctx, hipEventSynchronize(ctx->param_ev[slot]));        // (a never-recorded event is complete)
 		CovParams *hp = ctx->hParams + (size_t)slot * GPEMU_MAX_BATCH;
 		memcpy(hp, ps, (size_t)nb * sizeof(CovParams));
@@ -714,16 +600,6 @@ static int stage_matrices(gpemu_ctx *ctx, const CovParams *ps, int nb, int inv)
 	if (inv)
 		HIPCHK(ctx, launch_set_identity_rows(ctx->stream, ctx->dT + (size_t)(Np + Rp) * Np, Np, Np, nb, (long)ctx->T_stride));
 	HIPCHK(ctx, hipMemsetAsync(ctx->dInfo, 0x7f, (size_t)nb * sizeof(int), ctx->stream));
-	// solve-ahead flags (one per 64-column block), zero before every factorisation
-	if (ctx->flags_len < Np / LEAF + 1) {
-		HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-		free_graphs(ctx);
-		if (ctx->dFlags) hipFree(ctx->dFlags);
-		ctx->dFlags = nullptr; ctx->flags_len = 0;
-		HIPCHK(ctx, hipMalloc(&ctx->dFlags, (size_t)(Np / LEAF + 1) * sizeof(int)));
-		ctx->flags_len = Np / LEAF + 1;
-	}
-	HIPCHK(ctx, hipMemsetAsync(ctx->dFlags, 0, (size_t)ctx->flags_len * sizeof(int), ctx->stream));
 	return GPEMU_OK;
 }
 
@@ -743,6 +619,7 @@ static int enqueue_results(gpemu_ctx *ctx)
 	ctx->hRes = ctx->hResRing + (size_t)slot * ctx->batch_cap * ctx->res_len;
 	ctx->hInfo = ctx->hInfoRing + (size_t)slot * ctx->batch_cap;
 	ctx->res_nb[slot] = nb;
+	ctx->res_kind[slot] = 0;
 	HIPCHK(ctx, hipMemcpyAsync(ctx->hRes, ctx->dRes, ((size_t)(nb - 1) * ctx->res_len + (size_t)Rp * Rp + 1) * sizeof(double),
 	                           hipMemcpyDeviceToHost, ctx->stream));
 	HIPCHK(ctx, hipMemcpyAsync(ctx->hInfo, ctx->dInfo, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -850,7 +727,6 @@ static int collect_one(gpemu_ctx *ctx, int b, double *neg_loglik, double *sigma2
 {
 	const int inf = (ctx->hInfo[b] >= INFO_NONE) ? 0 : ctx->hInfo[b];
 	if (info) *info = inf;
-	if (inf < 0) return fail(ctx, GPEMU_ERR_HIP, "device: a solve-ahead tile gave up waiting for its diagonal block");
 	if (inf != 0) {
 		if (neg_loglik) *neg_loglik = NAN;
 		if (sigma2) *sigma2 = NAN;
@@ -897,6 +773,7 @@ extern "C" int gpemu_loglik_batch_collect_back(gpemu_ctx *ctx, int back, int nb,
 		return fail(ctx, GPEMU_ERR_STATE, "no such batch in the result ring");
 	const int slot = (int)((ctx->res_seq - 1 - (unsigned long long)back) % gpemu_ctx::RES_RING);
 	if (nb < 1 || nb != ctx->res_nb[slot]) return fail(ctx, GPEMU_ERR_STATE, "batch size differs from the enqueued batch");
+	if (ctx->res_kind[slot] != 0) return fail(ctx, GPEMU_ERR_STATE, "that batch is a value+gradient batch: use gpemu_loglik_grad_batch_collect_back");
 	HIPCHK(ctx, hipEventSynchronize(ctx->res_ev[slot]));
 	double *saveR = ctx->hRes;
 	int *saveI = ctx->hInfo;
@@ -1008,7 +885,6 @@ static int factor_with_inverse(gpemu_ctx *ctx, const double *thetas, int nthetas
 	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 	const int inf = (*ctx->hInfo >= INFO_NONE) ? 0 : *ctx->hInfo;
 	if (info) *info = inf;
-	if (inf < 0) return fail(ctx, GPEMU_ERR_HIP, "device: a solve-ahead tile gave up waiting for its diagonal block");
 	if (inf) return fail(ctx, GPEMU_ERR_NOT_PD, "covariance matrix is not positive definite");
 	return GPEMU_OK;
 }
@@ -1239,39 +1115,16 @@ extern "C" int gpemu_get_cinverse(gpemu_ctx *ctx, double *cinv_out)
 }
 
 // ---------------------------------------------------------------------------
-// gradient (gradFnMulti, maxmultimin.c:416-550)
+// gradient (gradFnMulti, maxmultimin.c:416-550) and value+gradient (evalFnGradMulti, :615-618)
+//
+// One implementation for one evaluation and for a lock-step batch, in two halves:
+//   enqueue: stage nb matrices with their inverse rows, factor them in lock-step (U = L^-T falls out), Gram / log det
+//            as for a likelihood batch; then per chunk of corners C^-1 = U U^T (one batched GEMM), alpha = C^-1 y (or
+//            C^-1 (y - H beta) with beta solved on the device, exact mode), the tile reductions tr(C^-1 dC_k),
+//            alpha^T dC_k alpha, their second-stage sums, and one small copy into the pinned result ring.  No host
+//            synchronisation anywhere: the call returns while the device works.
+//   collect: waits for THAT batch's event and finishes on the host (nreg x nreg solve, the reference's scalings).
 // ---------------------------------------------------------------------------
-static int grad_impl(gpemu_ctx *ctx, const double *thetas, int nthetas, double *grad, int *info, HostLik *lik_out);
-
-extern "C" int gpemu_grad(gpemu_ctx *ctx, const double *thetas, int nthetas, double *grad, int *info)
-{
-	return grad_impl(ctx, thetas, nthetas, grad, info, nullptr);
-}
-
-// evalFnGradMulti (maxmultimin.c:615-618) with ONE factorisation shared by value and gradient
-extern "C" int gpemu_loglik_grad(gpemu_ctx *ctx, const double *thetas, int nthetas, double *neg_loglik, double *sigma2,
-                                 double *beta, double *grad, int *info)
-{
-	HostLik r;
-	int rc = grad_impl(ctx, thetas, nthetas, grad, info, &r);
-	if (rc == GPEMU_ERR_NOT_PD) {
-		if (neg_loglik) *neg_loglik = NAN;
-		if (sigma2) *sigma2 = NAN;
-		return rc;
-	}
-	if (rc) return rc;
-	if (beta) for (int a = 0; a < ctx->nreg; a++) beta[a] = r.beta[a];
-	if (sigma2) *sigma2 = r.sigma2;
-	if (neg_loglik) {
-		const double log_2_pi = 1.83788;
-		const double ll = -(1.0 / 2.0) * r.logdet - (ctx->N / 2.0) * log_2_pi + r.quad * (-1.0 / 2.0);
-		*neg_loglik = -1 * ll;
-	}
-	return GPEMU_OK;
-}
-
-// second half of a gradient evaluation: matrix b of the workspace holds the factorisation with its inverse rows
-// (U = L^-T); builds C^-1 = U U^T and reduces tr(C^-1 dC_k), alpha^T dC_k alpha over its tiles
 // corners S kept in flight at a time by the gradient of a batch: as many as fit in about 10 GB
 static int grad_chunk_size(const gpemu_ctx *ctx, int nb)
 {
@@ -1280,22 +1133,30 @@ static int grad_chunk_size(const gpemu_ctx *ctx, int nb)
 	return std::max(1, std::min(nb, fit));
 }
 
-// gradients of the batch elements b0 .. b0+nbc-1 whose likelihood pieces are in liks[] (elements with liks[i] == nullptr
-// -- not positive definite -- are computed and ignored): one batched C^-1 = U U^T product, one reduction launch, one
-// upload, one download and one synchronisation for the chunk.
-static int grad_finish_chunk(gpemu_ctx *ctx, int b0, int nbc, const double *const *th /* full thetas, th[0] = 0 */,
-                             const HostLik *const *liks, double *const *grad)
+static int grad_check_args(gpemu_ctx *ctx, int nthetas)
+{
+	if (!ctx->dX) return fail(ctx, GPEMU_ERR_STATE, "model not set");
+	const int trainable_matern = (ctx->mode & GPEMU_MODE_EXACT_GRAD) && (ctx->mode & GPEMU_MODE_MATERN_LOG);
+	if (ctx->kind != GPEMU_POWEREXP && !trainable_matern)
+		return fail(ctx, GPEMU_ERR_ARG,
+		            "Matern gradient needs GPEMU_MODE_EXACT_GRAD | GPEMU_MODE_MATERN_LOG: the reference's literal Matern "
+		            "derivative matrices (emulator.c:401-433, 497-532) carry an accumulator across elements and its training "
+		            "path zeroes the raw amplitude (maxmultimin.c:311,495) -- there is no literal Matern gradient to reproduce");
+	if (nthetas < nthetas_for(ctx)) return fail(ctx, GPEMU_ERR_ARG, "nthetas too small");
+	if (nthetas > GPEMU_MAX_PARAMS + 2) return fail(ctx, GPEMU_ERR_ARG, "nthetas too large");
+	return GPEMU_OK;
+}
+
+// gradient reductions of the batch elements b0 .. b0+nbc-1 of the factorisation in the workspace, into dGradSum
+static int grad_enqueue_chunk(gpemu_ctx *ctx, int b0, int nbc, const double *th_all, int nthetas)
 {
 	int rc = build_corner(ctx, b0, nbc);
 	if (rc) return rc;
 	const int N = ctx->N, d = ctx->d, Rp = ctx->Rp;
 	const size_t dim = ctx->S_dim, sstride = dim * dim;
-	// the length thetas (and, exact mode, the regression coefficients) of the chunk in one upload (2-D: they sit behind
-	// each corner's alpha scratch), one gather + one reduction launch for all its corners, one download, one
-	// synchronisation
 	const bool exact = (ctx->mode & GPEMU_MODE_EXACT_GRAD) != 0;
 	const int nlen = ctx->kind == GPEMU_POWEREXP ? d : 1;           // length-scale directions
-	const size_t gslot = (size_t)ctx->Np + 2 * GPEMU_MAX_PARAMS;
+	const size_t gslot = (size_t)ctx->Np + 2 * GPEMU_MAX_PARAMS;    // per corner: alpha scratch | length thetas | beta
 	if (ctx->alpha_cap < nbc) {
 		if (ctx->dAlpha) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); hipFree(ctx->dAlpha); ctx->dAlpha = nullptr; }
 		ctx->alpha_cap = 0;
@@ -1311,89 +1172,30 @@ static int grad_finish_chunk(gpemu_ctx *ctx, int b0, int nbc, const double *cons
 		HIPCHK(ctx, hipMalloc(&ctx->dGradPart, need * nbc * sizeof(double)));
 		ctx->gradpart_len = need * nbc;
 	}
-	std::vector<double> part(need * nbc), gph((size_t)nbc * 2 * GPEMU_MAX_PARAMS, 0.0);
-	for (int i = 0; i < nbc; i++) {
-		for (int k = 0; k < nlen; k++) gph[(size_t)i * 2 * GPEMU_MAX_PARAMS + k] = th[i][2 + k];
-		if (exact && liks[i])
-			for (int a = 0; a < ctx->nreg; a++) gph[(size_t)i * 2 * GPEMU_MAX_PARAMS + GPEMU_MAX_PARAMS + a] = liks[i]->beta[a];
-	}
+	// the length thetas of the chunk: from the pinned entry that belongs to this batch's hyper-parameter upload (reused
+	// only after param_ev of the entry, re-recorded below behind this copy)
+	double *gph = ctx->hGph + ((size_t)ctx->param_slot * GPEMU_MAX_BATCH + b0) * GPEMU_MAX_PARAMS;
+	for (int i = 0; i < nbc; i++)
+		for (int k = 0; k < GPEMU_MAX_PARAMS; k++)
+			gph[(size_t)i * GPEMU_MAX_PARAMS + k] = k < nlen ? th_all[(size_t)(b0 + i) * nthetas + 2 + k] : 0.0;
+	HIPCHK(ctx, hipMemcpy2DAsync(ctx->dAlpha + ctx->Np, gslot * sizeof(double), gph, GPEMU_MAX_PARAMS * sizeof(double),
+	                             GPEMU_MAX_PARAMS * sizeof(double), nbc, hipMemcpyHostToDevice, ctx->stream));
+	HIPCHK(ctx, hipEventRecord(ctx->param_ev[ctx->param_slot], ctx->stream));
+	if (exact)
+		HIPCHK(ctx, launch_beta_solve(ctx->stream, ctx->dRes + (size_t)b0 * ctx->res_len, (long)ctx->res_len, Rp, ctx->nreg, nbc,
+		                              ctx->dAlpha, (long)gslot, ctx->Np));
 	int nparts = 0;
-	hipError_t e = hipMemcpy2DAsync(ctx->dAlpha + ctx->Np, gslot * sizeof(double), gph.data(), 2 * GPEMU_MAX_PARAMS * sizeof(double),
-	                                2 * GPEMU_MAX_PARAMS * sizeof(double), nbc, hipMemcpyHostToDevice, ctx->stream);
-	if (e == hipSuccess)
-		e = launch_grad_partials(ctx->stream, ctx->dS, (long)dim, Rp, (long)sstride, nbc, ctx->dX, N, d, ctx->dAlpha, ctx->Np,
-		                         (long)gslot, ctx->dGradPart, (long)need, &nparts, exact ? ctx->kind : 0, ctx->nreg,
-		                         ctx->dParams + b0);
-	if (e == hipSuccess)
-		e = hipMemcpyAsync(part.data(), ctx->dGradPart, need * nbc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-	HIPCHK(ctx, e);
-	for (int i = 0; i < nbc; i++) {
-		if (!liks[i]) continue;
-		std::vector<double> sums(np, 0.0);
-		const double *pi = part.data() + (size_t)i * need;
-		for (int t = 0; t < nparts; t++)
-			for (int k = 0; k < np; k++) sums[k] += pi[(size_t)t * np + k];
-		if (exact) {
-			// d(-logL)/dtheta = 1/2 sum_ab (A_ab - alpha_a alpha_b) dC_ab: slot nlen = nugget direction, slots < nlen the lengths
-			grad[i][0] = 0.5 * sums[nlen];
-			for (int k = 0; k < nlen; k++) grad[i][k + 1] = 0.5 * sums[k];
-			continue;
-		}
-		const double aa = sums[2 * d + 1];
-		const double amp = exp(log(liks[i]->sigma2));     // maxmultimin.c:503,514
-		const double nug = exp(th[i][1]);                 // :515
-		// G(dC) = -1/2 tr(A dC) + 1/2 alpha^T dC alpha ;  grad = -G   (:527,535; getGradientCn :571-608)
-		grad[i][0] = -1.0 * (-0.5 * nug * sums[2 * d] + 0.5 * nug * aa);
-		for (int k = 0; k < d; k++)
-			grad[i][k + 1] = -1.0 * (amp * (-0.5 * sums[2 * k] + 0.5 * sums[2 * k + 1]));
-	}
+	HIPCHK(ctx, launch_grad_partials(ctx->stream, ctx->dS, (long)dim, Rp, (long)sstride, nbc, ctx->dX, N, d, ctx->dAlpha, ctx->Np,
+	                                 (long)gslot, ctx->dGradPart, (long)need, &nparts, exact ? ctx->kind : 0, ctx->nreg,
+	                                 ctx->dParams + b0));
+	HIPCHK(ctx, launch_grad_reduce(ctx->stream, ctx->dGradPart, (long)need, nparts, np, nbc,
+	                               ctx->dGradSum + (size_t)b0 * gpemu_ctx::GRAD_NP_MAX, (long)gpemu_ctx::GRAD_NP_MAX));
 	return GPEMU_OK;
 }
 
-static int grad_finish(gpemu_ctx *ctx, int b, const double *th, const HostLik &r, double *grad)
+extern "C" int gpemu_loglik_grad_batch_enqueue(gpemu_ctx *ctx, int nb, const double *thetas, int nthetas)
 {
-	const HostLik *lp = &r;
-	return grad_finish_chunk(ctx, b, 1, &th, &lp, &grad);
-}
-
-static int grad_check_args(gpemu_ctx *ctx, int nthetas)
-{
-	if (!ctx->dX) return fail(ctx, GPEMU_ERR_STATE, "model not set");
-	const int trainable_matern = (ctx->mode & GPEMU_MODE_EXACT_GRAD) && (ctx->mode & GPEMU_MODE_MATERN_LOG);
-	if (ctx->kind != GPEMU_POWEREXP && !trainable_matern)
-		return fail(ctx, GPEMU_ERR_ARG,
-		            "Matern gradient needs GPEMU_MODE_EXACT_GRAD | GPEMU_MODE_MATERN_LOG: the reference's literal Matern "
-		            "derivative matrices (emulator.c:401-433, 497-532) carry an accumulator across elements and its training "
-		            "path zeroes the raw amplitude (maxmultimin.c:311,495) -- there is no literal Matern gradient to reproduce");
-	if (nthetas < nthetas_for(ctx)) return fail(ctx, GPEMU_ERR_ARG, "nthetas too small");
-	return GPEMU_OK;
-}
-
-static int grad_impl(gpemu_ctx *ctx, const double *thetas, int nthetas, double *grad, int *info, HostLik *lik_out)
-{
-	if (!ctx || !grad) return GPEMU_ERR_ARG;
-	int rc = grad_check_args(ctx, nthetas);
-	if (rc) return rc;
-	std::vector<double> th(thetas, thetas + nthetas);
-	th[0] = 0.0;                                      // maxmultimin.c:441
-	ctx->pred_ready = false; ctx->cinv_ready = false;
-	CovParams p;
-	rc = factor_with_inverse(ctx, th.data(), nthetas, &p, info);
-	if (rc) return rc;
-	HostLik r = host_likelihood(ctx);
-	if (r.status) return fail(ctx, r.status, "H^T C^-1 H is not positive definite");
-	if (lik_out) *lik_out = r;
-	return grad_finish(ctx, 0, th.data(), r, grad);
-}
-
-// evalFnGradMulti for a list of thetas (the line-search points of independent restarts): the nb factorisations with
-// their inverse rows run in lock-step (as gpemu_loglik_batch), then C^-1 and the gradient reductions element by
-// element (those launches fill the chip on their own).  status[b] as gpemu_loglik_grad would return for element b.
-extern "C" int gpemu_loglik_grad_batch(gpemu_ctx *ctx, int nb, const double *thetas, int nthetas, double *neg_loglik,
-                                       double *sigma2, double *beta, double *grad, int *info, int *status)
-{
-	if (!ctx || !grad || !thetas) return GPEMU_ERR_ARG;
+	if (!ctx || !thetas) return GPEMU_ERR_ARG;
 	int rc = grad_check_args(ctx, nthetas);
 	if (rc) return rc;
 	if (nb < 1 || nb > GPEMU_MAX_BATCH) return fail(ctx, GPEMU_ERR_ARG, "batch size must be 1..GPEMU_MAX_BATCH");
@@ -1411,54 +1213,121 @@ extern "C" int gpemu_loglik_grad_batch(gpemu_ctx *ctx, int nb, const double *the
 	if (rc) return rc;
 	rc = run_potrf(ctx, 1);
 	if (rc) return rc;
-	rc = enqueue_results(ctx);
+	rc = enqueue_results(ctx);                       // Gram, log det, info words -> the next slot of the pinned ring
 	if (rc) return rc;
-	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-	const int ng = nthetas - 1;
-	std::vector<HostLik> liks((size_t)nb);
-	std::vector<int> st((size_t)nb, GPEMU_OK);
+	const int slot = (int)((ctx->res_seq - 1) % gpemu_ctx::RES_RING);
+	ctx->res_kind[slot] = 1;
+	ctx->res_th[slot] = th;
+	ctx->res_nthetas[slot] = nthetas;
+	const int chunk = grad_chunk_size(ctx, nb);
+	for (int b0 = 0; b0 < nb; b0 += chunk) {
+		rc = grad_enqueue_chunk(ctx, b0, std::min(chunk, nb - b0), th.data(), nthetas);
+		if (rc) return rc;
+	}
+	HIPCHK(ctx, hipMemcpyAsync(ctx->hGradRing + (size_t)slot * ctx->batch_cap * gpemu_ctx::GRAD_NP_MAX, ctx->dGradSum,
+	                           (size_t)nb * gpemu_ctx::GRAD_NP_MAX * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(ctx, hipEventRecord(ctx->res_ev[slot], ctx->stream));     // (re-recorded: now behind the gradient sums as well)
+	return GPEMU_OK;
+}
+
+// host half of a value+gradient batch whose results sit in ring slot `slot` (its event has been waited for)
+static int grad_collect_slot(gpemu_ctx *ctx, int slot, int nb, double *neg_loglik, double *sigma2, double *beta, double *grad,
+                             int *info, int *status)
+{
+	const int nthetas = ctx->res_nthetas[slot], ng = nthetas - 1, d = ctx->d;
+	const bool exact = (ctx->mode & GPEMU_MODE_EXACT_GRAD) != 0;
+	const int nlen = ctx->kind == GPEMU_POWEREXP ? d : 1;
+	const double *th_all = ctx->res_th[slot].data();
+	double *saveR = ctx->hRes;
+	int *saveI = ctx->hInfo;
+	ctx->hRes = ctx->hResRing + (size_t)slot * ctx->batch_cap * ctx->res_len;
+	ctx->hInfo = ctx->hInfoRing + (size_t)slot * ctx->batch_cap;
 	for (int b = 0; b < nb; b++) {
 		const int inf = (ctx->hInfo[b] >= INFO_NONE) ? 0 : ctx->hInfo[b];
+		int st = GPEMU_OK;
 		if (info) info[b] = inf;
-		for (int i = 0; i < ng; i++) grad[(size_t)b * ng + i] = NAN;
+		if (grad) for (int i = 0; i < ng; i++) grad[(size_t)b * ng + i] = NAN;
 		if (beta) for (int a = 0; a < ctx->nreg; a++) beta[(size_t)b * ctx->nreg + a] = NAN;
 		if (neg_loglik) neg_loglik[b] = NAN;
 		if (sigma2) sigma2[b] = NAN;
 		if (inf) {
-			st[b] = fail(ctx, GPEMU_ERR_NOT_PD, "covariance matrix is not positive definite");
-			continue;
+			st = fail(ctx, GPEMU_ERR_NOT_PD, "covariance matrix is not positive definite");
+		} else {
+			const HostLik r = host_likelihood(ctx, b);
+			if (r.status) {
+				st = fail(ctx, r.status, "H^T C^-1 H is not positive definite");
+			} else {
+				const double log_2_pi = 1.83788;
+				if (neg_loglik) neg_loglik[b] = -1 * (-(1.0 / 2.0) * r.logdet - (ctx->N / 2.0) * log_2_pi + r.quad * (-1.0 / 2.0));
+				if (sigma2) sigma2[b] = r.sigma2;
+				if (beta) for (int a = 0; a < ctx->nreg; a++) beta[(size_t)b * ctx->nreg + a] = r.beta[a];
+				if (grad) {
+					const double *sums = ctx->hGradRing + ((size_t)slot * ctx->batch_cap + b) * gpemu_ctx::GRAD_NP_MAX;
+					double *g = grad + (size_t)b * ng;
+					if (exact) {
+						// d(-logL)/dtheta = 1/2 sum_ab (A_ab - alpha_a alpha_b) dC_ab: slot nlen = nugget direction, slots < nlen the lengths
+						g[0] = 0.5 * sums[nlen];
+						for (int k = 0; k < nlen; k++) g[k + 1] = 0.5 * sums[k];
+					} else {
+						const double aa = sums[2 * d + 1];
+						const double amp = exp(log(r.sigma2));                          // maxmultimin.c:503,514
+						const double nug = exp(th_all[(size_t)b * nthetas + 1]);         // :515
+						// G(dC) = -1/2 tr(A dC) + 1/2 alpha^T dC alpha ;  grad = -G   (:527,535; getGradientCn :571-608)
+						g[0] = -1.0 * (-0.5 * nug * sums[2 * d] + 0.5 * nug * aa);
+						for (int k = 0; k < d; k++) g[k + 1] = -1.0 * (amp * (-0.5 * sums[2 * k] + 0.5 * sums[2 * k + 1]));
+					}
+				}
+			}
 		}
-		liks[b] = host_likelihood(ctx, b);
-		if (liks[b].status) st[b] = fail(ctx, liks[b].status, "H^T C^-1 H is not positive definite");
+		if (status) status[b] = st;
 	}
-	const int chunk = grad_chunk_size(ctx, nb);
-	for (int b0 = 0; b0 < nb; b0 += chunk) {
-		const int nbc = std::min(chunk, nb - b0);
-		std::vector<const double *> thp((size_t)nbc);
-		std::vector<const HostLik *> lp((size_t)nbc);
-		std::vector<double *> gp((size_t)nbc);
-		bool any = false;
-		for (int i = 0; i < nbc; i++) {
-			thp[i] = &th[(size_t)(b0 + i) * nthetas];
-			lp[i] = st[b0 + i] == GPEMU_OK ? &liks[b0 + i] : nullptr;
-			gp[i] = grad + (size_t)(b0 + i) * ng;
-			any = any || lp[i];
-		}
-		if (!any) continue;
-		rc = grad_finish_chunk(ctx, b0, nbc, thp.data(), lp.data(), gp.data());
-		if (rc != GPEMU_OK) return rc;                                           // HIP failure: give up on the batch
-	}
-	for (int b = 0; b < nb; b++) {
-		if (st[b] == GPEMU_OK) {
-			const HostLik &r = liks[b];
-			const double log_2_pi = 1.83788;
-			if (neg_loglik) neg_loglik[b] = -1 * (-(1.0 / 2.0) * r.logdet - (ctx->N / 2.0) * log_2_pi + r.quad * (-1.0 / 2.0));
-			if (sigma2) sigma2[b] = r.sigma2;
-			if (beta) for (int a = 0; a < ctx->nreg; a++) beta[(size_t)b * ctx->nreg + a] = r.beta[a];
-		}
-		if (status) status[b] = st[b];
-	}
+	ctx->hRes = saveR; ctx->hInfo = saveI;
 	return GPEMU_OK;
+}
+
+// results of the value+gradient batch enqueued `back` batches (of either kind) before the newest one; waits for it only
+extern "C" int gpemu_loglik_grad_batch_collect_back(gpemu_ctx *ctx, int back, int nb, double *neg_loglik, double *sigma2,
+                                                    double *beta, double *grad, int *info, int *status)
+{
+	if (!ctx) return GPEMU_ERR_ARG;
+	if (back < 0 || back >= gpemu_ctx::RES_RING || (unsigned long long)back >= ctx->res_seq)
+		return fail(ctx, GPEMU_ERR_STATE, "no such batch in the result ring");
+	const int slot = (int)((ctx->res_seq - 1 - (unsigned long long)back) % gpemu_ctx::RES_RING);
+	if (nb < 1 || nb != ctx->res_nb[slot]) return fail(ctx, GPEMU_ERR_STATE, "batch size differs from the enqueued batch");
+	if (ctx->res_kind[slot] != 1) return fail(ctx, GPEMU_ERR_STATE, "that batch is a likelihood batch: use gpemu_loglik_batch_collect_back");
+	HIPCHK(ctx, hipEventSynchronize(ctx->res_ev[slot]));
+	return grad_collect_slot(ctx, slot, nb, neg_loglik, sigma2, beta, grad, info, status);
+}
+
+extern "C" int gpemu_loglik_grad_batch_collect(gpemu_ctx *ctx, int nb, double *neg_loglik, double *sigma2, double *beta,
+                                               double *grad, int *info, int *status)
+{
+	return gpemu_loglik_grad_batch_collect_back(ctx, 0, nb, neg_loglik, sigma2, beta, grad, info, status);
+}
+
+// evalFnGradMulti for a list of thetas (the line-search points of independent restarts): enqueue + collect
+extern "C" int gpemu_loglik_grad_batch(gpemu_ctx *ctx, int nb, const double *thetas, int nthetas, double *neg_loglik,
+                                       double *sigma2, double *beta, double *grad, int *info, int *status)
+{
+	if (!ctx || !grad || !thetas) return GPEMU_ERR_ARG;
+	int rc = gpemu_loglik_grad_batch_enqueue(ctx, nb, thetas, nthetas);
+	if (rc) return rc;
+	return gpemu_loglik_grad_batch_collect(ctx, nb, neg_loglik, sigma2, beta, grad, info, status);
+}
+
+// evalFnGradMulti (maxmultimin.c:615-618) with ONE factorisation shared by value and gradient: a batch of one
+extern "C" int gpemu_loglik_grad(gpemu_ctx *ctx, const double *thetas, int nthetas, double *neg_loglik, double *sigma2,
+                                 double *beta, double *grad, int *info)
+{
+	if (!ctx || !grad) return GPEMU_ERR_ARG;
+	int st = GPEMU_OK;
+	int rc = gpemu_loglik_grad_batch(ctx, 1, thetas, nthetas, neg_loglik, sigma2, beta, grad, info, &st);
+	return rc ? rc : st;
+}
+
+extern "C" int gpemu_grad(gpemu_ctx *ctx, const double *thetas, int nthetas, double *grad, int *info)
+{
+	return gpemu_loglik_grad(ctx, thetas, nthetas, nullptr, nullptr, nullptr, grad, info);
 }
 
 // ---------------------------------------------------------------------------
@@ -1529,7 +1398,7 @@ extern "C" int gpemu_chol_inverse(gpemu_ctx *ctx, int n, double *a, int lda, dou
 	if (!ctx || n < 1 || !a || lda < n) return GPEMU_ERR_ARG;
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	gpemu_ctx tmp;                       // scratch state on the caller's stream: sizes of this matrix, no model
-	tmp.device = ctx->device; tmp.stream = ctx->stream; tmp.use_graph = false;
+	tmp.device = ctx->device; tmp.stream = ctx->stream; tmp.use_graph = false; tmp.sched = ctx->sched;
 	tmp.Np = round_up(n, LEAF); tmp.Rp = 64; tmp.N = n; tmp.nrhs = 0; tmp.nb = 1;
 	const int Np = tmp.Np, Rp = tmp.Rp;
 	const size_t rows = (size_t)2 * Np + Rp, dim = (size_t)Np + Rp;
@@ -1542,7 +1411,6 @@ extern "C" int gpemu_chol_inverse(gpemu_ctx *ctx, int n, double *a, int lda, dou
 	if (e == hipSuccess) e = hipMalloc(&tmp.dInfo, sizeof(int));
 	if (e == hipSuccess) e = hipMalloc(&tmp.dS, dim * dim * sizeof(double));
 	if (e == hipSuccess) { tmp.S_dim = dim; tmp.S_cap = 1; }
-	tmp.dDiagInv = ctx->dDiagInv;
 	if (e == hipSuccess) e = hipMemcpyAsync(tmp.dT, h.data(), h.size() * 8, hipMemcpyHostToDevice, tmp.stream);
 	if (e == hipSuccess) e = hipMemsetAsync(tmp.dT + (size_t)Np * Np, 0, (size_t)Rp * Np * 8, tmp.stream);
 	if (e == hipSuccess) e = launch_set_identity_rows(tmp.stream, tmp.dT + (size_t)(Np + Rp) * Np, Np, Np);
@@ -1565,7 +1433,7 @@ extern "C" int gpemu_chol_inverse(gpemu_ctx *ctx, int n, double *a, int lda, dou
 	if (tmp.dT) hipFree(tmp.dT);
 	if (tmp.dInfo) hipFree(tmp.dInfo);
 	if (tmp.dS) hipFree(tmp.dS);
-	tmp.dT = nullptr; tmp.dInfo = nullptr; tmp.dS = nullptr; tmp.stream = nullptr; tmp.dDiagInv = nullptr;
+	tmp.dT = nullptr; tmp.dInfo = nullptr; tmp.dS = nullptr; tmp.stream = nullptr;
 	HIPCHK(ctx, e);
 	if (info) *info = bad;
 	if (bad) return fail(ctx, GPEMU_ERR_NOT_PD, "matrix is not positive definite");
@@ -1605,24 +1473,43 @@ static uint64_t matrix_checksum(const double *a, int n, int lda)
 	return r ^ (r >> 32);
 }
 
-// forget the cached device copy of the host matrix (a caller that knows it has rewritten the buffer can skip the
-// checksum pass this way; not needed for correctness)
+// forget the cached device copy of the host matrix: the next gpemu_symm_apply uploads without comparing checksums
+// (not needed for correctness; saves a caller that knows it has rewritten the buffer one pass over it)
 extern "C" int gpemu_symm_invalidate(gpemu_ctx *ctx)
 {
 	if (!ctx) return GPEMU_ERR_ARG;
 	ctx->sym_key = nullptr;
+	ctx->sym_pinned = false;
+	return GPEMU_OK;
+}
+
+// pinned = 1: the caller promises not to modify the matrix it passes to gpemu_symm_apply / gpemu_trace_product until it
+// unpins (or invalidates): calls with the same (pointer, n, lda) then skip the per-call checksum pass (one read of
+// N x N doubles from host memory -- 0.1 s at N = 8192, far more than the device product it guards).  The reference's
+// per-point loops (makeEmulatedMean / makeEmulatedVariance over one cinverse, emulator.c:672-785) are such callers.
+extern "C" int gpemu_symm_pin(gpemu_ctx *ctx, int pinned)
+{
+	if (!ctx) return GPEMU_ERR_ARG;
+	ctx->sym_pinned = pinned != 0;
 	return GPEMU_OK;
 }
 
 // out[v][i] = sum_j A[i][j] V[v][j] for nvec vectors stored as rows; A symmetric, host-resident, N x N with row
-// stride lda.  A is uploaded when (pointer, sizes, checksum of all its elements) differ from the cached copy.
+// stride lda.  A is uploaded when (pointer, sizes) differ from the cached copy, or -- unless pinned -- when the checksum
+// of all its elements does (the checksum pass runs only when pointer and sizes match: a new matrix is uploaded at once).
 extern "C" int gpemu_symm_apply(gpemu_ctx *ctx, int n, const double *a, int lda, int nvec, const double *v, double *out)
 {
 	if (!ctx || n < 1 || !a || lda < n || nvec < 1 || !v || !out) return GPEMU_ERR_ARG;
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	const int Npad = round_up(n, 64);
-	const uint64_t fp = matrix_checksum(a, n, lda);
-	if (ctx->sym_key != a || ctx->sym_N != n || ctx->sym_lda != lda || ctx->sym_fp != fp || !ctx->dSym) {
+	const bool same_key = ctx->dSym && ctx->sym_key == a && ctx->sym_N == n && ctx->sym_lda == lda;
+	bool current = same_key && ctx->sym_pinned;
+	uint64_t fp = 0;
+	if (same_key && !current) {
+		fp = matrix_checksum(a, n, lda);
+		current = fp == ctx->sym_fp;
+	}
+	if (!current) {
 		HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 		if (ctx->sym_pad != Npad || !ctx->dSym) {
 			if (ctx->dSym) hipFree(ctx->dSym);
@@ -1634,6 +1521,7 @@ extern "C" int gpemu_symm_apply(gpemu_ctx *ctx, int n, const double *a, int lda,
 		HIPCHK(ctx, hipMemsetAsync(ctx->dSym, 0, (size_t)Npad * Npad * sizeof(double), ctx->stream));
 		HIPCHK(ctx, hipMemcpy2DAsync(ctx->dSym, (size_t)Npad * sizeof(double), a, (size_t)lda * sizeof(double),
 		                             (size_t)n * sizeof(double), n, hipMemcpyHostToDevice, ctx->stream));
+		if (!same_key) fp = matrix_checksum(a, n, lda);      // (a new matrix: its checksum for the calls that follow)
 		ctx->sym_key = a; ctx->sym_N = n; ctx->sym_lda = lda; ctx->sym_fp = fp;
 	}
 	if (ctx->sym_vcap < nvec) {
@@ -1772,13 +1660,13 @@ extern "C" int gpemu_test_tile_table(int tiles_m, int tiles_n, int tri, int sb, 
 	return (int)t.size();
 }
 
-namespace gpemu { extern int g_gemm_force_cfg; hipError_t launch_fill_random(hipStream_t s, double *p, size_t n, unsigned seed); }
+namespace gpemu { hipError_t launch_fill_random(hipStream_t s, double *p, size_t n, unsigned seed); }
 
 // times `reps` launches of one GEMM shape with HIP events on the ctx stream (device-resident random operands)
 extern "C" int gpemu_test_gemm_bench(gpemu_ctx *ctx, int m, int n, int k, int ld_in, int cfg, int tri, int beta,
                                      int reps, double *ms_avg, double *flops)
 {
-	if (!ctx || m < 1 || n < 1 || k < 16 || (k % GEMM_BK) != 0 || reps < 1) return GPEMU_ERR_ARG;
+	if (!ctx || m < 1 || n < 1 || k < 16 || (k % GEMM_BK) != 0 || reps < 1 || (cfg != 0 && cfg != 2 && cfg != 8)) return GPEMU_ERR_ARG;
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	const long ld = std::max(std::max(k, n), ld_in);
 	double *da = nullptr, *dc = nullptr;
@@ -1801,8 +1689,8 @@ extern "C" int gpemu_test_gemm_bench(gpemu_ctx *ctx, int m, int n, int k, int ld
 		HIPCHK(ctx, hipMemsetAsync(ctx->dTrace, 0, (size_t)ctx->trace_cap * 64, ctx->stream));
 		g.trace = trace_slot(ctx, "gemm_bench m=%d n=%d k=%d", m, n, k);
 	}
-	const int saved = g_gemm_force_cfg;
-	g_gemm_force_cfg = cfg;
+	g.force_cfg = cfg;                                      // 2: 64x64 tiles, 8: 128x128 tiles, 0: the automatic choice
+	g.big_tiles = ctx->sched.gemm_big_tiles; g.table_sb = ctx->sched.gemm_table;
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0); hipEventCreate(&e1);
 	hipError_t e = launch_gemm(ctx->stream, g);
@@ -1811,7 +1699,6 @@ extern "C" int gpemu_test_gemm_bench(gpemu_ctx *ctx, int m, int n, int k, int ld
 	for (int r = 0; r < reps && e == hipSuccess; r++) e = launch_gemm(ctx->stream, g);
 	hipEventRecord(e1, ctx->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-	g_gemm_force_cfg = saved;
 	float ms = 0.f;
 	hipEventElapsedTime(&ms, e0, e1);
 	hipEventDestroy(e0); hipEventDestroy(e1);
@@ -1828,7 +1715,7 @@ extern "C" int gpemu_test_potrf(gpemu_ctx *ctx, int n, double *a, int *info)
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	// run through a scratch ctx-like state: temporarily adopt sizes
 	gpemu_ctx tmp;
-	tmp.device = ctx->device; tmp.stream = ctx->stream; tmp.use_graph = false;
+	tmp.device = ctx->device; tmp.stream = ctx->stream; tmp.use_graph = false; tmp.sched = ctx->sched;
 	tmp.Np = round_up(n, LEAF); tmp.Rp = 64; tmp.N = n; tmp.nrhs = 0;
 	const int Np = tmp.Np;
 	std::vector<double> h((size_t)(Np + 64) * Np, 0.0);
@@ -1837,7 +1724,6 @@ extern "C" int gpemu_test_potrf(gpemu_ctx *ctx, int n, double *a, int *info)
 			h[(size_t)i * Np + j] = (i < n) ? a[(size_t)i * n + j] : (i == j ? 1.0 : 0.0);
 	hipError_t e = hipMalloc(&tmp.dT, h.size() * 8);
 	if (e == hipSuccess) e = hipMalloc(&tmp.dInfo, sizeof(int));
-	tmp.dDiagInv = ctx->dDiagInv;
 	int big = INFO_NONE;
 	if (e == hipSuccess) e = hipMemcpy(tmp.dT, h.data(), h.size() * 8, hipMemcpyHostToDevice);
 	if (e == hipSuccess) e = hipMemcpy(tmp.dInfo, &big, sizeof(int), hipMemcpyHostToDevice);
@@ -1848,7 +1734,7 @@ extern "C" int gpemu_test_potrf(gpemu_ctx *ctx, int n, double *a, int *info)
 	if (e == hipSuccess) e = hipMemcpy(&inf, tmp.dInfo, sizeof(int), hipMemcpyDeviceToHost);
 	if (tmp.dT) hipFree(tmp.dT);
 	if (tmp.dInfo) hipFree(tmp.dInfo);
-	tmp.dT = nullptr; tmp.dInfo = nullptr; tmp.stream = nullptr; tmp.dDiagInv = nullptr;
+	tmp.dT = nullptr; tmp.dInfo = nullptr; tmp.stream = nullptr;
 	HIPCHK(ctx, e);
 	if (info) *info = (inf >= INFO_NONE) ? 0 : inf;
 	for (int i = 0; i < n; i++)

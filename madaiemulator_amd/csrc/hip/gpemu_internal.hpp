@@ -64,11 +64,22 @@ struct GemmArgs {
 	int fa;              // factor-ahead: the workgroup of tile (0,0) factors its updated 64x64 diagonal block (64x64 tiles only)
 	int fa_c0;           // global column of that block (for the 1-based index of a failed pivot)
 	int *fa_info;        // info words (one per matrix of the batch)
-	int sa;              // solve-ahead (with fa, ONE matrix per launch): the tiles of tile column 0 wait for that L and solve their rows
-	int *sa_flag;        // zero before the launch; set by tile (0,0) once L is visible
-	int prio;            // 1: the waves raise their issue priority (s_setprio 3): critical-chain launches of the look-ahead schedule
-	int half_occ;        // 1: launch with an LDS pad that halves the workgroups per CU (bulk update of the look-ahead schedule:
-	                     // leaves registers and LDS for the chain kernels that run beside it)
+	// schedule switches of the calling context (Sched below), carried per call: nothing process-wide
+	int big_tiles;       // 128x128 tiles once a lock-step launch has this many of them (0: 1024)
+	int table_sb;        // XCD-blocked tile table for launches of >= 512 tiles: side of the super-blocks (0: off)
+	int force_cfg;       // test/bench hook: 2 = 64x64 tiles, 8 = 128x128 tiles, 0 = automatic
+};
+
+// Schedule switches of ONE context: read from the environment once, when the context is created (INTEGRATION.md lists
+// the variables), and constant for its lifetime.  Two contexts of a process may differ; nothing process-wide is written
+// after start-up, so contexts created and driven from several host threads (csrc/host/multi.c) cannot disturb each other,
+// and a context's cached launch graphs always match its switches.
+struct Sched {
+	int gemm_big_tiles = 1024;   // GPEMU_GEMM_BIG_TILES
+	int gemm_table = 8;          // GPEMU_GEMM_TABLE (0 .. 64)
+	int factor_ahead = 1;        // GPEMU_FACTOR_AHEAD: the update's tile (0,0) factors the next diagonal block
+	int fill_gram = 1;           // GPEMU_FILL_GRAM: MFMA Gram form of the training fill
+	int nb_top = 0;              // GPEMU_NB_TOP: outer panel width; 0 = automatic (512 for one matrix, 2048 / 1024 for a batch)
 };
 
 struct ProfState {
@@ -83,10 +94,8 @@ struct ProfState {
 
 struct gpemu_ctx {
 	int device = 0;
-	hipStream_t stream = nullptr;      // panel / critical-path stream (high priority)
-	hipStream_t stream2 = nullptr;     // look-ahead stream: the bulk of each trailing update
-	std::vector<hipEvent_t> ev_pool;   // fork/join events of the look-ahead schedule
-	size_t ev_next = 0;
+	hipStream_t stream = nullptr;      // the context's one stream: every launch and copy of the context is ordered on it
+	gpemu::Sched sched;                // schedule switches, fixed at creation
 	std::string err;
 
 	// model
@@ -106,9 +115,6 @@ struct gpemu_ctx {
 	size_t T_stride = 0;         // elements between consecutive matrices of the batch
 	int batch_cap = 0;           // allocated per-matrix result slots (dInfo, dGramPart, dRes, hRes, hInfo)
 	int *dInfo = nullptr;
-	int *dFlags = nullptr;       // solve-ahead flags, one per 64-column block (zeroed before every factorisation)
-	int flags_len = 0;
-	double *dDiagInv = nullptr;  // eight inverted 16x16 diagonal blocks of the current 128-column leaf
 	double *dGramPart = nullptr; // [Np/128][Rp*Rp]
 	double *dRes = nullptr;      // Rp*Rp gram + logdet + spare
 	double *hRes = nullptr;      // pinned mirror: the newest slot of the ring below
@@ -118,6 +124,14 @@ struct gpemu_ctx {
 	int *hInfoRing = nullptr;    // RES_RING x batch_cap
 	hipEvent_t res_ev[RES_RING] = {nullptr, nullptr, nullptr, nullptr};   // recorded behind the copies into a slot
 	int res_nb[RES_RING] = {0, 0, 0, 0};
+	int res_kind[RES_RING] = {0, 0, 0, 0};          // 0: likelihood batch, 1: value+gradient batch
+	std::vector<double> res_th[RES_RING];           // value+gradient batches: the thetas they were enqueued with (theta[0] = 0)
+	int res_nthetas[RES_RING] = {0, 0, 0, 0};
+	static constexpr int GRAD_NP_MAX = 2 * GPEMU_MAX_PARAMS + 2;   // reduced gradient sums per batch element
+	double *dGradSum = nullptr;  // batch_cap x GRAD_NP_MAX
+	double *hGradRing = nullptr; // pinned, RES_RING x batch_cap x GRAD_NP_MAX
+	double *hGph = nullptr;      // pinned upload ring of the length thetas: PARAM_RING x GPEMU_MAX_BATCH x GPEMU_MAX_PARAMS
+	unsigned param_slot = 0;     // ring entry of the hyper-parameter upload of the batch being enqueued
 	unsigned long long res_seq = 0;      // batches enqueued since the ring was (re)allocated
 	size_t res_len = 0;
 
@@ -154,6 +168,7 @@ struct gpemu_ctx {
 	const double *sym_key = nullptr;
 	int sym_N = 0, sym_lda = 0, sym_pad = 0, sym_vcap = 0;
 	uint64_t sym_fp = 0;          // checksum of every element of the cached host matrix
+	bool sym_pinned = false;      // gpemu_symm_pin: the caller vouches for the buffer, no per-call checksum
 	gpemu::CovParams *dParams = nullptr;   // hyper-parameters of the batch elements (GPEMU_MAX_BATCH slots)
 	gpemu::CovParams *hParams = nullptr;   // pinned upload ring: PARAM_RING x GPEMU_MAX_BATCH slots, one event per ring entry
 	hipEvent_t param_ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -191,6 +206,10 @@ hipError_t launch_grad_partials(hipStream_t s, const double *S, long lds, int so
                                 int d, double *ag, int np_pad, long gstride, double *part, long pstride, int *nparts,
                                 int exact_kind = 0, int nbeta = 0, const CovParams *pp_dev = nullptr);
 
+hipError_t launch_beta_solve(hipStream_t s, const double *res, long rstride, int Rp, int nreg, int nb, double *ag, long gstride,
+                             int np_pad);
+hipError_t launch_grad_reduce(hipStream_t s, const double *part, long pstride, int ntiles, int np, int nb, double *sums, long sstride);
+
 hipError_t launch_deriv_gauss(hipStream_t s, double *out, long ld, const double *xcol, int n, double theta_len);
 hipError_t launch_trace_product(hipStream_t s, const double *A, const double *B, long ld, int n, double *part);
 
@@ -198,17 +217,12 @@ hipError_t launch_trace_product(hipStream_t s, const double *A, const double *B,
 hipError_t launch_gemm(hipStream_t s, const GemmArgs &a);
 hipError_t launch_skinny_nt(hipStream_t s, const double *Kq, long ldk, const double *L, long ldl, double *Vp, long ldv,
                             long sstride, int tq, int ntot, int K, int ntri, int nslice, int klen);
-extern int g_gemm_big_tiles, g_gemm_big_cfg, g_gemm_table, g_gemm_small_dma, g_la_bulk_cfg;
 std::vector<int> build_tile_table(int tiles_m, int tiles_n, int tri, int S, int bm = 128, int bn = 128);
 hipError_t launch_leaf(hipStream_t s, double *T, long ld, int c0, int m_below, int *info,
                        unsigned long long *trace_factor = nullptr, unsigned long long *trace_solve = nullptr,
-                       int nbatch = 1, long bstride = 0, bool skip_factor = false, bool skip_solve = false, int prio = 0);
+                       int nbatch = 1, long bstride = 0, bool skip_factor = false);
 bool gemm_factor_ahead_ok(const GemmArgs &a);
-hipError_t launch_panel_trsm(hipStream_t s, double *T, long ld, int c0, int n, int j0, int row0, int m, int nbatch, long bstride,
-                             unsigned long long *trace = nullptr);
 bool gemm_uses_big_tiles(const GemmArgs &a);
-hipError_t launch_leaf128(hipStream_t s, double *T, long ld, int c0, int m_below, int *info, double *dinv,
-                          int nbatch = 1, long bstride = 0);
 hipError_t launch_gram_partials(hipStream_t s, const double *Z, long ld, int Np, int nrhs, int Rp, double *part,
                                 int nbatch = 1, long zstride = 0);
 hipError_t launch_finish(hipStream_t s, const double *part, int nparts, int Rp, int nrhs, const double *T, long ld,

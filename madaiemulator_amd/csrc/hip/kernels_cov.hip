@@ -721,6 +721,85 @@ __global__ __launch_bounds__(256) void grad_exact_kernel(const double *S, long l
 	}
 }
 
+// beta = (H^T C^-1 H)^-1 (H^T C^-1 y) of one batch element from its Gram matrix G = Z^T Z (res: Rp x Rp row-major, G[0][0]
+// = y.Cinv.y, G[1+a][0] = (H^T Cinv y)_a, G[1+a][1+b] = (H^T Cinv H)_ab -- what finish_kernel leaves in dRes), by a
+// Cholesky solve in LDS; written behind the element's alpha scratch, where gather_alpha_kernel expects it.  This is the
+// estimateBeta of the exact-gradient mode (regression.c:120-176 on the Gram matrix) done on the device so that a
+// value+gradient batch needs no host round trip between its factorisation and its gradient reductions.  One wave per
+// element; a matrix that is not positive definite gives NaNs (the host reports GPEMU_ERR_REGRESSION for that element).
+__global__ __launch_bounds__(64) void beta_solve_kernel(const double *res, long rstride, int Rp, int nreg, double *ag,
+                                                        long gstride, int np_pad)
+{
+	__shared__ double A[64 * 65];
+	__shared__ double b[64];
+	const double *G = res + (long)blockIdx.x * rstride;
+	double *beta = ag + (long)blockIdx.x * gstride + np_pad + GPEMU_MAX_PARAMS;
+	const int i = threadIdx.x;
+	if (i < nreg) {
+		for (int j = 0; j < nreg; j++) A[i * 65 + j] = G[(long)(1 + i) * Rp + 1 + j];
+		b[i] = G[(long)(1 + i) * Rp];
+	}
+	__syncthreads();
+	for (int j = 0; j < nreg; j++) {
+		const double pv = A[j * 65 + j];
+		const double l = pv > 0.0 ? sqrt(pv) : nan("");
+		__syncthreads();
+		if (i == j) A[j * 65 + j] = l;
+		if (i > j && i < nreg) A[i * 65 + j] /= l;
+		__syncthreads();
+		if (i > j && i < nreg)
+			for (int k = j + 1; k <= i; k++) A[i * 65 + k] -= A[i * 65 + j] * A[k * 65 + j];
+		__syncthreads();
+	}
+	// L z = b, then L^T beta = z
+	for (int j = 0; j < nreg; j++) {
+		if (i == j) b[j] /= A[j * 65 + j];
+		__syncthreads();
+		if (i > j && i < nreg) b[i] -= A[i * 65 + j] * b[j];
+		__syncthreads();
+	}
+	for (int j = nreg - 1; j >= 0; j--) {
+		if (i == j) b[j] /= A[j * 65 + j];
+		__syncthreads();
+		if (i < j) b[i] -= A[j * 65 + i] * b[j];
+		__syncthreads();
+	}
+	if (i < nreg) beta[i] = b[i];
+}
+
+hipError_t launch_beta_solve(hipStream_t s, const double *res, long rstride, int Rp, int nreg, int nb, double *ag, long gstride,
+                             int np_pad)
+{
+	if (nreg < 1 || nreg > 63) return hipErrorInvalidValue;
+	hipLaunchKernelGGL(beta_solve_kernel, dim3(nb), dim3(64), 0, s, res, rstride, Rp, nreg, ag, gstride, np_pad);
+	return hipGetLastError();
+}
+
+// sums[b][k] = sum over the tiles t of part[b][t][k] in a fixed order (thread j takes tiles j, j + 256, ...; then a tree
+// over the 256 partial sums): the second stage of the gradient reductions, so that a batch hands back 2d+2 numbers per
+// element instead of 2d+2 per tile.  grid (np, nb)
+__global__ __launch_bounds__(256) void grad_reduce_kernel(const double *part, long pstride, int ntiles, int np, double *sums,
+                                                          long sstride)
+{
+	__shared__ double red[256];
+	const double *p = part + (long)blockIdx.y * pstride + blockIdx.x;
+	double acc = 0.0;
+	for (int t = threadIdx.x; t < ntiles; t += 256) acc += p[(long)t * np];
+	red[threadIdx.x] = acc;
+	__syncthreads();
+	for (int st = 128; st > 0; st >>= 1) {
+		if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) sums[(long)blockIdx.y * sstride + blockIdx.x] = red[0];
+}
+
+hipError_t launch_grad_reduce(hipStream_t s, const double *part, long pstride, int ntiles, int np, int nb, double *sums, long sstride)
+{
+	hipLaunchKernelGGL(grad_reduce_kernel, dim3(np, nb), dim3(256), 0, s, part, pstride, ntiles, np, sums, sstride);
+	return hipGetLastError();
+}
+
 // nb corners sstride apart; ag: nb slots of gstride doubles [alpha scratch (np_pad) | the length thetas]; part: nb blocks
 // of pstride doubles
 hipError_t launch_grad_partials(hipStream_t s, const double *S, long lds_, int soff, long sstride, int nb, const double *X, int N,

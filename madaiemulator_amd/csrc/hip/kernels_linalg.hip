@@ -18,24 +18,17 @@ namespace gpemu {
 typedef double d4_t __attribute__((ext_vector_type(4)));
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
-// LDS row stride (doubles).  Fragments are read as ds_read_b128: lane (q = lane&15, g = lane>>4) takes the
-// two doubles k = 8t+2g, 8t+2g+1 of its row and feeds them to MFMA k-steps 2t and 2t+1 (A and B use the same
-// k permutation, so the contraction is unchanged).  With a 20-double stride the four 16-lane groups of a
-// b128 read hit 64 distinct banks; the former 18-double stride with ds_read2_b64 (what hipcc emitted for
-// scalar reads) measured 40 % bank-conflict cycles (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).
-constexpr int LDS_S = GEMM_BK + 4;
-
 // ---------------------------------------------------------------------------
 // GEMM  C[m x n] = beta*C + alpha * A[m x K] * B[n x K]^T   (row-major, k contiguous in A and B)
 //
-// 256 threads = 4 waves as 2x2; each wave owns a (BM/2)x(BN/2) sub-tile of
+// 4 waves as 2x2 (64x64 tiles) or 8 waves as 4x2 (128x128 tiles); each wave owns a (BM/WGM)x(BN/WGN) sub-tile of
 // 16x16 MFMA tiles.  MFMA f64 16x16x4 operand maps (cdna_hip_programming.md
 // section 3): A lane l -> A[row l&15][k l>>4], B lane l -> B[k l>>4][col l&15],
-// D reg r -> D[row (l>>4)+4r][col l&15].
-// Tile shapes 128x128 (4 or 8 waves), 128x64, 64x64: the fp64 MFMA rate per CU is low
-// (one 16x16x4 per 64 cycles per SIMD), so short or narrow updates need many
-// small tiles to cover 256 CUs while the big trailing updates want 128x128
-// for L2 traffic; launch_gemm picks per call.
+// D reg r -> D[row (l>>4)+4r][col l&15].  A lane reads its fragment as one ds_read_b128 = the doubles k = 8t+2g, 8t+2g+1
+// of its row and feeds them to MFMA k-steps 2t and 2t+1 (A and B use the same k permutation: contraction unchanged).
+// Two tile shapes: the fp64 MFMA rate per CU is low (one 16x16x4 per 64 cycles per SIMD), so short or narrow updates
+// need many small tiles to cover 256 CUs while the big trailing updates want 128x128 for L2 traffic; launch_gemm
+// picks per call.
 // ---------------------------------------------------------------------------
 // (A persistent variant -- grid = resident workgroups, tile loop with the next tile's first chunk and the C
 // tile prefetched under the epilogue -- was measured 5-10 % slower on the big updates (register pressure,
@@ -72,42 +65,31 @@ template <int P, int LD> __device__ __forceinline__ void panel_factor(double *A,
 template <int P, int LD> __device__ __forceinline__ void panel_update(double *A, int wave, int lane);
 __device__ __forceinline__ void tri_inverse16(double *M, int o, double *tile, int lane);
 
-// PF = global-load prefetch distance in k-steps.  1: the chunk for step k+1 is requested at the top of step k and
-// written to LDS at its end.  2 (two register stages, for the 64x64 tiles that have the registers to spare): requested
-// two steps ahead -- the short-K panel updates are chains of dependent HBM round trips, one per k-step, and this halves
-// the chain.
-// L2PF = 1: every thread also touches one 64-byte sector of the chunk AFTER the next one (a 4-byte load whose value is
-// never used): the real 16-byte loads of that chunk, issued a k-step later, then find their lines in the XCD's L2
-// instead of paying the fabric / HBM round trip inside their own k-step -- a prefetch distance of two k-steps for one
-// VGPR, where a second register stage (PF = 2) would cost 16 and drop the 128x128 tiles to one workgroup per CU.
 // FA = 1 (factor-ahead, 64x64 tiles of a triangular trailing update): the workgroup of tile (0,0) -- the diagonal block
 // the NEXT leaf factorisation starts from -- does not store its updated tile: it keeps it in LDS, factors it there
 // (the leaf_factor_kernel code) and writes L.  The 64 sequential pivots of that block then run beside the other tiles
 // of the update instead of in a launch of their own behind it (one launch and ~10 us less on the critical chain per
 // 64 columns); the arithmetic is the update's and the leaf's, so the bits do not change.
-// DMA = 1 (128x128 tiles, 8 waves): the operand chunks go global -> LDS directly (buffer_load ... lds, 1 KB per
+// Operand staging: the 16-deep operand chunks go global -> LDS directly (buffer_load ... lds, 1 KB per
 // wave-instruction, no staging registers, no ds_write pass) into an unpadded image whose 16-byte slots are XOR-swizzled
-// through the SOURCE address (the destination of an LDS-DMA is lane-linear); the 40 VGPRs this frees hold a second set
+// through the SOURCE address (the destination of an LDS-DMA is lane-linear); the registers this frees hold a second set
 // of MFMA fragments, so the LDS reads of one half k-step are issued a whole block of 16 MFMAs before their use, and the
 // one barrier of a k-step sits between the two blocks: after it the next chunk's DMA starts (a full k-step to land) and
-// the first fragments of the next chunk are read under the second block.  Same MFMA sequence per accumulator as the
-// register-staged loop: the bits do not change.
-template <int BM, int BN, int MINW, int WGM = 2, int WGN = 2, int PF = 1, int L2PF = 0, int FA = 0, int DMA = 0>
+// the first fragments of the next chunk are read under the second block.  Per accumulator the MFMA sequence is the
+// k-ordered chain whatever the tile shape: 128x128 and 64x64 tiles give the same bits.
+// (The register-staged loops of rounds 1-2, their L2-prefetch variant and the 128x64 / 256x128 / 128x256 shapes measured
+// slower -- profiles/r02_gemm_*.txt -- and left the tree in round 3; `git log` has them.)
+template <int BM, int BN, int MINW, int WGM, int WGN, int FA = 0>
 __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs g)
 {
-	constexpr int NT = 64 * WGM * WGN;              // threads: WGM x WGN waves
 	constexpr int WM = BM / WGM, WN = BN / WGN;
 	constexpr int TM = WM / 16, TN = WN / 16;
-	constexpr int AIT = BM * 8 / NT, BIT = BN * 8 / NT;
 	constexpr int NW = WGM * WGN;                       // waves
-	constexpr int NPA = BM / (8 * NW), NPB = BN / (8 * NW);      // LDS-DMA pieces (8 rows x 128 B) per wave and operand (DMA = 1)
-	constexpr int SMEM_GEMM = 2 * (BM + BN) * (DMA ? GEMM_BK : LDS_S);      // the LDS-DMA image has no padding
+	constexpr int NPA = BM / (8 * NW), NPB = BN / (8 * NW);      // LDS-DMA pieces (8 rows x 128 B) per wave and operand
+	constexpr int SMEM_GEMM = 2 * (BM + BN) * GEMM_BK;        // two unpadded chunk images
 	constexpr int SMEM = (FA && LEAF * LP > SMEM_GEMM) ? LEAF * LP : SMEM_GEMM;
 	__shared__ double smem[SMEM];
-	double (*As)[BM * LDS_S] = reinterpret_cast<double (*)[BM * LDS_S]>(smem);
-	double (*Bs)[BN * LDS_S] = reinterpret_cast<double (*)[BN * LDS_S]>(smem + 2 * BM * LDS_S);
 
-	if (g.prio) __builtin_amdgcn_s_setprio(3);          // a chain launch beside a bulk update: its instructions issue first
 	// batch of independent problems (lock-step factorisations): blockIdx.y selects the matrix
 	g.C += (long)blockIdx.y * g.bsC;
 	g.A += (long)blockIdx.y * g.bsA;
@@ -178,48 +160,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 	const int wave = tid >> 6;
 	const int wm = wave / WGN, wn = wave % WGN;
 
-	// staging map: (row, 16-byte segment) pairs per operand per thread
-	const double *ag[AIT];
-	const double *bg[BIT];
-	int lofs_a[AIT], lofs_b[BIT];
-#pragma unroll
-	for (int it = 0; it < AIT; it++) {
-		int idx = tid + NT * it;
-		int row = idx >> 3, seg = idx & 7;
-		int ar = tm * BM + row; if (ar > g.m - 1) ar = g.m - 1;
-		ag[it] = g.A + (long)ar * g.lda + 2 * seg;
-		lofs_a[it] = row * LDS_S + 2 * seg;
-	}
-#pragma unroll
-	for (int it = 0; it < BIT; it++) {
-		int idx = tid + NT * it;
-		int row = idx >> 3, seg = idx & 7;
-		int br = tn * BN + row; if (br > g.n - 1) br = g.n - 1;
-		bg[it] = g.B + (long)br * g.ldb + 2 * seg;
-		lofs_b[it] = row * LDS_S + 2 * seg;
-	}
-
-	// L2 prefetch map: thread -> (row of the A|B tile rows, 64-byte half of its 128-byte k-chunk)
-	// (a buffer descriptor on the wave-uniform first row of the tile's operand rows + a 32-bit byte offset per lane;
-	// the k advance is the scalar offset of the load: no vector address arithmetic, one VGPR besides the target)
-	__amdgpu_buffer_rsrc_t pf_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(g.A), 0, 0, 0x00020000);
-	unsigned pf_off = 0;
-	if (L2PF) {
-		const int prow = (tid >> 1) % (BM + BN), half = tid & 1;
-		const bool isA = __builtin_amdgcn_readfirstlane(prow < BM ? 1 : 0) != 0;      // whole waves take A rows or B rows
-		static_assert(!L2PF || (BM % 32 == 0 && BN % 32 == 0), "a wave's 32 prefetch rows lie in one operand");
-		const double *base = isA ? g.A : g.B;
-		const long ldx = isA ? g.lda : g.ldb;
-		const int lim = (isA ? g.m : g.n) - 1;
-		int r = isA ? tm * BM + prow : tn * BN + (prow - BM);
-		if (r > lim) r = lim;
-		int r0 = isA ? tm * BM : tn * BN;
-		if (r0 > lim) r0 = lim;
-		pf_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(base + (long)r0 * ldx), 0, -1, 0x00020000);
-		pf_off = (unsigned)((long)(r - r0) * ldx * 8 + 64 * half);
-	}
-	int pfv = 0;
-
 	// The accumulators start from the C tile itself (scaled by beta/alpha, alpha = +-1 when beta is set: exact), so
 	// the read half of the read-modify-write overlaps the operand prologue and the epilogue is stores only.  (Read
 	// in the epilogue, load and store of one element serialise: 11 us per 128x128 tile, 38 us under load.)
@@ -266,217 +206,104 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 			for (int j = 0; j < TN; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
 	}
 
-	const int a_base = (wm * WM + (lane & 15)) * LDS_S + 2 * (lane >> 4);
-	const int b_base = (wn * WN + (lane & 15)) * LDS_S + 2 * (lane >> 4);
-
-#define GEMM_LOAD(RA, RB, kk)                                                                                     \
-	do {                                                                                                          \
-		_Pragma("unroll") for (int it = 0; it < AIT; it++) RA[it] = *reinterpret_cast<const d2_t *>(ag[it] + (kk)); \
-		_Pragma("unroll") for (int it = 0; it < BIT; it++) RB[it] = *reinterpret_cast<const d2_t *>(bg[it] + (kk)); \
-	} while (0)
-#define GEMM_STORE(RA, RB, buf)                                                                                   \
-	do {                                                                                                          \
-		_Pragma("unroll") for (int it = 0; it < AIT; it++) *reinterpret_cast<d2_t *>(&As[buf][lofs_a[it]]) = RA[it]; \
-		_Pragma("unroll") for (int it = 0; it < BIT; it++) *reinterpret_cast<d2_t *>(&Bs[buf][lofs_b[it]]) = RB[it]; \
-	} while (0)
-#define GEMM_STEP(buf)                                                                                            \
-	do {                                                                                                          \
-		const double *as = As[buf];                                                                               \
-		const double *bs = Bs[buf];                                                                               \
-		_Pragma("unroll") for (int t = 0; t < GEMM_BK / 8; t++) {                                                  \
-			d2_t a[TM], b[TN];                                                                                    \
-			_Pragma("unroll") for (int i = 0; i < TM; i++)                                                         \
-				a[i] = *reinterpret_cast<const d2_t *>(&as[a_base + i * 16 * LDS_S + 8 * t]);                      \
-			_Pragma("unroll") for (int j = 0; j < TN; j++)                                                         \
-				b[j] = *reinterpret_cast<const d2_t *>(&bs[b_base + j * 16 * LDS_S + 8 * t]);                      \
+	static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && NW % 2 == 0 && NPA + NPB <= 8 && GEMM_BK == 16 && WM % 16 == 0 && WN % 16 == 0,
+	              "LDS-DMA loop: 16-deep chunks, 8-row pieces dealt to the waves in turn");
+	if (kb < ke) {
+		// LDS image (bytes): buffer b at b * BUFB; operand row R (A rows 0..BM-1, then the B rows) at R * 128; its 16-byte
+		// segment s (doubles 2s, 2s+1 of the chunk) in slot s ^ f(R), f(R) = (r >> 1) ^ (4 <= r <= 11), r = R mod 16.
+		// A ds_read_b128 is served in four groups of 16 non-contiguous lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}
+		// and the same + 32 (MI355X_MICROARCH.md, LDS) -- i.e. with fragment lane = q + 16 g: rows q in {0-3, 12-15} at
+		// segment 4t+g together with rows q in {4-11} at segment 4t+(g^1).  Rows alternate between the two 128-byte halves
+		// of the 256-byte bank row (row stride 128 B), so the 8 even and the 8 odd rows of a group each need 8 different
+		// slots: (4t+g) ^ f(q) for the outer rows and (4t+g) ^ 1 ^ f(q) for the middle ones are 8 different values because
+		// f(q) ^ (4 <= q <= 11) = q >> 1.  (The first form of the swizzle, (R & 7) ^ ((R >> 3) & 1), assumed contiguous
+		// 16-lane groups: SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE.)
+		constexpr int BUFB = (BM + BN) * GEMM_BK * 8;
+		char *lds = reinterpret_cast<char *>(smem);
+		// DMA pieces: wave w moves rows 8 NW p + 8 w .. + 7 of the image for p = 0 .. NPA+NPB-1 (the first NPA: A rows),
+		// lane l -> row + (l >> 3), slot l & 7 (8 NW is a multiple of 16: row mod 16, hence f, does not depend on p)
+		const int uw = __builtin_amdgcn_readfirstlane(wave);
+		const int prow = 8 * uw + (lane >> 3);
+		const int prow16 = prow & 15;
+		const int pseg = (lane & 7) ^ ((prow16 >> 1) ^ (((prow16 + 4) >> 3) & 1));
+		int ra0 = tm * BM; if (ra0 > g.m - 1) ra0 = g.m - 1;
+		int rb0 = tn * BN; if (rb0 > g.n - 1) rb0 = g.n - 1;
+		const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(g.A + (long)ra0 * g.lda), 0, -1, 0x00020000);
+		const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(g.B + (long)rb0 * g.ldb), 0, -1, 0x00020000);
+		unsigned vo[8];                                   // (a size that depends on the template arguments loses the host stubs with this hipcc)
+#pragma unroll
+		for (int p = 0; p < NPA; p++) {
+			int ar = tm * BM + 8 * NW * p + prow; if (ar > g.m - 1) ar = g.m - 1;
+			vo[p] = (unsigned)((long)(ar - ra0) * g.lda * 8 + 16 * pseg);
+		}
+#pragma unroll
+		for (int p = 0; p < NPB; p++) {
+			int br = tn * BN + 8 * NW * p + prow; if (br > g.n - 1) br = g.n - 1;
+			vo[NPA + p] = (unsigned)((long)(br - rb0) * g.ldb * 8 + 16 * pseg);
+		}
+		typedef __attribute__((address_space(3))) void *lds_ptr_t;
+#define GEMM_DMA1(rs, d, p, kk) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)((d) + 1024 * NW * (p)), 16, vo[p], (kk) * 8, 0, 0)
+#define GEMM_DMA(buf, kk)                                                                                         \
+		do {                                                                                                      \
+			char *d = lds + (buf) * BUFB + uw * 1024;                                                              \
+			GEMM_DMA1(rsA, d, 0, kk);                                                                              \
+			if constexpr (NPA > 1) GEMM_DMA1(rsA, d, 1, kk);                                                       \
+			if constexpr (NPA > 2) GEMM_DMA1(rsA, d, 2, kk);                                                       \
+			if constexpr (NPA > 3) GEMM_DMA1(rsA, d, 3, kk);                                                       \
+			GEMM_DMA1(rsB, d, NPA, kk);                                                                            \
+			if constexpr (NPB > 1) GEMM_DMA1(rsB, d, NPA + 1, kk);                                                 \
+			if constexpr (NPB > 2) GEMM_DMA1(rsB, d, NPA + 2, kk);                                                 \
+			if constexpr (NPB > 3) GEMM_DMA1(rsB, d, NPA + 3, kk);                                                 \
+		} while (0)
+		// fragment addresses: lane (q, gq) reads row q of its 16-row group, logical segment 4 t + gq
+		const int q = lane & 15, gq = lane >> 4;
+		const int fsw = (q >> 1) ^ (((q + 4) >> 3) & 1);
+		const int fa0 = (wm * WM + q) * 128 + 16 * (gq ^ fsw);
+		const int fb0 = (BM + wn * WN + q) * 128 + 16 * (gq ^ fsw);
+#define GEMM_FRAGS(FA_, FB_, buf, t)                                                                              \
+		do {                                                                                                      \
+			const char *pa = lds + (buf) * BUFB + (fa0 ^ (64 * (t)));                                              \
+			const char *pb = lds + (buf) * BUFB + (fb0 ^ (64 * (t)));                                              \
+			_Pragma("unroll") for (int i = 0; i < TM; i++) FA_[i] = *reinterpret_cast<const d2_t *>(pa + i * 2048); \
+			_Pragma("unroll") for (int j = 0; j < TN; j++) FB_[j] = *reinterpret_cast<const d2_t *>(pb + j * 2048); \
+		} while (0)
+#define GEMM_BLOCK(FA_, FB_)                                                                                      \
+		do {                                                                                                      \
 			_Pragma("unroll") for (int h = 0; h < 2; h++)                                                          \
 				_Pragma("unroll") for (int i = 0; i < TM; i++)                                                     \
 					_Pragma("unroll") for (int j = 0; j < TN; j++)                                                 \
-						acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][h], b[j][h], acc[i][j], 0, 0, 0);    \
-		}                                                                                                         \
-	} while (0)
-	if (DMA) {
-		static_assert(!DMA || (BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && NW % 2 == 0 && NPA + NPB <= 8 && GEMM_BK == 16 && WM % 16 == 0 && WN % 16 == 0),
-		              "LDS-DMA loop: 16-deep chunks, 8-row pieces dealt to the waves in turn");
-		if (kb < ke) {
-			// LDS image (bytes): buffer b at b * BUFB; operand row R (A rows 0..BM-1, then the B rows) at R * 128; its 16-byte
-			// segment s (doubles 2s, 2s+1 of the chunk) in slot s ^ f(R), f(R) = (r >> 1) ^ (4 <= r <= 11), r = R mod 16.
-			// A ds_read_b128 is served in four groups of 16 non-contiguous lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}
-			// and the same + 32 (MI355X_MICROARCH.md, LDS) -- i.e. with fragment lane = q + 16 g: rows q in {0-3, 12-15} at
-			// segment 4t+g together with rows q in {4-11} at segment 4t+(g^1).  Rows alternate between the two 128-byte halves
-			// of the 256-byte bank row (row stride 128 B), so the 8 even and the 8 odd rows of a group each need 8 different
-			// slots: (4t+g) ^ f(q) for the outer rows and (4t+g) ^ 1 ^ f(q) for the middle ones are 8 different values because
-			// f(q) ^ (4 <= q <= 11) = q >> 1.  (The first form of the swizzle, (R & 7) ^ ((R >> 3) & 1), assumed contiguous
-			// 16-lane groups: SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE.)
-			constexpr int BUFB = (BM + BN) * GEMM_BK * 8;
-			char *lds = reinterpret_cast<char *>(smem);
-			// DMA pieces: wave w moves rows 8 NW p + 8 w .. + 7 of the image for p = 0 .. NPA+NPB-1 (the first NPA: A rows),
-			// lane l -> row + (l >> 3), slot l & 7 (8 NW is a multiple of 16: row mod 16, hence f, does not depend on p)
-			const int uw = __builtin_amdgcn_readfirstlane(wave);
-			const int prow = 8 * uw + (lane >> 3);
-			const int prow16 = prow & 15;
-			const int pseg = (lane & 7) ^ ((prow16 >> 1) ^ (((prow16 + 4) >> 3) & 1));
-			int ra0 = tm * BM; if (ra0 > g.m - 1) ra0 = g.m - 1;
-			int rb0 = tn * BN; if (rb0 > g.n - 1) rb0 = g.n - 1;
-			const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(g.A + (long)ra0 * g.lda), 0, -1, 0x00020000);
-			const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(g.B + (long)rb0 * g.ldb), 0, -1, 0x00020000);
-			unsigned vo[8];                                   // (a size that depends on the template arguments loses the host stubs with this hipcc)
-#pragma unroll
-			for (int p = 0; p < NPA; p++) {
-				int ar = tm * BM + 8 * NW * p + prow; if (ar > g.m - 1) ar = g.m - 1;
-				vo[p] = (unsigned)((long)(ar - ra0) * g.lda * 8 + 16 * pseg);
-			}
-#pragma unroll
-			for (int p = 0; p < NPB; p++) {
-				int br = tn * BN + 8 * NW * p + prow; if (br > g.n - 1) br = g.n - 1;
-				vo[NPA + p] = (unsigned)((long)(br - rb0) * g.ldb * 8 + 16 * pseg);
-			}
-			typedef __attribute__((address_space(3))) void *lds_ptr_t;
-#define GEMM_DMA1(rs, d, p, kk) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)((d) + 1024 * NW * (p)), 16, vo[p], (kk) * 8, 0, 0)
-#define GEMM_DMA(buf, kk)                                                                                         \
-			do {                                                                                                      \
-				char *d = lds + (buf) * BUFB + uw * 1024;                                                              \
-				GEMM_DMA1(rsA, d, 0, kk);                                                                              \
-				if constexpr (NPA > 1) GEMM_DMA1(rsA, d, 1, kk);                                                       \
-				if constexpr (NPA > 2) GEMM_DMA1(rsA, d, 2, kk);                                                       \
-				if constexpr (NPA > 3) GEMM_DMA1(rsA, d, 3, kk);                                                       \
-				GEMM_DMA1(rsB, d, NPA, kk);                                                                            \
-				if constexpr (NPB > 1) GEMM_DMA1(rsB, d, NPA + 1, kk);                                                 \
-				if constexpr (NPB > 2) GEMM_DMA1(rsB, d, NPA + 2, kk);                                                 \
-				if constexpr (NPB > 3) GEMM_DMA1(rsB, d, NPA + 3, kk);                                                 \
-			} while (0)
-			// fragment addresses: lane (q, gq) reads row q of its 16-row group, logical segment 4 t + gq
-			const int q = lane & 15, gq = lane >> 4;
-			const int fsw = (q >> 1) ^ (((q + 4) >> 3) & 1);
-			const int fa0 = (wm * WM + q) * 128 + 16 * (gq ^ fsw);
-			const int fb0 = (BM + wn * WN + q) * 128 + 16 * (gq ^ fsw);
-#define GEMM_FRAGS(FA_, FB_, buf, t)                                                                              \
-			do {                                                                                                      \
-				const char *pa = lds + (buf) * BUFB + (fa0 ^ (64 * (t)));                                              \
-				const char *pb = lds + (buf) * BUFB + (fb0 ^ (64 * (t)));                                              \
-				_Pragma("unroll") for (int i = 0; i < TM; i++) FA_[i] = *reinterpret_cast<const d2_t *>(pa + i * 2048); \
-				_Pragma("unroll") for (int j = 0; j < TN; j++) FB_[j] = *reinterpret_cast<const d2_t *>(pb + j * 2048); \
-			} while (0)
-#define GEMM_BLOCK(FA_, FB_)                                                                                      \
-			do {                                                                                                      \
-				_Pragma("unroll") for (int h = 0; h < 2; h++)                                                          \
-					_Pragma("unroll") for (int i = 0; i < TM; i++)                                                     \
-						_Pragma("unroll") for (int j = 0; j < TN; j++)                                                 \
-							acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA_[i][h], FB_[j][h], acc[i][j], 0, 0, 0); \
-			} while (0)
-			d2_t xa[TM], xb[TN], ya[TM], yb[TN];
-			GEMM_DMA(0, kb);
+						acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA_[i][h], FB_[j][h], acc[i][j], 0, 0, 0); \
+		} while (0)
+		d2_t xa[TM], xb[TN], ya[TM], yb[TN];
+		// (every wave's buffer_load ... lds must have landed before the barrier that hands the chunk to the other waves: the
+		// compiler places this wait itself today; it is spelled out so that correctness does not hang on that)
+		GEMM_DMA(0, kb);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		if (kb + GEMM_BK < ke) GEMM_DMA(1, kb + GEMM_BK);
+		GEMM_FRAGS(xa, xb, 0, 0);
+		if (g.trace && tr0.wall) atomicAdd(g.trace + 5, (unsigned long long)clock64() - tr0.clk);   // prologue
+		int cur = 0;
+		for (int k = kb; k < ke; k += GEMM_BK) {
+			GEMM_FRAGS(ya, yb, cur, 1);
+			__builtin_amdgcn_sched_barrier(0);
+			GEMM_BLOCK(xa, xb);
+			__builtin_amdgcn_sched_barrier(0);
+			// chunk k+1 (requested a k-step ago) has landed for every wave; every wave has read the last of chunk k
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			__syncthreads();
-			if (kb + GEMM_BK < ke) GEMM_DMA(1, kb + GEMM_BK);
-			GEMM_FRAGS(xa, xb, 0, 0);
-			if (g.trace && tr0.wall) atomicAdd(g.trace + 5, (unsigned long long)clock64() - tr0.clk);   // prologue
-			int cur = 0;
-			for (int k = kb; k < ke; k += GEMM_BK) {
-				GEMM_FRAGS(ya, yb, cur, 1);
-				__builtin_amdgcn_sched_barrier(0);
-				GEMM_BLOCK(xa, xb);
-				__builtin_amdgcn_sched_barrier(0);
-				// chunk k+1 (requested a k-step ago) has landed for every wave; every wave has read the last of chunk k
-				__syncthreads();
-				if (k + 2 * GEMM_BK < ke) GEMM_DMA(cur, k + 2 * GEMM_BK);
-				if (k + GEMM_BK < ke) GEMM_FRAGS(xa, xb, cur ^ 1, 0);
-				__builtin_amdgcn_sched_barrier(0);
-				GEMM_BLOCK(ya, yb);
-				__builtin_amdgcn_sched_barrier(0);
-				cur ^= 1;
-			}
+			if (k + 2 * GEMM_BK < ke) GEMM_DMA(cur, k + 2 * GEMM_BK);
+			if (k + GEMM_BK < ke) GEMM_FRAGS(xa, xb, cur ^ 1, 0);
+			__builtin_amdgcn_sched_barrier(0);
+			GEMM_BLOCK(ya, yb);
+			__builtin_amdgcn_sched_barrier(0);
+			cur ^= 1;
+		}
 #undef GEMM_DMA
 #undef GEMM_DMA1
 #undef GEMM_FRAGS
 #undef GEMM_BLOCK
-		}
-	} else
-	if (PF == 2 && kb < ke) {
-		d2_t r0a[AIT], r0b[BIT], r1a[AIT], r1b[BIT];
-		GEMM_LOAD(r0a, r0b, kb);
-		if (kb + GEMM_BK < ke) GEMM_LOAD(r1a, r1b, kb + GEMM_BK);
-		GEMM_STORE(r0a, r0b, 0);
-		__syncthreads();
-		if (g.trace && tr0.wall) atomicAdd(g.trace + 5, (unsigned long long)clock64() - tr0.clk);   // prologue
-		int cur = 0;
-		for (int k = kb; k < ke; k += 2 * GEMM_BK) {
-			// even step: chunk k is in LDS[cur], chunk k+16 in r1 (requested a step ago); request chunk k+32 into r0
-			if (k + 2 * GEMM_BK < ke) GEMM_LOAD(r0a, r0b, k + 2 * GEMM_BK);
-			GEMM_STEP(cur);
-			if (k + GEMM_BK < ke) GEMM_STORE(r1a, r1b, cur ^ 1);
-			__syncthreads();
-			cur ^= 1;
-			if (k + GEMM_BK >= ke) break;
-			// odd step: chunk k+16 in LDS[cur], chunk k+32 in r0; request chunk k+48 into r1
-			if (k + 3 * GEMM_BK < ke) GEMM_LOAD(r1a, r1b, k + 3 * GEMM_BK);
-			GEMM_STEP(cur);
-			if (k + 2 * GEMM_BK < ke) GEMM_STORE(r0a, r0b, cur ^ 1);
-			__syncthreads();
-			cur ^= 1;
-		}
-	} else if (kb < ke) {
-		d2_t ra[AIT], rb[BIT];
-#pragma unroll
-		for (int it = 0; it < AIT; it++) ra[it] = *reinterpret_cast<const d2_t *>(ag[it] + kb);
-#pragma unroll
-		for (int it = 0; it < BIT; it++) rb[it] = *reinterpret_cast<const d2_t *>(bg[it] + kb);
-#pragma unroll
-		for (int it = 0; it < AIT; it++) *reinterpret_cast<d2_t *>(&As[0][lofs_a[it]]) = ra[it];
-#pragma unroll
-		for (int it = 0; it < BIT; it++) *reinterpret_cast<d2_t *>(&Bs[0][lofs_b[it]]) = rb[it];
-		__syncthreads();
-		if (g.trace && tr0.wall) atomicAdd(g.trace + 5, (unsigned long long)clock64() - tr0.clk);   // prologue
-
-		int cur = 0;
-		int step = 0;
-		for (int k = kb; k < ke; k += GEMM_BK, step++) {
-			const bool more = (k + GEMM_BK) < ke;
-			if (more) {
-#pragma unroll
-				for (int it = 0; it < AIT; it++) ra[it] = *reinterpret_cast<const d2_t *>(ag[it] + k + GEMM_BK);
-#pragma unroll
-				for (int it = 0; it < BIT; it++) rb[it] = *reinterpret_cast<const d2_t *>(bg[it] + k + GEMM_BK);
-			}
-			if (L2PF) {
-				// touch the chunk after the next one.  Issued AFTER the real loads (they are not held up behind it) and
-				// unconditionally (every thread, the k offset clamped at the tail): only then can the compiler count it
-				// and wait for the real loads with vmcnt(1) instead of vmcnt(0)
-				static_assert(!L2PF || NT == 2 * (BM + BN), "one 64-byte sector per thread");
-				int kp = k + 2 * GEMM_BK;
-				if (kp > ke - GEMM_BK) kp = ke - GEMM_BK;
-				pfv = __builtin_amdgcn_raw_buffer_load_b32(pf_rsrc, pf_off, kp * 8, 0);
-			}
-			const double *as = As[cur];
-			const double *bs = Bs[cur];
-#pragma unroll
-			for (int t = 0; t < GEMM_BK / 8; t++) {
-				d2_t a[TM], b[TN];
-#pragma unroll
-				for (int i = 0; i < TM; i++) a[i] = *reinterpret_cast<const d2_t *>(&as[a_base + i * 16 * LDS_S + 8 * t]);
-#pragma unroll
-				for (int j = 0; j < TN; j++) b[j] = *reinterpret_cast<const d2_t *>(&bs[b_base + j * 16 * LDS_S + 8 * t]);
-#pragma unroll
-				for (int h = 0; h < 2; h++)
-#pragma unroll
-					for (int i = 0; i < TM; i++)
-#pragma unroll
-						for (int j = 0; j < TN; j++)
-							acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][h], b[j][h], acc[i][j], 0, 0, 0);
-			}
-			if (more) {
-#pragma unroll
-				for (int it = 0; it < AIT; it++) *reinterpret_cast<d2_t *>(&As[cur ^ 1][lofs_a[it]]) = ra[it];
-#pragma unroll
-				for (int it = 0; it < BIT; it++) *reinterpret_cast<d2_t *>(&Bs[cur ^ 1][lofs_b[it]]) = rb[it];
-			}
-			__syncthreads();
-			cur ^= 1;
-		}
-		if (L2PF) asm volatile("" :: "v"(pfv));                  // the touched values are never used
 	}
-#undef GEMM_LOAD
-#undef GEMM_STORE
-#undef GEMM_STEP
 
 	// epilogue: alpha * accumulators (a sign flip or nothing for alpha = -+1, see above)
 	unsigned long long clk_loop_end = 0;
@@ -521,100 +348,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 		if (wave == 0) panel_factor<3, LP>(A, lane, bad, 0);
 		__syncthreads();
 		if (tid == 0 && bad) atomicMin(g.fa_info + blockIdx.y, g.fa_c0 + bad);
-		if (!g.sa) {
 #pragma unroll
-			for (int u = 0; u < 16; u++) {
-				const int r = wave + 4 * u;
-				if (lane <= r) g.C[(long)r * g.ldc + lane] = A[r * LP + lane];
-			}
-		} else {
-			// solve-ahead: L goes out by write-through (sc1) stores and is published to the workgroups of tile column 0
-			// by a flag (MI355X_MICROARCH.md, inter-workgroup visibility, the form without fences: every byte handed
-			// over is stored sc1, every storing wave drains its stores, barrier, one lane stores the flag; the readers
-			// load those bytes sc1).  An agent-scope release fence instead would write back every dirty line of this
-			// XCD's L2 -- the other tiles' output of this very update -- and cost more than the launch it saves.
-#pragma unroll
-			for (int u = 0; u < 16; u++) {
-				const int r = wave + 4 * u;
-				if (lane <= r) __hip_atomic_store(&g.C[(long)r * g.ldc + lane], A[r * LP + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			}
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			__syncthreads();
-			if (tid == 0) __hip_atomic_store(g.sa_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		}
-		trace_end(g.trace, tr0);
-		return;
-	}
-	if (FA && g.sa && tn == 0 && tm > 0) {
-		// Solve-ahead (one matrix per launch only): this tile holds 64 rows of the block column whose diagonal block
-		// tile (0,0) is factoring right now.  Instead of storing the updated rows and leaving X L^T = B to a launch of
-		// its own, wait for L and solve here (the leaf_solve_kernel arithmetic on the same values: same bits).
-		// At most (rows below)/64 <= a few hundred workgroups wait, tile (0,0) never waits for anything and is the first
-		// workgroup of the grid: no waiting workgroup can keep it off the chip.  The wait is bounded all the same.
-		double *M = smem;
-#pragma unroll
-		for (int i = 0; i < TM; i++)
-#pragma unroll
-			for (int r = 0; r < 4; r++)
-#pragma unroll
-				for (int j = 0; j < TN; j++)
-					M[(wm * WM + i * 16 + (lane >> 4) + 4 * r) * LP + wn * WN + j * 16 + (lane & 15)] = acc[i][j][r];
-		__syncthreads();
-		const int q = lane & 15, gq = lane >> 4;
-		d4_t R[4];                         // wave w: rows 16w .. 16w+15 in the solve's layout (lane (q,g): row q, columns 16j + g + 4r)
-#pragma unroll
-		for (int j = 0; j < 4; j++)
-#pragma unroll
-			for (int r = 0; r < 4; r++) R[j][r] = M[(16 * wave + q) * LP + 16 * j + gq + 4 * r];
-		__syncthreads();
-		if (tid == 0) {
-			long spins = 0;
-			while (__hip_atomic_load(g.sa_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-				__builtin_amdgcn_s_sleep(8);
-				if (++spins > 400000L) { atomicMin(g.fa_info, -1); break; }       // (~0.3 s; never seen) reported as a device failure
-			}
-		}
-		__syncthreads();
-		{
-			// L (lower triangle of the diagonal block, tile (0,0)) by sc1 loads; the strict upper part is scratch for the
-			// 16x16 inversions and is not read from memory
-			const double *D = g.C;
-			double v[16];
-#pragma unroll
-			for (int u = 0; u < 16; u++) {
-				const int r = wave + 4 * u;
-				v[u] = (lane <= r) ? __hip_atomic_load(&D[(long)r * g.ldc + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-			}
-#pragma unroll
-			for (int u = 0; u < 16; u++) M[(wave + 4 * u) * LP + lane] = v[u];
-		}
-		__syncthreads();
-		{
-			const int sr = (wave == 3) ? 0 : wave, sc = (wave == 3) ? 3 : wave + 1;
-			tri_inverse16(M, 16 * wave, M + 16 * sr * LP + 16 * sc, lane);
-		}
-		__syncthreads();
-		double *bp = g.C + (long)(tm * BM + 16 * wave + q) * g.ldc;
-		d4_t X[4];
-#pragma unroll
-		for (int j = 0; j < 4; j++) {
-			d4_t a4 = R[j];
-#pragma unroll
-			for (int i = 0; i < j; i++)
-#pragma unroll
-				for (int r = 0; r < 4; r++) {
-					const double a = -M[(16 * j + q) * LP + 16 * i + gq + 4 * r];
-					a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[i][r], a4, 0, 0, 0);
-				}
-			d4_t xj = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-			for (int r = 0; r < 4; r++) {
-				const double a = M[(16 * j + q) * LP + 16 * j + gq + 4 * r];
-				xj = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a4[r], xj, 0, 0, 0);
-			}
-			X[j] = xj;
-#pragma unroll
-			for (int r = 0; r < 4; r++) bp[16 * j + gq + 4 * r] = xj[r];
+		for (int u = 0; u < 16; u++) {
+			const int r = wave + 4 * u;
+			if (lane <= r) g.C[(long)r * g.ldc + lane] = A[r * LP + lane];
 		}
 		trace_end(g.trace, tr0);
 		return;
@@ -739,44 +476,34 @@ static long count_tiles(const GemmArgs &a, int BM, int BN)
 	return c;
 }
 
-int g_gemm_small_dma = 1;      // 64x64 tiles by the LDS-DMA loop too (GPEMU_GEMM_SMALL_DMA=0: register-staged, two k-steps ahead)
-int g_gemm_force_cfg = -1;   // test/bench hook: 0 = 128x128, 1 = 128x64, 2 = 64x64
-
-// Tile shape per call (measured on MI355X, profiles/r01_gemm_tile_sweep.txt): with thousands of 128x128 tiles
-// the big shape wins (less LDS/L2 traffic per flop: 60-62 vs 52 TF/s on the prediction GEMM); below that the
-// 64x64 shape is never slower (more workgroups for 256 CUs, 4 resident per CU) and up to 3x faster on the
-// narrow K<=256 updates of the factorisation.
-int g_gemm_table = 8;          // XCD-blocked tile order from a table for launches of >= 512 tiles: side of the super-blocks (GPEMU_GEMM_TABLE; 0: off)
-int g_gemm_big_cfg = 8;        // tile configuration of the big launches (8: 128x128 8 waves by LDS-DMA, 3: the same tiles register-staged, 0: 4 waves)
-int g_gemm_big_tiles = 1024;   // 128x128 tiles (8 waves) once a lock-step launch has this many of them (twice as many for one matrix), else 64x64
-
-bool gemm_uses_big_tiles(const GemmArgs &a)
+// Tile shape per call (measured on MI355X, profiles/r01_gemm_tile_sweep.txt, r02_gemm_*.txt): with thousands of 128x128
+// tiles the big shape wins (less LDS/L2 traffic per flop); below that the 64x64 shape is never slower (more workgroups
+// for 256 CUs, 4-5 resident per CU) and up to 3x faster on the narrow K<=256 updates of the factorisation.
+// The switches travel in the GemmArgs of each call (filled from the calling context's Sched): nothing process-wide.
+//   a.force_cfg  test/bench hook: 2 = 64x64, 8 = 128x128, 0 = automatic
+//   a.big_tiles  128x128 tiles (8 waves) once a lock-step launch has this many of them (twice as many for one matrix)
+//   a.table_sb   XCD-blocked tile order from a table for launches of >= 512 tiles: side of the super-blocks (0: off)
+int choose_gemm_cfg(const GemmArgs &a)
 {
-	int choose_gemm_cfg(const GemmArgs &a);
-	return choose_gemm_cfg(a) != 2;
+	if (a.force_cfg == 2 || a.force_cfg == 8) return a.force_cfg;
+	const int big_tiles = a.big_tiles > 0 ? a.big_tiles : 1024;
+	// one matrix per launch: twice the threshold -- 1000-2000 tiles on the 512 resident workgroups of the chip are 2-4
+	// rounds, and the partly filled last one costs more than the faster tile gains (6.3 against 6.2 ms per evaluation)
+	const long thr = (a.nbatch > 1 || big_tiles < 64) ? big_tiles : 2L * big_tiles;   // (< 64: test settings, taken literally)
+	// updates narrower than two 128-column tiles stay on 64x64 tiles however many rows they have (the tall matrices of the
+	// gradient path reach any tile count at n = 64): half of a 128-wide tile would be idle there, and only the 64x64
+	// tiles carry the factor-ahead epilogue (value+gradient batch 158.4 -> 155.4 ms)
+	if (a.n < 256 && big_tiles >= 64) return 2;
+	return count_tiles(a, 128, 128) * (a.nbatch > 1 ? a.nbatch : 1) >= thr ? 8 : 2;
 }
+
+bool gemm_uses_big_tiles(const GemmArgs &a) { return choose_gemm_cfg(a) != 2; }
 
 // would launch_gemm run this update with the factor-ahead tile?  (the caller then skips the next leaf factorisation)
 bool gemm_factor_ahead_ok(const GemmArgs &a)
 {
-	int choose_gemm_cfg(const GemmArgs &a);
 	return a.fa && a.tri && a.diag_off == 0 && a.m >= LEAF && a.n >= LEAF && a.beta == 1 && a.alpha == -1.0 && !a.kstart_mode &&
 	       !a.kend_mode && a.ksplit <= 1 && choose_gemm_cfg(a) == 2;
-}
-
-int g_la_bulk_cfg = 8;          // tile configuration of the look-ahead schedule's bulk updates (GPEMU_LA_BULK_CFG: 8 or 2)
-int choose_gemm_cfg(const GemmArgs &a)
-{
-	if (g_gemm_force_cfg >= 0) return g_gemm_force_cfg;
-	if (a.half_occ) return (g_la_bulk_cfg == 8 && count_tiles(a, 128, 128) >= 256) ? 8 : 2;
-	// one matrix per launch: twice the threshold -- 1000-2000 tiles on the 512 resident workgroups of the chip are 2-4
-	// rounds, and the partly filled last one costs more than the faster tile gains (6.3 against 6.2 ms per evaluation)
-	const long thr = (a.nbatch > 1 || g_gemm_big_tiles < 64) ? g_gemm_big_tiles : 2L * g_gemm_big_tiles;   // (< 64: test settings, taken literally)
-	// updates narrower than two 128-column tiles stay on 64x64 tiles however many rows they have (the tall matrices of the
-	// gradient path reach any tile count at n = 64): half of a 128-wide tile would be idle there, and only the 64x64
-	// tiles carry the factor-ahead epilogue (value+gradient batch 158.4 -> 155.4 ms)
-	if (a.n < 256 && g_gemm_big_tiles >= 64) return 2;
-	return count_tiles(a, 128, 128) * (a.nbatch > 1 ? a.nbatch : 1) >= thr ? g_gemm_big_cfg : 2;
 }
 
 
@@ -784,7 +511,7 @@ int choose_gemm_cfg(const GemmArgs &a)
 // Tile order.  Workgroups are dealt round-robin to the 8 XCDs (ids b and b+8 share an XCD and its 4 MB L2).  In the
 // natural order the 64-128 tiles an XCD works on at a time lie in one tile column: one B panel, but a different A
 // panel each -- every tile fetches its own A panel from the fabric (PMC: 3.4 GB per evaluation against 1.2 GB
-// compulsory).  The table lists the valid tiles super-block by super-block (S x S tiles, S = g_gemm_table) and gives
+// compulsory).  The table lists the valid tiles super-block by super-block (S x S tiles of 128x128, S = GemmArgs.table_sb) and gives
 // XCD x the x-th eighth of that list, so that its concurrent tiles share S A and S B panels and all XCDs get equal
 // shares (unequal shares leave runs of idle slots at the tail: measured -6 %).  DESIGN.md section 7 has the numbers.
 // Tables are built on first use outside stream capture and cached per (device, shape).
@@ -823,17 +550,17 @@ std::vector<int> build_tile_table(int tiles_m, int tiles_n, int tri, int S, int 
 	return table;
 }
 
-static TileTable gemm_tile_table(hipStream_t s, int tiles_m, int tiles_n, int tri, int bm, int bn)
+static TileTable gemm_tile_table(hipStream_t s, int tiles_m, int tiles_n, int tri, int bm, int bn, int sb)
 {
 	int dev = 0;
 	(void)hipGetDevice(&dev);
-	const auto key = std::make_tuple(dev, tiles_m, tiles_n, tri, g_gemm_table, bm, bn);
+	const auto key = std::make_tuple(dev, tiles_m, tiles_n, tri, sb, bm, bn);
 	std::lock_guard<std::mutex> lock(g_tile_mutex);
 	auto it = g_tile_tables.find(key);
 	if (it != g_tile_tables.end()) return it->second;
 	hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
 	if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return TileTable{nullptr, 0};
-	const std::vector<int> table = build_tile_table(tiles_m, tiles_n, tri, g_gemm_table, bm, bn);
+	const std::vector<int> table = build_tile_table(tiles_m, tiles_n, tri, sb, bm, bn);
 	TileTable tt{nullptr, (int)table.size()};
 	if (hipMalloc(&tt.dptr, table.size() * sizeof(int)) != hipSuccess ||
 	    hipMemcpy(tt.dptr, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
@@ -849,56 +576,31 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs &a_in)
 	GemmArgs a = a_in;
 	if (a.m <= 0 || a.n <= 0) return hipSuccess;
 	if (a.beta && a.alpha != 1.0 && a.alpha != -1.0) return hipErrorInvalidValue;   // accumulators start from C/alpha
+	if (a.force_cfg != 0 && a.force_cfg != 2 && a.force_cfg != 8) return hipErrorInvalidValue;
 	if (a.ksplit > 1) {
 		if (a.beta || a.nbatch > 1) return hipErrorInvalidValue;      // slices write fresh partials of one problem
 		a.nbatch = a.ksplit; a.bsA = 0; a.bsB = 0;                      // bsC = stride between the partial outputs
 	}
 	const int nbatch = a.nbatch > 1 ? a.nbatch : 1;
-	const int cfg = choose_gemm_cfg(a);
+	const int cfg = choose_gemm_cfg(a);                                   // 8: 128x128 tiles, 8 waves; 2: 64x64 tiles, 4 waves
 	if (cfg != 2) a.fa = 0;                                               // factor-ahead lives in the 64x64 tiles only
-	if (!a.fa || nbatch > 1 || !a.sa_flag) a.sa = 0;
-	// tile shapes: 0 128x128 (4 waves), 1 128x64, 2 64x64, 3 128x128 (8 waves), 4 256x128 (8 waves, one workgroup
-	// per CU), 5 256x128 (16 waves), 6 128x256 (8 waves), 7 = 3 with the L2 prefetch of the chunk after the next
-	// 8 = 3 with LDS-DMA staging and a second fragment set; 9, 10 = 256x128 / 128x256 in that form (one workgroup per CU)
-	static const int k_bm[] = {128, 128, 64, 128, 256, 256, 128, 128, 128, 256, 128}, k_bn[] = {128, 64, 64, 128, 128, 128, 256, 128, 128, 128, 256};
-	if (cfg < 0 || cfg > 10) return hipErrorInvalidValue;
-	const int bm = k_bm[cfg], bn = k_bn[cfg];
+	const int bm = cfg == 8 ? 128 : 64, bn = bm;
 	const int tiles_m = (a.m + bm - 1) / bm, tiles_n = (a.n + bn - 1) / bn;
-	// lower-triangular updates enumerate only their non-empty tiles: square tiles by a closed form, any shape by table
+	// lower-triangular updates enumerate only their non-empty tiles: by a closed form, or by table
 	const bool tri_ok = a.tri && a.diag_off == 0 && a.m >= a.n;
-	const bool dense_tri = tri_ok && bm == bn;
-	a.order_mode = dense_tri ? 2 : 0;
-	int T = dense_tri ? (int)count_tiles(a, bm, bn) : tiles_m * tiles_n;
+	a.order_mode = tri_ok ? 2 : 0;
+	int T = tri_ok ? (int)count_tiles(a, bm, bn) : tiles_m * tiles_n;
 	// (not for the triangular-operand products of the prediction path: their K differs from tile column to tile column, so
 	// equal shares of tiles are unequal shares of work -- measured 2x slower -- and the long-K-first order matters more)
-	if (g_gemm_table && cfg != 1 && count_tiles(a, bm, bn) >= (bm * bn > 128 * 128 ? 256 : 512) && (tri_ok || !a.tri) &&
-	    !a.kstart_mode && !a.kend_mode) {
+	if (a.table_sb > 0 && count_tiles(a, bm, bn) >= 512 && (tri_ok || !a.tri) && !a.kstart_mode && !a.kend_mode) {
 		if (tiles_m < 32768 && tiles_n < 32768) {
-			const TileTable tt = gemm_tile_table(s, tiles_m, tiles_n, tri_ok ? 1 : 0, bm, bn);
+			const TileTable tt = gemm_tile_table(s, tiles_m, tiles_n, tri_ok ? 1 : 0, bm, bn, a.table_sb);
 			if (tt.dptr) { a.order_mode = 3; a.tile_table = tt.dptr; T = tt.len; }
 		}
 	}
-	switch (cfg) {
-	case 0: hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 2>), dim3(T, nbatch), dim3(256), 0, s, a); break;
-	case 1: hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 2>), dim3(T, nbatch), dim3(256), 0, s, a); break;
-	case 3: hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 4, 4, 2>), dim3(T, nbatch), dim3(512), 0, s, a); break;
-	case 4: hipLaunchKernelGGL((gemm_nt_kernel<256, 128, 2, 4, 2>), dim3(T, nbatch), dim3(512), 0, s, a); break;
-	case 5: hipLaunchKernelGGL((gemm_nt_kernel<256, 128, 4, 8, 2>), dim3(T, nbatch), dim3(1024), 0, s, a); break;
-	case 6: hipLaunchKernelGGL((gemm_nt_kernel<128, 256, 2, 2, 4>), dim3(T, nbatch), dim3(512), 0, s, a); break;
-	case 7: hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 4, 4, 2, 1, 1>), dim3(T, nbatch), dim3(512), 0, s, a); break;
-	case 8: hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 4, 4, 2, 1, 0, 0, 1>), dim3(T, nbatch), dim3(512), a.half_occ ? 32768 : 0, s, a); break;   // 64 + 32 KB: one per CU
-	case 9: hipLaunchKernelGGL((gemm_nt_kernel<256, 128, 2, 4, 2, 1, 0, 0, 1>), dim3(T, nbatch), dim3(512), 0, s, a); break;
-	case 10: hipLaunchKernelGGL((gemm_nt_kernel<128, 256, 2, 2, 4, 1, 0, 0, 1>), dim3(T, nbatch), dim3(512), 0, s, a); break;
-	default:
-		if (g_gemm_small_dma) {
-			if (a.fa) hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2, 1, 0, 1, 1>), dim3(T, nbatch), dim3(256), 0, s, a);
-			else hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2, 1, 0, 0, 1>), dim3(T, nbatch), dim3(256), a.half_occ ? 36864 : 0, s, a);   // 32 + 36 KB: two per CU
-		} else {
-			if (a.fa) hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2, 2, 0, 1>), dim3(T, nbatch), dim3(256), 0, s, a);
-			else hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2, 2>), dim3(T, nbatch), dim3(256), 0, s, a);
-		}
-		break;
-	}
+	if (cfg == 8) hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 4, 4, 2>), dim3(T, nbatch), dim3(512), 0, s, a);
+	else if (a.fa) hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2, 1>), dim3(T, nbatch), dim3(256), 0, s, a);
+	else hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2>), dim3(T, nbatch), dim3(256), 0, s, a);
 	return hipGetLastError();
 }
 
@@ -1004,9 +706,8 @@ __device__ __forceinline__ void panel_update(double *A, int wave, int lane)
 		}
 }
 
-__global__ __launch_bounds__(256) void leaf_factor_kernel(double *T, long ld, int c0, int *info, unsigned long long *trace, long bstride, int prio)
+__global__ __launch_bounds__(256) void leaf_factor_kernel(double *T, long ld, int c0, int *info, unsigned long long *trace, long bstride)
 {
-	if (prio) __builtin_amdgcn_s_setprio(3);
 	T += (long)blockIdx.y * bstride;     // lock-step batch: one diagonal block per matrix
 	info += blockIdx.y;
 	__shared__ double A[LEAF * LP];
@@ -1129,9 +830,8 @@ __device__ __forceinline__ void tri_inverse16(double *M, int o, double *tile, in
 	tri_inverse16_to<LP, LP>(M, o, tile, lane, M + o * LP + o, LP);
 }
 
-__global__ __launch_bounds__(256) void leaf_solve_kernel(double *T, long ld, int c0, int m_below, unsigned long long *trace, long bstride, int prio)
+__global__ __launch_bounds__(256) void leaf_solve_kernel(double *T, long ld, int c0, int m_below, unsigned long long *trace, long bstride)
 {
-	if (prio) __builtin_amdgcn_s_setprio(3);
 	T += (long)blockIdx.y * bstride;
 	__shared__ double M[LEAF * LP];        // L; diagonal 16x16 blocks replaced by their inverses
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1191,443 +891,16 @@ __global__ __launch_bounds__(256) void leaf_solve_kernel(double *T, long ld, int
 	trace_end(trace, tr0);
 }
 
-// ---------------------------------------------------------------------------
-// Panel solve X L^T = B against a whole factored n x n diagonal block (n = 128 ... 512, a multiple of 64) for the rows
-// below it: ONE read-modify-write of the panel.
-//
-// The recursion above would reach the same rows log2(n/64) times with updates of K = 64, 128, 256 (each level reads
-// half the panel and read-modify-writes the other half) and once per 64 columns with the leaf solve: 6.5 panel volumes
-// for n = 512, all of it from HBM when a lock-step batch of 16 sub-panels (16 x 29 MB) is in flight -- those launches
-// run at 4-7 TB/s, i.e. AT the HBM roofline, and at 21-52 TFLOP/s.  Here a workgroup owns 64 rows and walks the
-// n/64 column blocks itself:  X_j = (B_j - sum_{i<j} X_i L_ji^T) L_jj^-T.  B_j comes from HBM once and X_j goes back
-// once; the X_i it re-reads are its own earlier output (L2; read with sc1 loads so that a stale L1 copy of the line from
-// before the store cannot be served) and the L blocks are shared by every workgroup (L2 / Infinity Cache).
-//
-// The arithmetic is the recursion's, element for element: an update is the k-ordered chain of MFMA accumulations
-// that starts from the stored C value (gemm_nt_kernel), the recursion applies the levels to a block column in
-// ascending k, and the solve of a 64-column block is leaf_solve_kernel's.  So the bits do not change.
-// grid (rows/64, nbatch), 256 threads = 4 waves as 2x2 over a 64x64 tile, LDS 40 KB (4 workgroups per CU).
-// ---------------------------------------------------------------------------
-typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
-
-__global__ __launch_bounds__(256, 3) void panel_trsm_kernel(double *T, long ld, int c0, int n, int j0, int row0, long bstride,
-                                                            unsigned long long *trace)
-{
-	constexpr int BM = 64, BN = 64, WM = 32, WN = 32, TM = 2, TN = 2, AIT = 2, BIT = 2;
-	__shared__ double smem[2 * (BM + BN) * LDS_S];
-	double (*As)[BM * LDS_S] = reinterpret_cast<double (*)[BM * LDS_S]>(smem);
-	double (*Bs)[BN * LDS_S] = reinterpret_cast<double (*)[BN * LDS_S]>(smem + 2 * BM * LDS_S);
-	T += (long)blockIdx.y * bstride;
-	const TraceT0 tr0 = trace_begin(trace);
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const int wm = wave >> 1, wn = wave & 1;
-	const int q = lane & 15, gq = lane >> 4;
-	const long rbase = (long)row0 + 64L * blockIdx.x;             // this workgroup's 64 panel rows
-	double *P = T + rbase * ld + c0;                              // their first panel column
-	// A operand = this workgroup's own rows (X_i, written by this very workgroup): 16-byte sc1 buffer loads
-	const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(P, 0, -1, 0x00020000);
-	unsigned a_off[AIT];
-	int lofs[AIT];
-#pragma unroll
-	for (int it = 0; it < AIT; it++) {
-		const int idx = tid + 256 * it, row = idx >> 3, seg = idx & 7;
-		a_off[it] = (unsigned)((long)row * ld * 8 + 16 * seg);
-		lofs[it] = row * LDS_S + 2 * seg;
-	}
-	const int a_base = (wm * WM + q) * LDS_S + 2 * gq;
-	const int b_base = (wn * WN + q) * LDS_S + 2 * gq;
-	const int nblk = n / 64;
-#pragma unroll 1
-	for (int j = j0; j < nblk; j++) {        // (blocks < j0 were solved by the solve-ahead tiles of the update before)
-		// (the per-row addresses of this iteration are derived from bases the compiler cannot see through: hoisted out
-		// of the j loop as loop invariants they cost ~60 VGPRs of 64-bit row pointers and the kernel spilled)
-		double *Pj = P + 64 * j;
-		const double *Lj = T + (long)(c0 + 64 * j) * ld + c0;         // row 64j of L, first panel column
-		long ldj = ld;
-		asm volatile("" : "+s"(Pj), "+s"(Lj), "+s"(ldj));
-		// accumulators start from -B_j (the update is C -= A B^T: alpha = -1, the chain runs on C / alpha)
-		d4_t acc[TM][TN];
-		{
-			// (row pointers by successive additions of a scalar stride: nothing for the compiler to pre-compute per row)
-			const double *crow = Pj + (long)(wm * WM + gq) * ldj + wn * WN + q;
-#pragma unroll
-			for (int i = 0; i < TM; i++)
-#pragma unroll
-				for (int r = 0; r < 4; r++) {
-#pragma unroll
-					for (int jj = 0; jj < TN; jj++) acc[i][jj][r] = -1.0 * crow[jj * 16];
-					crow += (r == 3) ? 4 * ldj : 4 * ldj;
-				}
-		}
-		const int ke = 64 * j;
-		if (ke > 0) {
-			// B operand = rows 64j .. 64j+63 of L (the diagonal block's own rows), columns [0, 64j)
-			const double *bg[BIT];
-			bg[0] = Lj + (long)(tid >> 3) * ldj + 2 * (tid & 7);
-			bg[1] = bg[0] + 32 * ldj;
-#define TRSM_LOAD(RA, RB, kk)                                                                                      \
-			do {                                                                                                   \
-				_Pragma("unroll") for (int it = 0; it < AIT; it++) {                                                \
-					const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[it], (kk) * 8, 16 /* sc1 */); \
-					RA[it] = __builtin_bit_cast(d2_t, v);                                                           \
-				}                                                                                                  \
-				_Pragma("unroll") for (int it = 0; it < BIT; it++) RB[it] = *reinterpret_cast<const d2_t *>(bg[it] + (kk)); \
-			} while (0)
-#define TRSM_STORE(RA, RB, buf)                                                                                    \
-			do {                                                                                                   \
-				_Pragma("unroll") for (int it = 0; it < AIT; it++) *reinterpret_cast<d2_t *>(&As[buf][lofs[it]]) = RA[it]; \
-				_Pragma("unroll") for (int it = 0; it < BIT; it++) *reinterpret_cast<d2_t *>(&Bs[buf][lofs[it]]) = RB[it]; \
-			} while (0)
-#define TRSM_STEP(buf)                                                                                             \
-			do {                                                                                                   \
-				const double *as = As[buf];                                                                        \
-				const double *bs = Bs[buf];                                                                        \
-				_Pragma("unroll") for (int t = 0; t < GEMM_BK / 8; t++) {                                           \
-					d2_t a[TM], b[TN];                                                                             \
-					_Pragma("unroll") for (int i = 0; i < TM; i++)                                                  \
-						a[i] = *reinterpret_cast<const d2_t *>(&as[a_base + i * 16 * LDS_S + 8 * t]);               \
-					_Pragma("unroll") for (int jj = 0; jj < TN; jj++)                                               \
-						b[jj] = *reinterpret_cast<const d2_t *>(&bs[b_base + jj * 16 * LDS_S + 8 * t]);             \
-					_Pragma("unroll") for (int h = 0; h < 2; h++)                                                   \
-						_Pragma("unroll") for (int i = 0; i < TM; i++)                                              \
-							_Pragma("unroll") for (int jj = 0; jj < TN; jj++)                                       \
-								acc[i][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][h], b[jj][h], acc[i][jj], 0, 0, 0); \
-				}                                                                                                  \
-			} while (0)
-			d2_t r0a[AIT], r0b[BIT], r1a[AIT], r1b[BIT];
-			TRSM_LOAD(r0a, r0b, 0);
-			if (GEMM_BK < ke) TRSM_LOAD(r1a, r1b, GEMM_BK);
-			TRSM_STORE(r0a, r0b, 0);
-			__syncthreads();
-			int cur = 0;
-#pragma unroll 1
-			for (int k = 0; k < ke; k += 2 * GEMM_BK) {
-				if (k + 2 * GEMM_BK < ke) TRSM_LOAD(r0a, r0b, k + 2 * GEMM_BK);
-				TRSM_STEP(cur);
-				if (k + GEMM_BK < ke) TRSM_STORE(r1a, r1b, cur ^ 1);
-				__syncthreads();
-				cur ^= 1;
-				if (k + GEMM_BK >= ke) break;
-				if (k + 3 * GEMM_BK < ke) TRSM_LOAD(r1a, r1b, k + 3 * GEMM_BK);
-				TRSM_STEP(cur);
-				if (k + 2 * GEMM_BK < ke) TRSM_STORE(r0a, r0b, cur ^ 1);
-				__syncthreads();
-				cur ^= 1;
-			}
-#undef TRSM_LOAD
-#undef TRSM_STORE
-#undef TRSM_STEP
-		}
-		// the updated B_j -> LDS (what the update would have stored: alpha * acc), then leaf_solve_kernel's solve
-		double *M = smem;
-#pragma unroll
-		for (int i = 0; i < TM; i++)
-#pragma unroll
-			for (int r = 0; r < 4; r++)
-#pragma unroll
-				for (int jj = 0; jj < TN; jj++)
-					M[(wm * WM + i * 16 + gq + 4 * r) * LP + wn * WN + jj * 16 + q] = -1.0 * acc[i][jj][r];
-		__syncthreads();
-		d4_t R[4];
-#pragma unroll
-		for (int jj = 0; jj < 4; jj++)
-#pragma unroll
-			for (int r = 0; r < 4; r++) R[jj][r] = M[(16 * wave + q) * LP + 16 * jj + gq + 4 * r];
-		__syncthreads();
-		{
-			const double *D = Lj + 64 * j;                                    // L_jj
-			double v[16];
-			const double *dp = D + (long)wave * ldj + lane;
-#pragma unroll
-			for (int u = 0; u < 16; u++) { v[u] = *dp; dp += 4 * ldj; }
-#pragma unroll
-			for (int u = 0; u < 16; u++) M[(wave + 4 * u) * LP + lane] = v[u];
-		}
-		__syncthreads();
-		{
-			const int sr = (wave == 3) ? 0 : wave, sc = (wave == 3) ? 3 : wave + 1;
-			tri_inverse16(M, 16 * wave, M + 16 * sr * LP + 16 * sc, lane);
-		}
-		__syncthreads();
-		double *bp = Pj + (long)(16 * wave + q) * ldj;
-		d4_t X[4];
-#pragma unroll
-		for (int jj = 0; jj < 4; jj++) {
-			d4_t a4 = R[jj];
-#pragma unroll
-			for (int i = 0; i < jj; i++)
-#pragma unroll
-				for (int r = 0; r < 4; r++) {
-					const double a = -M[(16 * jj + q) * LP + 16 * i + gq + 4 * r];
-					a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[i][r], a4, 0, 0, 0);
-				}
-			d4_t xj = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-			for (int r = 0; r < 4; r++) {
-				const double a = M[(16 * jj + q) * LP + 16 * jj + gq + 4 * r];
-				xj = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a4[r], xj, 0, 0, 0);
-			}
-			X[jj] = xj;
-#pragma unroll
-			for (int r = 0; r < 4; r++) bp[16 * jj + gq + 4 * r] = xj[r];
-		}
-		// X_j must have reached the L2 before any wave of this workgroup loads it as an A operand (and the LDS is reused)
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		__syncthreads();
-	}
-	trace_end(trace, tr0);
-}
-
-// rows [row0, row0 + m) of the panel columns [c0, c0 + n): m a multiple of 64, n a multiple of 64
-hipError_t launch_panel_trsm(hipStream_t s, double *T, long ld, int c0, int n, int j0, int row0, int m, int nbatch, long bstride,
-                             unsigned long long *trace)
-{
-	if (m <= 0 || j0 >= n / 64) return hipSuccess;
-	if (m % 64 || n % 64 || n < 64 || (long)64 * ld * 8 + 16 * 8 > 0x7fffffffL) return hipErrorInvalidValue;
-	if (nbatch < 1) nbatch = 1;
-	hipLaunchKernelGGL(panel_trsm_kernel, dim3(m / 64, nbatch), dim3(256), 0, s, T, ld, c0, n, j0, row0, bstride, trace);
-	return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------
-// 128-column leaf: the same two steps on a 128x128 diagonal block, one launch each instead of five
-// (factor, solve, K=64 update, factor, solve on 64-column halves) -- the chain of small dependent
-// kernels is the critical path of the factorisation, so fewer, fatter links win.
-//
-//  leaf128_factor_kernel (1 workgroup): block in LDS (133 KB).  A11 = chol (four 16-column panels as
-//    above); A21 <- A21 L11^-T on the MFMA (needs the inverses of L11's 16x16 diagonal blocks);
-//    A22 -= A21 A21^T (MFMA, K = 64); A22 = chol.  The eight inverted 16x16 diagonal blocks are
-//    written to `dinv` for the panel solve.
-//  leaf128_solve_kernel (16 panel rows per wave): X L^T = B for the rows below, L and the inverted
-//    diagonal blocks staged in LDS; left half as a dependent MFMA chain, the cross update with four
-//    independent accumulators, then the right half chain.
-// ---------------------------------------------------------------------------
-constexpr int L2 = 128;
-constexpr int LP2 = L2 + 2;
-
-// rows [row0,row0+16) of the block: X_j^T = Inv_j (R_j^T - sum_{i<j} L_ji X_i^T), j = j0..j1-1, in place in LDS
-template <int J0, int J1, int LD>
-__device__ __forceinline__ void solve_rows_lds(double *A, int row0, const double *inv, int lane)
-{
-	const int g = lane >> 4, q = lane & 15;
-	d4_t X[J1 - J0];
-#pragma unroll
-	for (int j = J0; j < J1; j++) {
-		d4_t acc;
-#pragma unroll
-		for (int r = 0; r < 4; r++) acc[r] = A[(row0 + q) * LD + 16 * j + g + 4 * r];
-#pragma unroll
-		for (int i = J0; i < j; i++)
-#pragma unroll
-			for (int r = 0; r < 4; r++) {
-				const double a = -A[(16 * j + q) * LD + 16 * i + g + 4 * r];
-				acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[i - J0][r], acc, 0, 0, 0);
-			}
-		d4_t xj = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-		for (int r = 0; r < 4; r++) {
-			const double a = inv[j * 256 + q * 16 + g + 4 * r];
-			xj = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[r], xj, 0, 0, 0);
-		}
-		X[j - J0] = xj;
-	}
-	// the X tiles are written only after every read of this wave's rows (acc loads above) is done
-#pragma unroll
-	for (int j = J0; j < J1; j++)
-#pragma unroll
-		for (int r = 0; r < 4; r++) A[(row0 + q) * LD + 16 * j + g + 4 * r] = X[j - J0][r];
-}
-
-__global__ __launch_bounds__(256) void leaf128_factor_kernel(double *T, long ld, int c0, int *info, double *dinv, long bstride)
-{
-	T += (long)blockIdx.y * bstride;          // lock-step batch
-	info += blockIdx.y;
-	dinv += (long)blockIdx.y * 8 * 256;
-	__shared__ double A[L2 * LP2];
-	__shared__ double Inv[8 * 256];
-	__shared__ double Xs[4][16 * 17];
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const int g = lane >> 4, q = lane & 15;
-	double *D = T + (long)c0 * ld + c0;
-	// stage the lower block rows (row r: columns 0..127 -- whole rows keep the loads 512-byte contiguous)
-#pragma unroll 4
-	for (int u = 0; u < 32; u++) {
-		const int r = wave + 4 * u;
-		const d2_t v = *reinterpret_cast<const d2_t *>(D + (long)r * ld + 2 * lane);
-		*reinterpret_cast<d2_t *>(&A[r * LP2 + 2 * lane]) = v;
-	}
-	__syncthreads();
-	int bad = 0;
-	double *A11 = A, *A22 = A + 64 * LP2 + 64;
-	// ---- A11 = chol
-	if (wave == 0) panel_factor<0, LP2>(A11, lane, bad, 0);
-	__syncthreads();
-	panel_update<0, LP2>(A11, wave, lane);
-	__syncthreads();
-	if (wave == 0) panel_factor<1, LP2>(A11, lane, bad, 0);
-	__syncthreads();
-	panel_update<1, LP2>(A11, wave, lane);
-	__syncthreads();
-	if (wave == 0) panel_factor<2, LP2>(A11, lane, bad, 0);
-	__syncthreads();
-	panel_update<2, LP2>(A11, wave, lane);
-	__syncthreads();
-	if (wave == 0) panel_factor<3, LP2>(A11, lane, bad, 0);
-	__syncthreads();
-	// ---- inverses of L11's diagonal blocks, then A21 <- A21 L11^-T (wave w: rows 64+16w..)
-	tri_inverse16_to<LP2>(A, 16 * wave, Xs[wave], lane, Inv + wave * 256, 16);
-	__syncthreads();
-	solve_rows_lds<0, 4, LP2>(A, 64 + 16 * wave, Inv, lane);
-	__syncthreads();
-	// ---- A22 -= A21 A21^T : lower tiles (ti,tj) of the 64x64 block, K = 64
-	{
-		int t = 0;
-#pragma unroll
-		for (int ti = 0; ti < 4; ti++)
-#pragma unroll
-			for (int tj = 0; tj <= ti; tj++) {
-				if ((t & 3) == wave) {
-					d4_t c;
-#pragma unroll
-					for (int r = 0; r < 4; r++) c[r] = A22[(16 * ti + g + 4 * r) * LP2 + 16 * tj + q];
-#pragma unroll
-					for (int kb = 0; kb < 4; kb++)
-#pragma unroll
-						for (int r = 0; r < 4; r++) {
-							const double a = -A[(64 + 16 * ti + q) * LP2 + 16 * kb + g + 4 * r];
-							const double b = A[(64 + 16 * tj + q) * LP2 + 16 * kb + g + 4 * r];
-							c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-						}
-#pragma unroll
-					for (int r = 0; r < 4; r++) A22[(16 * ti + g + 4 * r) * LP2 + 16 * tj + q] = c[r];
-				}
-				t++;
-			}
-	}
-	__syncthreads();
-	// ---- A22 = chol
-	if (wave == 0) panel_factor<0, LP2>(A22, lane, bad, 64);
-	__syncthreads();
-	panel_update<0, LP2>(A22, wave, lane);
-	__syncthreads();
-	if (wave == 0) panel_factor<1, LP2>(A22, lane, bad, 64);
-	__syncthreads();
-	panel_update<1, LP2>(A22, wave, lane);
-	__syncthreads();
-	if (wave == 0) panel_factor<2, LP2>(A22, lane, bad, 64);
-	__syncthreads();
-	panel_update<2, LP2>(A22, wave, lane);
-	__syncthreads();
-	if (wave == 0) panel_factor<3, LP2>(A22, lane, bad, 64);
-	__syncthreads();
-	tri_inverse16_to<LP2>(A, 64 + 16 * wave, Xs[wave], lane, Inv + (4 + wave) * 256, 16);
-	if (tid == 0 && bad) atomicMin(info, c0 + bad);
-	__syncthreads();
-	// ---- write L (lower triangle) and the eight inverted diagonal blocks
-#pragma unroll 4
-	for (int u = 0; u < 32; u++) {
-		const int r = wave + 4 * u;
-		if (lane <= r) D[(long)r * ld + lane] = A[r * LP2 + lane];
-		if (lane + 64 <= r) D[(long)r * ld + lane + 64] = A[r * LP2 + lane + 64];
-	}
-	for (int e = tid; e < 8 * 256; e += 256) dinv[e] = Inv[e];
-}
-
-__global__ __launch_bounds__(256) void leaf128_solve_kernel(double *T, long ld, int c0, int m_below, const double *dinv, long bstride)
-{
-	T += (long)blockIdx.y * bstride;
-	dinv += (long)blockIdx.y * 8 * 256;
-	__shared__ double M[L2 * LP2];
-	__shared__ double Inv[8 * 256];
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const int g = lane >> 4, q = lane & 15;
-	const int prow0 = (blockIdx.x * 4 + wave) * 16;
-	int prow = prow0 + q;
-	const bool valid = prow < m_below;
-	if (!valid) prow = m_below - 1;
-	double *bp = T + (long)(c0 + L2 + prow) * ld + c0;
-	d4_t R[8];
-#pragma unroll
-	for (int j = 0; j < 8; j++)
-#pragma unroll
-		for (int r = 0; r < 4; r++) R[j][r] = bp[16 * j + g + 4 * r];
-	{
-		const double *D = T + (long)c0 * ld + c0;
-#pragma unroll 8
-		for (int u = 0; u < 32; u++) {
-			const int r = wave + 4 * u;
-			const d2_t v = *reinterpret_cast<const d2_t *>(D + (long)r * ld + 2 * lane);
-			*reinterpret_cast<d2_t *>(&M[r * LP2 + 2 * lane]) = v;
-		}
-		for (int e = tid; e < 8 * 256; e += 256) Inv[e] = dinv[e];
-	}
-	__syncthreads();
-	if (prow0 >= m_below) return;
-	d4_t X[8];
-	// left half: dependent chain
-#pragma unroll
-	for (int j = 0; j < 4; j++) {
-		d4_t acc = R[j];
-#pragma unroll
-		for (int i = 0; i < j; i++)
-#pragma unroll
-			for (int r = 0; r < 4; r++)
-				acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-M[(16 * j + q) * LP2 + 16 * i + g + 4 * r], X[i][r], acc, 0, 0, 0);
-		d4_t xj = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-		for (int r = 0; r < 4; r++) xj = __builtin_amdgcn_mfma_f64_16x16x4f64(Inv[j * 256 + q * 16 + g + 4 * r], acc[r], xj, 0, 0, 0);
-		X[j] = xj;
-	}
-	// cross update R_j -= L_ji X_i (j = 4..7, i = 0..3): four independent accumulators, i outermost
-#pragma unroll
-	for (int i = 0; i < 4; i++)
-#pragma unroll
-		for (int r = 0; r < 4; r++)
-#pragma unroll
-			for (int j = 4; j < 8; j++)
-				R[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-M[(16 * j + q) * LP2 + 16 * i + g + 4 * r], X[i][r], R[j], 0, 0, 0);
-	// right half chain
-#pragma unroll
-	for (int j = 4; j < 8; j++) {
-		d4_t acc = R[j];
-#pragma unroll
-		for (int i = 4; i < j; i++)
-#pragma unroll
-			for (int r = 0; r < 4; r++)
-				acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-M[(16 * j + q) * LP2 + 16 * i + g + 4 * r], X[i][r], acc, 0, 0, 0);
-		d4_t xj = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-		for (int r = 0; r < 4; r++) xj = __builtin_amdgcn_mfma_f64_16x16x4f64(Inv[j * 256 + q * 16 + g + 4 * r], acc[r], xj, 0, 0, 0);
-		X[j] = xj;
-	}
-	if (valid) {
-#pragma unroll
-		for (int j = 0; j < 8; j++)
-#pragma unroll
-			for (int r = 0; r < 4; r++) bp[16 * j + g + 4 * r] = X[j][r];
-	}
-}
-
-hipError_t launch_leaf128(hipStream_t s, double *T, long ld, int c0, int m_below, int *info, double *dinv, int nbatch,
-                          long bstride)
-{
-	if (nbatch < 1) nbatch = 1;
-	hipLaunchKernelGGL(leaf128_factor_kernel, dim3(1, nbatch), dim3(256), 0, s, T, ld, c0, info, dinv, bstride);
-	if (m_below > 0)
-		hipLaunchKernelGGL(leaf128_solve_kernel, dim3((m_below + 63) / 64, nbatch), dim3(256), 0, s, T, ld, c0, m_below,
-		                   dinv, bstride);
-	return hipGetLastError();
-}
 
 hipError_t launch_leaf(hipStream_t s, double *T, long ld, int c0, int m_below, int *info, unsigned long long *trf,
-                       unsigned long long *trs, int nbatch, long bstride, bool skip_factor, bool skip_solve, int prio)
+                       unsigned long long *trs, int nbatch, long bstride, bool skip_factor)
 {
 	if (nbatch < 1) nbatch = 1;
 	if (!skip_factor)                    // (skipped: the diagonal block was factored by the update before, factor-ahead)
-		hipLaunchKernelGGL(leaf_factor_kernel, dim3(1, nbatch), dim3(256), 0, s, T, ld, c0, info, trf, bstride, prio);
-	if (m_below > 0 && !skip_solve)      // (skipped: the rows were solved by the update before, solve-ahead)
+		hipLaunchKernelGGL(leaf_factor_kernel, dim3(1, nbatch), dim3(256), 0, s, T, ld, c0, info, trf, bstride);
+	if (m_below > 0)
 		hipLaunchKernelGGL(leaf_solve_kernel, dim3((m_below + 63) / 64, nbatch), dim3(256), 0, s, T, ld, c0, m_below,
-		                   trs, bstride, prio);
+		                   trs, bstride);
 	return hipGetLastError();
 }
 
