@@ -59,13 +59,57 @@ int gpemu_host_thread_device_get(void) { return tls_device; }
 int gpemu_host_device(void) { return tls_device >= 0 ? tls_device : gpemu_host_slot_device(0); }
 
 /* ---------------------------------------------------------------- registry */
+/* the last few (theta -> value, sigma^2, status) results of one caller (a `params`): evalFnMulti and estimateSigmaFull
+ * are pure functions of theta and the model, and the search asks for both at the point its last evalFnGradMulti call
+ * already evaluated (maxmultimin.c:98-103, 757: the value of the final thetas and their sigma^2) -- those two calls per
+ * run are answered from here instead of two more factorisations.  Exact theta bits only; dropped when the model data
+ * change. */
+#define VCACHE_N 4
+struct vcache {
+	int n, next, nthetas;
+	double th[VCACHE_N][GPEMU_MAX_PARAMS + 2];
+	double val[VCACHE_N], sigma2[VCACHE_N];
+	int status[VCACHE_N];
+};
+
 struct entry {
 	const void *key;
 	gpemu_ctx *ctx;
-	const double *xdata, *ydata;      /* identity of the uploaded data */
+	const double *xdata, *ydata;      /* where the uploaded data came from ... */
+	unsigned long long xsum, ysum;    /* ... and a 64-bit checksum of every value: callers rewrite the buffers in place */
 	int N, d, kind, order;
+	struct vcache vc;                 /* (callers with a context of their own; group members have theirs in the group) */
 	struct entry *next;
 };
+
+static void vcache_clear(struct vcache *c) { c->n = 0; c->next = 0; }
+static int vcache_find(const struct vcache *c, const double *th, int nthetas)
+{
+	if (c->nthetas != nthetas) return -1;
+	for (int i = 0; i < c->n; i++)
+		if (!memcmp(c->th[i] + 1, th + 1, sizeof(double) * (size_t)(nthetas - 1))) return i;     /* theta[0] is ignored by every entry */
+	return -1;
+}
+static void vcache_put(struct vcache *c, const double *th, int nthetas, double val, double sigma2, int status)
+{
+	if (nthetas > GPEMU_MAX_PARAMS + 2) return;
+	if (c->nthetas != nthetas) { c->n = 0; c->next = 0; c->nthetas = nthetas; }
+	int i = vcache_find(c, th, nthetas);
+	if (i < 0) { i = c->next; c->next = (c->next + 1) % VCACHE_N; if (c->n < VCACHE_N) c->n++; }
+	memcpy(c->th[i], th, sizeof(double) * (size_t)nthetas);
+	c->val[i] = val; c->sigma2[i] = sigma2; c->status[i] = status;
+}
+
+/* evaluation counters of the whole process (gpemu_host_eval_stats): device evaluations by kind and cache answers */
+static long g_n_value = 0, g_n_valgrad = 0, g_n_cached = 0, g_n_rounds = 0, g_n_round_elems = 0;
+void gpemu_host_eval_stats(long *value_evals, long *valgrad_evals, long *cached, long *rounds, long *round_elements)
+{
+	if (value_evals) *value_evals = __sync_fetch_and_add(&g_n_value, 0);
+	if (valgrad_evals) *valgrad_evals = __sync_fetch_and_add(&g_n_valgrad, 0);
+	if (cached) *cached = __sync_fetch_and_add(&g_n_cached, 0);
+	if (rounds) *rounds = __sync_fetch_and_add(&g_n_rounds, 0);
+	if (round_elements) *round_elements = __sync_fetch_and_add(&g_n_round_elems, 0);
+}
 static struct entry *g_entries = NULL;
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 
@@ -134,29 +178,65 @@ static double *pack_vector(const gsl_vector *v)
 	return p;
 }
 
-/* make sure the model's design / training vector are the ones resident in this entry's HBM */
-static gpemu_ctx *bind_model(const void *key, modelstruct *m, const char *where)
+/* 64-bit checksum of every element (multiply-xor, position dependent): N*(d+1) doubles, microseconds */
+static unsigned long long sum_doubles(unsigned long long h, const double *p, size_t n, size_t stride)
+{
+	const unsigned long long K = 0xFF51AFD7ED558CCDull;
+	for (size_t i = 0; i < n; i++) {
+		unsigned long long w;
+		memcpy(&w, p + i * stride, sizeof w);
+		h = (h ^ w) * K;
+		h ^= h >> 29;
+	}
+	return h;
+}
+static unsigned long long sum_matrix(const gsl_matrix *m)
+{
+	unsigned long long h = 0x9E3779B97F4A7C15ull;
+	for (size_t i = 0; i < m->size1; i++) h = sum_doubles(h, m->data + i * m->tda, m->size2, 1);
+	return h;
+}
+static unsigned long long sum_vector(const gsl_vector *v) { return sum_doubles(0xBF58476D1CE4E5B9ull, v->data, v->size, v->stride); }
+
+/* make sure the model's design / training vector are the ones resident in this entry's HBM.  The reference re-reads the
+ * model on every call (maxmultimin.c:317 fills the matrix from the_model->xmodel each time), so a caller may rewrite
+ * xmodel->data or training_vector->data in place between calls (libRbind-style loops, an MCMC re-fit): pointer identity
+ * says nothing -- the resident copy is kept only while a checksum over ALL values agrees.  *changed (optional) is set
+ * when anything was uploaded. */
+static struct entry *bind_model_entry(const void *key, modelstruct *m, const char *where, int *changed)
 {
 	struct entry *e = lookup(key, 1);
 	const optstruct *o = m->options;
 	const int kind = gpemu_host_kind_of(m->covariance_fn);
 	if (!kind) { fprintf(stderr, "%s: unknown covariance function (no device kernel)\n", where); exit(EXIT_FAILURE); }
-	if (e->xdata != m->xmodel->data || e->N != o->nmodel_points || e->d != o->nparams || e->kind != kind ||
+	const unsigned long long xsum = sum_matrix(m->xmodel), ysum = sum_vector(m->training_vector);
+	if (changed) *changed = 0;
+	if (e->xdata != m->xmodel->data || e->xsum != xsum || e->N != o->nmodel_points || e->d != o->nparams || e->kind != kind ||
 	    e->order != o->regression_order) {
 		double *X = pack_matrix(m->xmodel), *y = pack_vector(m->training_vector);
 		int rc = gpemu_set_model(e->ctx, kind, o->regression_order, o->nmodel_points, o->nparams, X, y);
 		free(X); free(y);
 		if (rc) die(e->ctx, rc, where);
 		e->xdata = m->xmodel->data; e->ydata = m->training_vector->data;
+		e->xsum = xsum; e->ysum = ysum;
 		e->N = o->nmodel_points; e->d = o->nparams; e->kind = kind; e->order = o->regression_order;
-	} else if (e->ydata != m->training_vector->data) {
+		vcache_clear(&e->vc);
+		if (changed) *changed = 1;
+	} else if (e->ydata != m->training_vector->data || e->ysum != ysum) {
 		double *y = pack_vector(m->training_vector);
 		int rc = gpemu_set_training(e->ctx, y);
 		free(y);
 		if (rc) die(e->ctx, rc, where);
-		e->ydata = m->training_vector->data;
+		e->ydata = m->training_vector->data; e->ysum = ysum;
+		vcache_clear(&e->vc);
+		if (changed) *changed = 1;
 	}
-	return e->ctx;
+	return e;
+}
+
+static gpemu_ctx *bind_model(const void *key, modelstruct *m, const char *where)
+{
+	return bind_model_entry(key, m, where, NULL)->ctx;
 }
 
 /* theta_local = [0, theta_less_amp...]  (maxmultimin.c:311-313) */
@@ -200,7 +280,8 @@ struct group {
 	const void **members;
 	int nmembers;
 	double *th, *val, *sigma2, *grad;
-	int *want_grad, *status;
+	int *want_grad, *status, *who;   /* who[slot]: member index of the request deposited in that slot */
+	struct vcache *vc;               /* one per member */
 	struct group *next;
 };
 static struct group *g_groups = NULL;
@@ -235,6 +316,8 @@ void *gpemu_host_group_create(struct estimate_thetas_params **members, int n)
 	G->grad = (double *)calloc((size_t)n * G->nthetas, sizeof(double));
 	G->want_grad = (int *)calloc((size_t)n, sizeof(int));
 	G->status = (int *)calloc((size_t)n, sizeof(int));
+	G->who = (int *)calloc((size_t)n, sizeof(int));
+	G->vc = (struct vcache *)calloc((size_t)n, sizeof(struct vcache));
 	pthread_mutex_lock(&g_lock);
 	G->next = g_groups;
 	g_groups = G;
@@ -254,46 +337,93 @@ void gpemu_host_group_destroy(void *group)
 	pthread_mutex_destroy(&G->mu);
 	pthread_cond_destroy(&G->cv);
 	free(G->members); free(G->th); free(G->val); free(G->sigma2); free(G->grad); free(G->want_grad); free(G->status);
+	free(G->who); free(G->vc);
 	free(G);
 }
 
-/* all live members have deposited a request: one or two device batches (value-only requests, value+gradient
- * requests), results into the slots.  Called with G->mu held. */
+/* all live members have deposited a request: the value+gradient requests go to the device as ONE lock-step batch; the
+ * value-only requests of the same round (rare: the two end-of-run calls are answered from the members' caches) as a
+ * second one, enqueued right behind it on the same stream before the first is collected.  Results into the slots and
+ * into the members' caches.  Called with G->mu held. */
 static void group_run_round(struct group *G)
 {
 	const int n = G->narrived, nt = G->nthetas;
 	const int saved_device = tls_device;          /* the round runs on whichever member arrived last: use the group's device */
 	tls_device = G->device;
-	gpemu_ctx *ctx = bind_model(G, G->model, "lock-step group");
+	int changed = 0;
+	gpemu_ctx *ctx = bind_model_entry(G, G->model, "lock-step group", &changed)->ctx;
 	tls_device = saved_device;
-	double *th = (double *)malloc(sizeof(double) * (size_t)n * nt);
+	if (changed) for (int i = 0; i < G->nmembers; i++) vcache_clear(&G->vc[i]);
+	double *th = (double *)malloc(sizeof(double) * (size_t)n * nt * 2);
 	double *val = (double *)malloc(sizeof(double) * (size_t)n), *s2 = (double *)malloc(sizeof(double) * (size_t)n);
 	double *gr = (double *)malloc(sizeof(double) * (size_t)n * nt);
-	int *st = (int *)malloc(sizeof(int) * (size_t)n), *idx = (int *)malloc(sizeof(int) * (size_t)n);
-	for (int pass = 0; pass < 2; pass++) {       /* pass 0: value only, pass 1: value + gradient */
-		int m = 0;
+	int *st = (int *)malloc(sizeof(int) * (size_t)n), *idx = (int *)malloc(sizeof(int) * (size_t)n * 2);
+	int m[2] = {0, 0};                            /* pass 1: value + gradient, pass 0: value only */
+	for (int pass = 1; pass >= 0; pass--)
 		for (int i = 0; i < n; i++)
-			if (G->want_grad[i] == pass) { memcpy(th + (size_t)m * nt, G->th + (size_t)i * nt, sizeof(double) * (size_t)nt); idx[m++] = i; }
-		if (!m) continue;
-		int rc = pass == 0 ? gpemu_loglik_batch(ctx, m, th, nt, val, s2, NULL, NULL, NULL, NULL, st)
-		                   : gpemu_loglik_grad_batch(ctx, m, th, nt, val, s2, NULL, gr, NULL, st);
+			if (G->want_grad[i] == pass) {
+				memcpy(th + ((size_t)pass * n + m[pass]) * nt, G->th + (size_t)i * nt, sizeof(double) * (size_t)nt);
+				idx[pass * n + m[pass]++] = i;
+			}
+	/* the larger batch first: the context sizes its per-batch result slots on the way up, and growing them between the
+	 * two enqueues would drop the first batch's entry of the result ring */
+	const int first = m[1] >= m[0] ? 1 : 0;
+	int rc = 0;
+	for (int k = 0; k < 2 && !rc; k++) {
+		const int pass = k == 0 ? first : 1 - first;
+		if (!m[pass]) continue;
+		rc = pass ? gpemu_loglik_grad_batch_enqueue(ctx, m[1], th + (size_t)n * nt, nt) : gpemu_loglik_batch_enqueue(ctx, m[0], th, nt);
+	}
+	if (rc) die(ctx, rc, "lock-step group");
+	for (int k = 0; k < 2; k++) {
+		const int pass = k == 0 ? first : 1 - first;
+		if (!m[pass]) continue;
+		const int back = (k == 0 && m[1 - pass]) ? 1 : 0;       /* the first of two enqueued batches sits one entry back */
+		rc = pass ? gpemu_loglik_grad_batch_collect_back(ctx, back, m[1], val, s2, NULL, gr, NULL, st)
+		          : gpemu_loglik_batch_collect_back(ctx, back, m[0], val, s2, NULL, NULL, NULL, NULL, st);
 		if (rc) die(ctx, rc, "lock-step group");
-		for (int k = 0; k < m; k++) {
-			const int i = idx[k];
-			G->val[i] = val[k]; G->sigma2[i] = s2[k]; G->status[i] = st[k];
-			if (pass == 1) memcpy(G->grad + (size_t)i * nt, gr + (size_t)k * (nt - 1), sizeof(double) * (size_t)(nt - 1));
+		for (int j = 0; j < m[pass]; j++) {
+			const int i = idx[pass * n + j];
+			G->val[i] = val[j]; G->sigma2[i] = s2[j]; G->status[i] = st[j];
+			if (pass == 1) memcpy(G->grad + (size_t)i * nt, gr + (size_t)j * (nt - 1), sizeof(double) * (size_t)(nt - 1));
+			vcache_put(&G->vc[G->who[i]], G->th + (size_t)i * nt, nt, val[j], s2[j], st[j]);
 		}
 	}
+	__sync_fetch_and_add(&g_n_valgrad, m[1]);
+	__sync_fetch_and_add(&g_n_value, m[0]);
+	__sync_fetch_and_add(&g_n_rounds, 1);
+	__sync_fetch_and_add(&g_n_round_elems, n);
 	free(th); free(val); free(s2); free(gr); free(st); free(idx);
 }
 
+static int group_member_index(const struct group *G, const void *params)
+{
+	for (int i = 0; i < G->nmembers; i++)
+		if (G->members[i] == params) return i;
+	return 0;
+}
+
 /* one member's request; returns the device status of ITS element */
-static int group_eval(struct group *G, const double *th, int want_grad, double *val, double *sigma2, double *grad)
+static int group_eval(struct group *G, const void *params, const double *th, int want_grad, double *val, double *sigma2, double *grad)
 {
 	pthread_mutex_lock(&G->mu);
+	const int me = group_member_index(G, params);
+	if (!want_grad) {
+		/* value / sigma^2 at a point this member has already evaluated: no device work, no round */
+		const int c = vcache_find(&G->vc[me], th, G->nthetas);
+		if (c >= 0) {
+			if (val) *val = G->vc[me].val[c];
+			if (sigma2) *sigma2 = G->vc[me].sigma2[c];
+			const int st = G->vc[me].status[c];
+			pthread_mutex_unlock(&G->mu);
+			__sync_fetch_and_add(&g_n_cached, 1);
+			return st;
+		}
+	}
 	const int slot = G->narrived++;
 	memcpy(G->th + (size_t)slot * G->nthetas, th, sizeof(double) * (size_t)G->nthetas);
 	G->want_grad[slot] = want_grad ? 1 : 0;
+	G->who[slot] = me;
 	const unsigned long gen = G->generation;
 	if (G->narrived == G->nlive) {
 		group_run_round(G);
@@ -331,18 +461,39 @@ void gpemu_host_group_leave(void *params)
 	pthread_mutex_unlock(&g_lock);
 }
 
+/* value / sigma^2 of a caller with a context of its own: from its cache when this theta has just been evaluated */
+static int own_value(struct estimate_thetas_params *params, const char *where, const double *th, int nthetas, double *val,
+                     double *sigma2, gpemu_ctx **ctx_out)
+{
+	struct entry *e = bind_model_entry(params, params->the_model, where, NULL);
+	*ctx_out = e->ctx;
+	const int c = vcache_find(&e->vc, th, nthetas);
+	if (c >= 0) {
+		if (val) *val = e->vc.val[c];
+		if (sigma2) *sigma2 = e->vc.sigma2[c];
+		__sync_fetch_and_add(&g_n_cached, 1);
+		return e->vc.status[c];
+	}
+	double v = GSL_NAN, s2 = GSL_NAN;
+	int info = 0;
+	const int rc = gpemu_loglik(e->ctx, th, nthetas, &v, &s2, NULL, NULL, NULL, &info);
+	__sync_fetch_and_add(&g_n_value, 1);
+	if (rc == GPEMU_OK || rc == GPEMU_ERR_NOT_PD) vcache_put(&e->vc, th, nthetas, v, s2, rc);
+	if (val) *val = v;
+	if (sigma2) *sigma2 = s2;
+	return rc;
+}
+
 /* libEmu/maxmultimin.c:288-394 */
 double evalFnMulti(const gsl_vector *theta_vec_less_amp, void *params_in)
 {
 	struct estimate_thetas_params *params = (struct estimate_thetas_params *)params_in;
 	const int nthetas = params->options->nthetas;
 	struct group *G = find_group(params);
-	gpemu_ctx *ctx = G ? NULL : bind_model(params, params->the_model, "evalFnMulti");
+	gpemu_ctx *ctx = NULL;
 	double *th = full_thetas(theta_vec_less_amp, nthetas);
 	double val = GSL_NAN;
-	int info = 0;
-	int rc = G ? group_eval(G, th, 0, &val, NULL, NULL)
-	           : gpemu_loglik(ctx, th, nthetas, &val, NULL, NULL, NULL, NULL, &info);
+	int rc = G ? group_eval(G, params, th, 0, &val, NULL, NULL) : own_value(params, "evalFnMulti", th, nthetas, &val, NULL, &ctx);
 	if (rc == GPEMU_ERR_NOT_PD) {
 		note_not_pd("evalFnMulti", th, nthetas);
 		val = GSL_NAN;
@@ -414,7 +565,8 @@ void gradFnMulti(const gsl_vector *theta_vec_less_amp, void *params_in, gsl_vect
 	double *th = full_thetas(theta_vec_less_amp, nthetas);
 	double *g = (double *)malloc(sizeof(double) * (size_t)(nthetas - 1));
 	int info = 0;
-	int rc = G ? group_eval(G, th, 1, NULL, NULL, g) : gpemu_grad(ctx, th, nthetas, g, &info);
+	int rc = G ? group_eval(G, params, th, 1, NULL, NULL, g) : gpemu_grad(ctx, th, nthetas, g, &info);
+	if (!G) __sync_fetch_and_add(&g_n_valgrad, 1);
 	if (rc) grad_failure(ctx, rc, th, nthetas);
 	for (int i = 0; i < nthetas - 1; i++) gsl_vector_set(grad_vec, i, g[i]);
 	free(g); free(th);
@@ -426,11 +578,17 @@ void evalFnGradMulti(const gsl_vector *theta_vec, void *params_in, double *fnval
 	struct estimate_thetas_params *params = (struct estimate_thetas_params *)params_in;
 	const int nthetas = params->options->nthetas;
 	struct group *G = find_group(params);
-	gpemu_ctx *ctx = G ? NULL : bind_model(params, params->the_model, "evalFnGradMulti");
+	struct entry *en = G ? NULL : bind_model_entry(params, params->the_model, "evalFnGradMulti", NULL);
+	gpemu_ctx *ctx = en ? en->ctx : NULL;
 	double *th = full_thetas(theta_vec, nthetas);
 	double *g = (double *)malloc(sizeof(double) * (size_t)(nthetas - 1));
 	int info = 0;
-	int rc = G ? group_eval(G, th, 1, fnval, NULL, g) : gpemu_loglik_grad(ctx, th, nthetas, fnval, NULL, NULL, g, &info);
+	double s2 = GSL_NAN;
+	int rc = G ? group_eval(G, params, th, 1, fnval, NULL, g) : gpemu_loglik_grad(ctx, th, nthetas, fnval, &s2, NULL, g, &info);
+	if (en) {
+		__sync_fetch_and_add(&g_n_valgrad, 1);
+		if (rc == GPEMU_OK || rc == GPEMU_ERR_NOT_PD) vcache_put(&en->vc, th, nthetas, *fnval, s2, rc);
+	}
 	if (rc == GPEMU_ERR_NOT_PD) {
 		/* The reference would return GSL_NAN from evalFnMulti and then exit(EXIT_FAILURE) inside gradFnMulti
 		 * (maxmultimin.c:349,495) -- a line-search trial point that is numerically not positive definite kills
@@ -452,11 +610,10 @@ double estimateSigmaFull(gsl_vector *thetas_less_amp, void *params_in)
 	struct estimate_thetas_params *params = (struct estimate_thetas_params *)params_in;
 	const int nthetas = params->options->nthetas;
 	struct group *G = find_group(params);
-	gpemu_ctx *ctx = G ? NULL : bind_model(params, params->the_model, "estimateSigmaFull");
+	gpemu_ctx *ctx = NULL;
 	double *th = full_thetas(thetas_less_amp, nthetas);
 	double s2 = GSL_NAN;
-	int info = 0;
-	int rc = G ? group_eval(G, th, 0, NULL, &s2, NULL) : gpemu_loglik(ctx, th, nthetas, NULL, &s2, NULL, NULL, NULL, &info);
+	int rc = G ? group_eval(G, params, th, 0, NULL, &s2, NULL) : own_value(params, "estimateSigmaFull", th, nthetas, NULL, &s2, &ctx);
 	if (rc == GPEMU_ERR_NOT_PD) { note_not_pd("estSigmaFull", th, nthetas); s2 = GSL_NAN; }
 	else if (rc) die(ctx, rc, "estimateSigmaFull");
 	free(th);

@@ -249,6 +249,9 @@ void gpemu_host_set_search(int nthreads, int restarts_per_job);   /* defaults: 1
 /* what the BFGS runs did so far in this process: runs, runs that ended at |g| < 0.1, runs that ended with "no progress",
  * line searches that fell back to "lowest trial value" (no Wolfe point), |g| at the end of the winning run of the last search */
 void gpemu_host_search_stats(long *runs, long *converged, long *noprogress, long *ls_fallbacks, double *best_gnorm);
+/* device evaluations of this process so far: value-only, value+gradient, requests answered from a caller's cache of its
+ * last results, lock-step rounds and the requests they carried (GPEMU_SEARCH_STATS=1 prints the figures of a search) */
+void gpemu_host_eval_stats(long *value_evals, long *valgrad_evals, long *cached, long *rounds, long *round_elements);
 void gpemu_host_release(void *params_or_emulator); /* drop the device context cached for a params / emulator pointer */
 /* lock-step group: n restart threads (one struct estimate_thetas_params each, same model) share one device context;
  * their concurrent evalFnMulti / gradFnMulti / evalFnGradMulti / estimateSigmaFull calls are gathered into device

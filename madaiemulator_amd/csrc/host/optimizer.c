@@ -312,35 +312,38 @@ static unsigned long seed_noblock(void)
 }
 
 struct pool {
-	pthread_mutex_t job_lock, result_lock;
-	int ntries, jobnumber;
+	pthread_mutex_t result_lock;
+	int total_runs, nthreads;
+	unsigned long seed;
 	gsl_vector *best_thetas;
 	double best_likelyhood_val;
+	int best_run;
 	double best_gnorm;
 };
 
-struct worker { struct pool *pool; struct estimate_thetas_params params; int id; int in_group; int device; };
+struct worker { struct pool *pool; struct estimate_thetas_params params; int id; int in_group; int device; gsl_vector *best_thetas; };
 
+/* The search is a LIST OF RUNS, r = 0 .. njobs * restarts - 1, each one maxWithMultiMin restart with its own generator
+ * seeded from (seed, r): the list -- how many runs, where each starts -- depends on GPEMU_JOBS / GPEMU_RESTARTS /
+ * GPEMU_SEED alone, not on how many threads, lock-step groups or GPUs the runs are dealt to, and the arg-max breaks ties
+ * by run index: with a fixed seed a 1-GPU and an 8-GPU machine train the same thetas and write the same snapshot.
+ * (The reference's amount of search depends on the core count, estimate_threaded.c:97-113; its seeds on /dev/urandom.) */
 static void *worker_main(void *arg)
 {
 	struct worker *w = (struct worker *)arg;
 	struct pool *P = w->pool;
 	gpemu_host_thread_device(w->device);         /* contexts this thread creates live on its slot's device */
-	for (int round = 0;; round++) {
-		int job;
-		if (w->in_group && round > 0) break;      /* lock-step group: exactly one job per member thread */
-		pthread_mutex_lock(&P->job_lock);
-		job = (P->jobnumber == P->ntries) ? -1 : P->jobnumber++;
-		pthread_mutex_unlock(&P->job_lock);
-		if (job < 0) break;
+	for (int run = w->id; run < P->total_runs; run += P->nthreads) {
+		gsl_rng_set(w->params.random_number, P->seed ? P->seed + 7919UL * (unsigned long)run : seed_noblock());
 		if (w->params.h_matrix) { gsl_matrix_free(w->params.h_matrix); w->params.h_matrix = NULL; }
-		maxWithMultiMin(&w->params);
+		maxWithMultiMin(&w->params);             /* max_tries = 1: one restart */
 		const double val = w->params.lhood_current;
-		if (val > w->params.my_best) w->params.my_best = val;
+		if (val > w->params.my_best) { w->params.my_best = val; gsl_vector_memcpy(w->best_thetas, w->params.the_model->thetas); }
 		pthread_mutex_lock(&P->result_lock);
-		if (val > P->best_likelyhood_val) {
+		if (val > P->best_likelyhood_val || (val == P->best_likelyhood_val && run < P->best_run)) {
 			gsl_vector_memcpy(P->best_thetas, w->params.the_model->thetas);
 			P->best_likelyhood_val = val;
+			P->best_run = run;
 			P->best_gnorm = tls_best_gnorm;
 			printf("# worker %d won with %g\n", w->id, val);
 		}
@@ -351,15 +354,18 @@ static void *worker_main(void *arg)
 }
 
 /* libEmu/estimate_threaded.c:78-237.  The reference starts one pthread per CPU, each running jobs of 50 restarts
- * on its own copy of the model.  Here the restarts run as LOCK-STEP GROUPS (default): up to 16 host threads per
- * device slot, each an ordinary sequential BFGS run, share one device context; whenever all threads of a group have
- * asked for a likelihood (+gradient) the requests go to the GPU as one batch (device_bridge.c).  The restarts of a
- * job (GPEMU_RESTARTS, default 50, times GPEMU_JOBS) are dealt evenly to the threads, the threads in contiguous
- * shares to the device slots (gpemu_host_device_slots(): every visible GPU unless GPEMU_DEVICES / GPEMU_DEVICE says
- * otherwise) -- one group per slot, no communication between groups until the arg-max under the result mutex
+ * on its own copy of the model.  Here the restarts run as LOCK-STEP GROUPS (default): up to 16 host threads per group,
+ * each an ordinary sequential BFGS run, share one device context; whenever all threads of a group have asked for a
+ * likelihood (+gradient) the requests go to the GPU as one batch (device_bridge.c).  TWO groups work for each device
+ * slot (GPEMU_GROUPS_PER_SLOT): while one group's host threads do their BFGS arithmetic -- and while its batch runs
+ * its latency-bound panel chain -- the other group's batch keeps the matrix cores busy (the device form of the
+ * reference keeping every core busy, estimate_threaded.c:172-188).  The runs of the list above are dealt round-robin to
+ * the threads, the threads in contiguous shares to the groups, the groups to the device slots
+ * (gpemu_host_device_slots(): every visible GPU unless GPEMU_DEVICES / GPEMU_DEVICE says otherwise -- set it on a
+ * shared node) -- no communication between groups until the arg-max under the result mutex
  * (estimate_threaded.c:308-313).  A caller that already works for one slot (a component thread of estimate_multi)
  * keeps the whole search on that slot.  GPEMU_LOCKSTEP=1 (or a Matern model without the corrected gradient) gives
- * the older scheme: GPEMU_NTHREADS workers with one device context each, one job at a time. */
+ * the older scheme: GPEMU_NTHREADS workers with one device context each. */
 void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 {
 	int nthreads = g_nthreads > 0 ? g_nthreads : 1;
@@ -376,31 +382,39 @@ void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 	env = getenv("GPEMU_LOCKSTEP");
 	if (env && atoi(env) > 0) lockstep = atoi(env);
 	if (lockstep > 64) lockstep = 64;
+	int per_slot = 2;
+	env = getenv("GPEMU_GROUPS_PER_SLOT");
+	if (env && atoi(env) > 0) per_slot = atoi(env) > 8 ? 8 : atoi(env);
 	/* the batched gradient exists for pow-exp (literal or exact) and for Matern with the corrected forms (gpemu.h modes) */
 	if (options->cov_fn_index != POWEREXPCOVFN && !(env_flag("GPEMU_EXACT_GRAD") && env_flag("GPEMU_MATERN_FIXED"))) lockstep = 1;
+	const int total = njobs * restarts;             /* the run list */
 	/* device slots this search may use */
 	const int pinned = gpemu_host_thread_device_get();
-	int nslots = pinned >= 0 ? 1 : gpemu_host_device_slots();
+	const int nslots = pinned >= 0 ? 1 : gpemu_host_device_slots();
 	int ngroups = 0;
 	if (lockstep > 1) {
-		/* njobs * restarts BFGS runs in total, spread over the threads of all groups, one job each */
-		const int total = njobs * restarts;
-		nthreads = lockstep * nslots;
+		nthreads = lockstep * per_slot * nslots;
 		if (nthreads > total) nthreads = total;
-		ngroups = nslots < nthreads ? nslots : nthreads;
-		njobs = nthreads;
-		restarts = (total + nthreads - 1) / nthreads;
-	}
+		/* full groups first: 20 runs on one slot are a group of 16 and a group of 4, not two of 10 (a batch of 16 costs
+		 * less per evaluation than two of 10 side by side) -- unless that leaves a slot without work */
+		ngroups = (nthreads + lockstep - 1) / lockstep;
+		if (ngroups < nslots) ngroups = nslots < nthreads ? nslots : nthreads;
+	} else if (nthreads > total) nthreads = total;
 	unsigned long seed = g_seed;
 	env = getenv("GPEMU_SEED");
 	if (env && atol(env) > 0) seed = (unsigned long)atol(env);
+	struct timeval tv0;
+	gettimeofday(&tv0, 0);
+	long ev0[5];
+	gpemu_host_eval_stats(&ev0[0], &ev0[1], &ev0[2], &ev0[3], &ev0[4]);
+	const long runs0 = __sync_fetch_and_add(&g_stat_runs, 0);
 
 	struct pool P;
-	pthread_mutex_init(&P.job_lock, NULL);
 	pthread_mutex_init(&P.result_lock, NULL);
-	P.ntries = njobs; P.jobnumber = 0;
+	P.total_runs = total; P.nthreads = nthreads; P.seed = seed;
 	P.best_thetas = gsl_vector_calloc(options->nthetas);
 	P.best_likelyhood_val = SCREWUPVALUE_T;
+	P.best_run = total;
 	P.best_gnorm = -1.0;
 
 	struct worker *W = (struct worker *)calloc((size_t)nthreads, sizeof *W);
@@ -413,20 +427,24 @@ void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 		m->thetas = gsl_vector_calloc(options->nthetas);
 		W[i].params.the_model = m;
 		W[i].params.options = options;
-		W[i].params.max_tries = restarts;
+		W[i].params.max_tries = 1;
 		W[i].params.my_best = SCREWUPVALUE_T;
+		W[i].best_thetas = gsl_vector_calloc(options->nthetas);
 		W[i].params.h_matrix = NULL;
 		W[i].params.random_number = gsl_rng_alloc(gsl_rng_default);
-		gsl_rng_set(W[i].params.random_number, seed ? seed + 7919UL * (unsigned long)i : seed_noblock());
 	}
 	void **groups = NULL;
 	if (lockstep > 1) {
-		/* group g = threads [g nthreads / ngroups, (g+1) nthreads / ngroups) on device slot g */
+		/* group g = threads [g nthreads / ngroups, (g+1) nthreads / ngroups) when the groups are even, else full groups of
+		 * `lockstep` and a remainder; group g works for device slot g mod nslots */
 		groups = (void **)calloc((size_t)ngroups, sizeof(void *));
 		struct estimate_thetas_params **members = (struct estimate_thetas_params **)malloc(sizeof(void *) * (size_t)nthreads);
+		const int even = ngroups != (nthreads + lockstep - 1) / lockstep;    /* spread over more slots than full groups would use */
 		for (int g = 0; g < ngroups; g++) {
-			const int lo = (int)((long)g * nthreads / ngroups), hi = (int)((long)(g + 1) * nthreads / ngroups);
-			const int dev = pinned >= 0 ? pinned : gpemu_host_slot_device(g);
+			int lo, hi;
+			if (even) { lo = (int)((long)g * nthreads / ngroups); hi = (int)((long)(g + 1) * nthreads / ngroups); }
+			else { lo = g * lockstep; hi = lo + lockstep < nthreads ? lo + lockstep : nthreads; }
+			const int dev = pinned >= 0 ? pinned : gpemu_host_slot_device(g % nslots);
 			for (int i = lo; i < hi; i++) { members[i - lo] = &W[i].params; W[i].in_group = 1; W[i].device = dev; }
 			gpemu_host_thread_device(dev);            /* the group's context is created on the creator's device */
 			groups[g] = gpemu_host_group_create(members, hi - lo);
@@ -445,7 +463,7 @@ void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 	printf("-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=\n");
 	for (int i = 0; i < nthreads; i++) {
 		printf("thread(%d)\tlog-L: %lf\tthetas:", i, W[i].params.my_best);
-		for (int j = 0; j < options->nthetas; j++) printf("%lf ", exp(gsl_vector_get(W[i].params.the_model->thetas, j)));
+		for (int j = 0; j < options->nthetas; j++) printf("%lf ", exp(gsl_vector_get(W[i].best_thetas, j)));
 		printf("\n");
 	}
 	printf("-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=\n");
@@ -455,13 +473,24 @@ void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 		gpemu_host_release(&W[i].params);
 		gsl_rng_free(W[i].params.random_number);
 		if (W[i].params.h_matrix) gsl_matrix_free(W[i].params.h_matrix);
+		gsl_vector_free(W[i].best_thetas);
 		gsl_vector_free(W[i].params.the_model->thetas);
 		free(W[i].params.the_model);
 	}
 	gsl_vector_memcpy(the_model->thetas, P.best_thetas);
 	g_stat_best_gnorm = P.best_gnorm;
+	if (env_flag("GPEMU_SEARCH_STATS")) {
+		/* one line for bench.py / a curious user: what this search cost on the device */
+		struct timeval tv1;
+		gettimeofday(&tv1, 0);
+		long ev1[5];
+		gpemu_host_eval_stats(&ev1[0], &ev1[1], &ev1[2], &ev1[3], &ev1[4]);
+		const double secs = (double)(tv1.tv_sec - tv0.tv_sec) + 1e-6 * (double)(tv1.tv_usec - tv0.tv_usec);
+		fprintf(stderr, "# search stats: runs %ld threads %d groups %d slots %d value_grad_evals %ld value_evals %ld cached %ld rounds %ld "
+		        "round_elements %ld seconds %.3f best %.10g\n", __sync_fetch_and_add(&g_stat_runs, 0) - runs0, nthreads, ngroups, nslots,
+		        ev1[1] - ev0[1], ev1[0] - ev0[0], ev1[2] - ev0[2], ev1[3] - ev0[3], ev1[4] - ev0[4], secs, P.best_likelyhood_val);
+	}
 	gsl_vector_free(P.best_thetas);
-	pthread_mutex_destroy(&P.job_lock);
 	pthread_mutex_destroy(&P.result_lock);
 	free(W); free(tid);
 }
