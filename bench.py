@@ -139,6 +139,91 @@ def cpu_baseline(kind, order, N, d, seed):
     }
 
 
+def train_through_cli(N, d, seed, dev, runs, exact=True):
+    """region D: `interactive_emulator estimate_thetas` (csrc/host, the reference's CLI contract) as a child process on a
+    pow-exp N x d INPUT_MODEL_FILE (interactive_emulator.c:222-238 format), fixed seed, `runs` BFGS runs in lock-step
+    groups (two per GPU).  Returns the search's own figures (GPEMU_SEARCH_STATS line of estimate_thetas_threaded)."""
+    import re
+    import subprocess
+    import tempfile
+    from madaiemulator_amd import build, synth
+    X, y = synth.design(N, d, seed)
+    with tempfile.TemporaryDirectory(prefix="gpemu_bench_") as tmp:
+        inp, snap = os.path.join(tmp, "model.dat"), os.path.join(tmp, "snapshot.txt")
+        with open(inp, "w") as f:
+            f.write(f"1\n{d}\n{N}\n")
+            np.savetxt(f, X, fmt="%.17g")
+            np.savetxt(f, y, fmt="%.17g")
+        env = dict(os.environ, GPEMU_DEVICES=str(dev), GPEMU_SEED="20261003", GPEMU_JOBS="1", GPEMU_RESTARTS=str(runs),
+                   GPEMU_SEARCH_STATS="1")
+        cmd = [build.CLI_BIN, "estimate_thetas", inp, snap, "--covariance_fn=1", "--regression_order=0"]
+        if exact:
+            cmd.append("--exact_gradient")
+        t0 = time.perf_counter()
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        wall = time.perf_counter() - t0
+        if out.returncode != 0:
+            return {"error": out.stderr[-600:]}
+        m = re.search(r"# search stats: runs (\d+) threads (\d+) groups (\d+) slots (\d+) value_grad_evals (\d+) value_evals (\d+) "
+                      r"cached (\d+) rounds (\d+) round_elements (\d+) iterations (\d+) seconds ([0-9.]+) best (\S+)", out.stderr)
+        if not m:
+            return {"error": "no search stats line", "stderr": out.stderr[-600:]}
+        g = m.groups()
+        nruns, nthreads, ngroups, nslots, nvg, nv, ncached, nrounds, nelem, niter = (int(x) for x in g[:10])
+        secs, best = float(g[10]), float(g[11])
+        return {"value_grad_evals_per_s": nvg / secs, "unit": "evalFnGradMulti calls/s inside estimate_thetas_threaded",
+                "runs": nruns, "host_threads": nthreads, "lockstep_groups": ngroups, "device_slots": nslots,
+                "value_grad_evals": nvg, "value_only_evals": nv, "answered_from_cache": ncached, "device_rounds": nrounds,
+                "mean_requests_per_round": nelem / max(nrounds, 1), "bfgs_iterations": niter,
+                "ms_per_bfgs_iteration_per_run": secs * 1e3 * nthreads / max(niter, 1),
+                "search_seconds": secs, "cli_wall_seconds": wall, "best_loglik": best,
+                "gradient": "exact" if exact else "literal (reference formulas)",
+                "workload": f"pow-exp, N={N}, d={d}, regression_order=0; lib/interactive_emulator estimate_thetas, GPEMU_RESTARTS={runs}"}
+
+
+def pca8_region(abi, shard, synth, dev, rank, world_size, steps, barrier, reduce_max):
+    """region E (BASELINE configs[3]): N=4096, d=16, t=9 outputs -> 8 PCA components (multi_modelstruct.c:172-338), each an
+    independent scalar GP on the shared design; component c -> rank c mod W.  Every component runs `steps` lock-step
+    batches of 64 fresh-theta likelihood evaluations (pow-exp, regression order 0) and its best value travels in the one
+    all-gather at the end.  Strong scaling: 8 * steps * 64 evaluations however many ranks share them."""
+    N, d, nt, B = 4096, 16, 9, 64
+    seed = 20261003 + 3
+    X, y = synth.design(N, d, seed)
+    Z = synth.pca_zmatrix(synth.multi_outputs(X, y, nt))[0]
+    nr = Z.shape[1]
+    mine = shard.cyclic_share(nr, rank, world_size)
+    ctxs = {}
+    for c in mine:
+        ctxs[c] = abi.Context(dev)
+        ctxs[c].set_model(1, 0, X, Z[:, c].copy())
+        for j in range(2):
+            ctxs[c].loglik_batch(np.array([synth.perturbed_thetas(1, d, seed + c, 9000 + 64 * j + i) for i in range(B)]))
+    barrier()
+    t0 = time.perf_counter()
+    best = {c: np.inf for c in mine}
+    for j in range(steps):                        # the components of a rank take turns: their batches overlap on the device
+        for c in mine:
+            if j > 0:
+                r = ctxs[c].loglik_batch_collect()
+                assert np.all(r["status"] == 0) and np.all(np.isfinite(r["value"])), r
+                best[c] = min(best[c], float(r["value"].min()))
+            ctxs[c].loglik_batch_enqueue(np.array([synth.perturbed_thetas(1, d, seed + c, j * B + i) for i in range(B)]))
+    for c in mine:
+        r = ctxs[c].loglik_batch_collect()
+        assert np.all(r["status"] == 0) and np.all(np.isfinite(r["value"])), r
+        best[c] = min(best[c], float(r["value"].min()))
+    barrier()
+    t = reduce_max(time.perf_counter() - t0)
+    rows = shard.farm_components(lambda c: [best[c]], nr, 1)           # the single collective: (component, best value)
+    assert rows.shape == (nr, 1) and np.all(np.isfinite(rows))
+    for c in mine:
+        ctxs[c].close()
+    return {"value": nr * steps * B / t, "unit": "likelihood-evals/s over the 8 components (total work fixed: strong scaling)",
+            "components": nr, "components_this_rank": len(mine), "batches_per_component": steps, "evaluations_per_batch": B,
+            "seconds": t, "workload": f"N={N}, d={d}, t={nt} outputs -> {nr} PCA components, pow-exp, regression_order=0",
+            "best_neg_loglik_per_component": rows[:, 0].tolist()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,6 +243,13 @@ def main():
     ap.add_argument("--no-grad", action="store_true", help="skip the value+gradient region")
     ap.add_argument("--no-single", action="store_true", help="skip the one-evaluation-at-a-time latency figure")
     ap.add_argument("--grad-steps", type=int, default=None, help="timed value+gradient batches (default min(steps, 8))")
+    ap.add_argument("--no-train", action="store_true", help="skip the estimate_thetas-through-the-C-layer region")
+    ap.add_argument("--grad-batch", type=int, default=None, help="evaluations per value+gradient batch (default min(batch, 16))")
+    ap.add_argument("--train-runs", type=int, default=64, help="BFGS runs (restarts) of that region (GPEMU_RESTARTS)")
+    ap.add_argument("--train-literal", action="store_true",
+                    help="that region with the reference's literal gradient formulas instead of the exact gradient")
+    ap.add_argument("--no-pca8", action="store_true", help="skip the 8-PCA-component region (BASELINE configs[3])")
+    ap.add_argument("--pca8-steps", type=int, default=4, help="lock-step batches of evaluations per PCA component")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -201,6 +293,11 @@ def main():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def allreduce_max(t):
+        tt = torch.tensor([t], dtype=torch.float64, device=tdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
 
     kind, N, d, order, nq = WORKLOADS[args.workload]
     if args.queries:
@@ -414,44 +511,92 @@ def main():
 
     note("region B (predictions) done")
     # ---- region C: value + gradient (evalFnGradMulti, maxmultimin.c:615-618 -- what estimate_thetas calls per BFGS
-    #      step), lock-step batches of Bg on a pow-exp model of the same N and d (own context, own HBM workspace)
+    #      step), lock-step batches of Bg on a pow-exp model of the same N and d; as in region A the batches are dealt to
+    #      `--streams` contexts through the asynchronous entry (gpemu_loglik_grad_batch_enqueue / _collect_back): the panel
+    #      chain and the host finishing of one context's batch overlap the GEMMs of the other's; every batch is collected
     vg = None
     if not args.no_grad:
-        Bg = min(B, 16)
+        Bg = args.grad_batch if args.grad_batch else min(B, 16)
         Kg = args.grad_steps if args.grad_steps else max(2, min(K, 8))
-        gctx = abi.Context(dev)
+        gns = min(nstreams, 2)
+        gctxs = [abi.Context(dev) for _ in range(gns)]
         Xg_, yg_ = synth.design(N, d, seed + 1)
-        gctx.set_model(1, 0, Xg_, yg_)
+        for gc in gctxs:
+            gc.set_model(1, 0, Xg_, yg_)
 
         def gtheta(i):
             return synth.perturbed_thetas(1, d, seed + 1, rank + world_size * i)
         for j in range(2):
-            gctx.loglik_grad_batch(np.array([gtheta(50000 + 31 * j + i) for i in range(Bg)]))
+            for gc in gctxs:
+                gc.loglik_grad_batch(np.array([gtheta(50000 + 31 * j + i) for i in range(Bg)]))
         barrier()
+        gpend = [[] for _ in gctxs]
+        gvals = np.full((Kg, Bg), np.nan)
+        ggrad_ok = True
         t0 = time.perf_counter()
-        gvals = []
         for j in range(Kg):
-            r = gctx.loglik_grad_batch(np.array([gtheta(j * Bg + i) for i in range(Bg)]))
-            assert np.all(r["status"] == 0) and np.all(np.isfinite(r["value"])) and np.all(np.isfinite(r["grad"])), r
-            gvals.append(r["value"])
+            s_ = j % gns
+            gc = gctxs[s_]
+            if len(gpend[s_]) == RING - 1:
+                r = gc.loglik_grad_batch_collect_back(RING - 2, Bg)
+                assert np.all(r["status"] == 0), r
+                gvals[gpend[s_].pop(0)] = r["value"]
+                ggrad_ok = ggrad_ok and bool(np.all(np.isfinite(r["grad"])))
+            gc.loglik_grad_batch_enqueue(np.array([gtheta(j * Bg + i) for i in range(Bg)]))
+            gpend[s_].append(j)
+        for s_, gc in enumerate(gctxs):
+            while gpend[s_]:
+                r = gc.loglik_grad_batch_collect_back(len(gpend[s_]) - 1, Bg)
+                assert np.all(r["status"] == 0), r
+                gvals[gpend[s_].pop(0)] = r["value"]
+                ggrad_ok = ggrad_ok and bool(np.all(np.isfinite(r["grad"])))
         barrier()
         tC = time.perf_counter() - t0
+        assert np.all(np.isfinite(gvals)) and ggrad_ok, "a value or gradient of the timed region is not finite"
         if distributed:
             tt = torch.tensor([tC], dtype=torch.float64, device=tdev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             tC = float(tt.item())
         gflops = float(N) ** 3 * Bg * Kg                # 2N^3/3 (factorisation with the inverse rows) + N^3/3 (C^-1 = U U^T)
         ach = gflops / tC / 1e12
+        # the same batch through the blocking entry on ONE context (what a single lock-step group sees per round)
+        t0 = time.perf_counter()
+        for j in range(2):
+            gctxs[0].loglik_grad_batch(np.array([gtheta(90000 + j * Bg + i) for i in range(Bg)]))
+        t_block = (time.perf_counter() - t0) / 2
         vg = {"value": ngpus * Kg * Bg / tC, "unit": "value+gradient evals/s", "steps": Kg, "evaluations_per_step": Bg,
-              "ms_per_evaluation": tC / (Kg * Bg) * 1e3, "workload": f"pow-exp, N={N}, d={d}, regression_order=0",
-              "gradient": "literal (reference formulas)" if not (gctx.get_mode() & abi.MODE_EXACT_GRAD) else "exact",
+              "contexts": gns, "ms_per_evaluation": tC / (Kg * Bg) * 1e3, "workload": f"pow-exp, N={N}, d={d}, regression_order=0",
+              "one_context_blocking_ms_per_batch": t_block * 1e3, "one_context_blocking_evals_per_s": Bg / t_block,
+              "gradient": "literal (reference formulas)" if not (gctxs[0].get_mode() & abi.MODE_EXACT_GRAD) else "exact",
               "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": ach / PEAK_FP64_MFMA_TFLOPS, "flops_per_eval": float(N) ** 3,
-                           "note": "whole host-visible call (staging, factorisation with inverse rows, U U^T, gradient "
-                                   "reductions, host finishing) against N^3 algorithmic flops per evaluation"}}
-        gctx.close()
+                           "note": "whole host-visible region (staging, factorisation with inverse rows, U U^T, gradient "
+                                   "reductions, host finishing, every batch collected) against N^3 algorithmic flops per evaluation"}}
+        for gc in gctxs:
+            gc.close()
 
     note("region C (value+gradient) done")
+
+    # ---- region D: estimate_thetas THROUGH THE DROP-IN (libEmuMI + the interactive_emulator CLI, a child process): the
+    #      product's own restart pool -- lock-step groups of BFGS threads over gpemu_loglik_grad_batch_* -- trains the
+    #      pow-exp model of region C from an INPUT_MODEL_FILE with a fixed seed and a bounded run list; what is reported is
+    #      what that search achieved (its own GPEMU_SEARCH_STATS line), beside the raw C-ABI figure of region C
+    train = None
+    if rank == 0 and ngpus == 1 and not args.no_train and not args.no_grad:
+        train = train_through_cli(N, d, seed + 1, dev, args.train_runs, exact=not args.train_literal)
+        if train and vg:
+            train["fraction_of_raw_value_grad"] = train["value_grad_evals_per_s"] / vg["value"]
+        note("region D (estimate_thetas through the C layer) done")
+
+    # ---- region E: BASELINE configs[3] -- the 8 PCA components of an N=4096, d=16, t=9 multi-output model
+    #      (multivar_support.c:20-28: independent scalar GPs on one design), component c -> rank c mod W
+    #      (shard.farm_components); every component gets the same number of likelihood evaluations, so the total work is
+    #      FIXED as ranks are added: the strong-scaling figure the ">= 6x at 8 GPUs" target is quoted on
+    pca8 = None
+    if not args.no_pca8:
+        pca8 = pca8_region(abi, shard, synth, dev, rank, world_size, args.pca8_steps, barrier,
+                           (lambda t: allreduce_max(t)) if distributed else (lambda t: t))
+        note("region E (8 PCA components) done")
     # ---- roofline of the prediction GEMM (the likelihood rooflines were taken right behind region A)
     if rank == 0:
         if pred is not None:
@@ -486,6 +631,8 @@ def main():
             "evaluations_per_step": B, "ms_per_evaluation": tA / (K * B) * 1e3,
             "predictions": pred,
             "value_grad": vg,
+            "estimate_thetas_c_layer": train,
+            "pca8": pca8,
             "single_evaluation": single,
             "rccl_ranks": (world_size if (distributed and backend == "nccl") else (1 if not distributed else 0)),
             "roofline": roof, "roofline_other": roof_other,

@@ -59,12 +59,12 @@ int gpemu_host_thread_device_get(void) { return tls_device; }
 int gpemu_host_device(void) { return tls_device >= 0 ? tls_device : gpemu_host_slot_device(0); }
 
 /* ---------------------------------------------------------------- registry */
-/* the last few (theta -> value, sigma^2, status) results of one caller (a `params`): evalFnMulti and estimateSigmaFull
+/* the last VCACHE_N (theta -> value, sigma^2, status) results of one caller (a `params`): evalFnMulti and estimateSigmaFull
  * are pure functions of theta and the model, and the search asks for both at the point its last evalFnGradMulti call
  * already evaluated (maxmultimin.c:98-103, 757: the value of the final thetas and their sigma^2) -- those two calls per
  * run are answered from here instead of two more factorisations.  Exact theta bits only; dropped when the model data
  * change. */
-#define VCACHE_N 4
+#define VCACHE_N 64   /* a run's final point was accepted at most one (failed) line search ago: <= 60 evaluations */
 struct vcache {
 	int n, next, nthetas;
 	double th[VCACHE_N][GPEMU_MAX_PARAMS + 2];

@@ -27,7 +27,7 @@
 #define SCREWUPVALUE_T (-HUGE_VAL)
 
 /* search statistics (gpemu_host_search_stats): what the minimiser runs of the last estimate_thetas_threaded calls did */
-static long g_stat_runs = 0, g_stat_converged = 0, g_stat_noprogress = 0, g_stat_fallbacks = 0;
+static long g_stat_runs = 0, g_stat_converged = 0, g_stat_noprogress = 0, g_stat_fallbacks = 0, g_stat_iters = 0;
 static double g_stat_best_gnorm = -1.0;         /* |gradient| at the end of the winning run of the LAST search */
 static __thread double tls_run_gnorm = -1.0, tls_best_gnorm = -1.0;
 void gpemu_host_search_stats(long *runs, long *converged, long *noprogress, long *ls_fallbacks, double *best_gnorm)
@@ -246,6 +246,7 @@ int doOptimizeMultiMin(double (*fn)(const gsl_vector *, void *),
 	if (status == GSL_CONTINUE && sqrt(dot(g, g, n)) < epsAbs) status = GSL_SUCCESS;
 	tls_run_gnorm = sqrt(dot(g, g, n));
 	__sync_fetch_and_add(&g_stat_runs, 1);
+	__sync_fetch_and_add(&g_stat_iters, stepcount);
 	if (status == GSL_SUCCESS) __sync_fetch_and_add(&g_stat_converged, 1);
 	if (status == GSL_ENOPROG) __sync_fetch_and_add(&g_stat_noprogress, 1);
 	if (stepcount == stepmax) fprintf(stderr, "# (error) multimin: no converge at stepmax %d\n", stepmax);
@@ -313,7 +314,7 @@ static unsigned long seed_noblock(void)
 
 struct pool {
 	pthread_mutex_t result_lock;
-	int total_runs, nthreads;
+	int total_runs, nthreads, next_run;
 	unsigned long seed;
 	gsl_vector *best_thetas;
 	double best_likelyhood_val;
@@ -327,13 +328,19 @@ struct worker { struct pool *pool; struct estimate_thetas_params params; int id;
  * seeded from (seed, r): the list -- how many runs, where each starts -- depends on GPEMU_JOBS / GPEMU_RESTARTS /
  * GPEMU_SEED alone, not on how many threads, lock-step groups or GPUs the runs are dealt to, and the arg-max breaks ties
  * by run index: with a fixed seed a 1-GPU and an 8-GPU machine train the same thetas and write the same snapshot.
+ * A thread that has finished a run takes the NEXT run of the list (the reference's job counter, estimate_threaded.c:
+ * 295-306): the lock-step groups stay full until the list is exhausted, whichever runs happen to stop early.
  * (The reference's amount of search depends on the core count, estimate_threaded.c:97-113; its seeds on /dev/urandom.) */
 static void *worker_main(void *arg)
 {
 	struct worker *w = (struct worker *)arg;
 	struct pool *P = w->pool;
 	gpemu_host_thread_device(w->device);         /* contexts this thread creates live on its slot's device */
-	for (int run = w->id; run < P->total_runs; run += P->nthreads) {
+	for (;;) {
+		pthread_mutex_lock(&P->result_lock);
+		const int run = P->next_run < P->total_runs ? P->next_run++ : -1;
+		pthread_mutex_unlock(&P->result_lock);
+		if (run < 0) break;
 		gsl_rng_set(w->params.random_number, P->seed ? P->seed + 7919UL * (unsigned long)run : seed_noblock());
 		if (w->params.h_matrix) { gsl_matrix_free(w->params.h_matrix); w->params.h_matrix = NULL; }
 		maxWithMultiMin(&w->params);             /* max_tries = 1: one restart */
@@ -407,11 +414,11 @@ void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 	gettimeofday(&tv0, 0);
 	long ev0[5];
 	gpemu_host_eval_stats(&ev0[0], &ev0[1], &ev0[2], &ev0[3], &ev0[4]);
-	const long runs0 = __sync_fetch_and_add(&g_stat_runs, 0);
+	const long runs0 = __sync_fetch_and_add(&g_stat_runs, 0), iters0 = __sync_fetch_and_add(&g_stat_iters, 0);
 
 	struct pool P;
 	pthread_mutex_init(&P.result_lock, NULL);
-	P.total_runs = total; P.nthreads = nthreads; P.seed = seed;
+	P.total_runs = total; P.nthreads = nthreads; P.next_run = 0; P.seed = seed;
 	P.best_thetas = gsl_vector_calloc(options->nthetas);
 	P.best_likelyhood_val = SCREWUPVALUE_T;
 	P.best_run = total;
@@ -487,8 +494,9 @@ void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 		gpemu_host_eval_stats(&ev1[0], &ev1[1], &ev1[2], &ev1[3], &ev1[4]);
 		const double secs = (double)(tv1.tv_sec - tv0.tv_sec) + 1e-6 * (double)(tv1.tv_usec - tv0.tv_usec);
 		fprintf(stderr, "# search stats: runs %ld threads %d groups %d slots %d value_grad_evals %ld value_evals %ld cached %ld rounds %ld "
-		        "round_elements %ld seconds %.3f best %.10g\n", __sync_fetch_and_add(&g_stat_runs, 0) - runs0, nthreads, ngroups, nslots,
-		        ev1[1] - ev0[1], ev1[0] - ev0[0], ev1[2] - ev0[2], ev1[3] - ev0[3], ev1[4] - ev0[4], secs, P.best_likelyhood_val);
+		        "round_elements %ld iterations %ld seconds %.3f best %.10g\n", __sync_fetch_and_add(&g_stat_runs, 0) - runs0, nthreads, ngroups, nslots,
+		        ev1[1] - ev0[1], ev1[0] - ev0[0], ev1[2] - ev0[2], ev1[3] - ev0[3], ev1[4] - ev0[4],
+		        __sync_fetch_and_add(&g_stat_iters, 0) - iters0, secs, P.best_likelyhood_val);
 	}
 	gsl_vector_free(P.best_thetas);
 	pthread_mutex_destroy(&P.result_lock);

@@ -50,6 +50,29 @@ def multi_outputs(X, y, nt):
     return Y
 
 
+def pca_zmatrix(Y, varfrac=1.0):
+    """the PCA decomposition of a multi-output training matrix as the reference does it (multi_modelstruct.c:172-338,
+    SURVEY App. A.6): column means, S = Yc^T Yc / N, eigenpairs sorted descending, nr = smallest i >= 1 whose leading
+    eigenvalues reach varfrac -- the loop stops at nt - 1 --, Z = Yc U_r diag(lambda_r^-1/2).  Returns (Z, evals_r,
+    evecs_r, ybar); eigenvector signs are LAPACK's (sign-ambiguous like GSL's)."""
+    N, nt = Y.shape
+    ybar = Y.mean(axis=0)
+    Yc = Y - ybar
+    lam, U = np.linalg.eigh(Yc.T @ Yc / N)
+    lam, U = lam[::-1], U[:, ::-1]
+    nr = 1
+    if nt > 1:
+        tot, frac = lam.sum(), 0.0
+        nr = nt - 1
+        for i in range(1, nt):
+            frac = lam[:i].sum() / tot
+            if frac >= varfrac:
+                nr = i
+                break
+    Z = Yc @ U[:, :nr] / np.sqrt(lam[:nr])
+    return Z, lam[:nr].copy(), U[:, :nr].copy(), ybar
+
+
 def queries(M, d, seed):
     return uniform(seed, (M, d))
 

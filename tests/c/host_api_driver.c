@@ -7,6 +7,7 @@
  *   host_api_driver roundtrip SNAPSHOT_IN SNAPSHOT_OUT
  *   host_api_driver multi SNAPSHOT QUERY_FILE
  *   host_api_driver lowlevel INPUT_MODEL_FILE cov_fn order QUERY_FILE theta_full...   (the host-matrix interface)
+ *   host_api_driver rewrite INPUT_MODEL_FILE cov_fn order theta_less_amp...   (the caller rewrites its buffers in place)
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -102,6 +103,32 @@ int main(int argc, char **argv)
 			printf("\n");
 		}
 		gpemu_host_release(&params);
+	} else if (!strcmp(argv[1], "rewrite")) {
+		/* the reference re-reads the model on every call (maxmultimin.c:317): a caller may rewrite training_vector->data or
+		 * xmodel->data IN PLACE between calls (same pointers) and must get the likelihood of the new data */
+		struct estimate_thetas_params params;
+		memset(&params, 0, sizeof params);
+		params.options = model->options;
+		params.the_model = model;
+		gsl_vector *th = gsl_vector_alloc(nthetas - 1), *g = gsl_vector_alloc(nthetas - 1);
+		for (int i = 0; i < nthetas - 1; i++) gsl_vector_set(th, i, atof(argv[5 + i]));
+		printf("step0 %.17g %.17g\n", evalFnMulti(th, &params), estimateSigmaFull(th, &params));
+		for (size_t i = 0; i < model->training_vector->size; i++)           /* same buffer, new outputs */
+			model->training_vector->data[i * model->training_vector->stride] = 0.5 * model->training_vector->data[i * model->training_vector->stride] + 0.01 * (double)(i % 7);
+		printf("step1 %.17g %.17g\n", evalFnMulti(th, &params), estimateSigmaFull(th, &params));
+		for (size_t i = 0; i < model->xmodel->size1; i++)                   /* same buffer, new design */
+			for (size_t k = 0; k < model->xmodel->size2; k++)
+				model->xmodel->data[i * model->xmodel->tda + k] = 0.9 * model->xmodel->data[i * model->xmodel->tda + k] + 0.003 * (double)((i + 3 * k) % 11);
+		double f2;
+		evalFnGradMulti(th, &params, &f2, g);
+		printf("step2 %.17g %.17g\n", f2, estimateSigmaFull(th, &params));
+		printf("step2b %.17g\n", evalFnMulti(th, &params));
+		{
+			long v, vg, c, r, e;
+			gpemu_host_eval_stats(&v, &vg, &c, &r, &e);
+			printf("evalstats %ld %ld %ld\n", v, vg, c);
+		}
+		gpemu_host_release(&params);
 	} else if (!strcmp(argv[1], "train")) {
 		/* estimate_thetas_threaded on the model, then the best thetas and -logL at them (evalFnMulti) */
 		setup_optimization_ranges(model->options, model);
@@ -121,6 +148,11 @@ int main(int argc, char **argv)
 			double gn;
 			gpemu_host_search_stats(&runs, &conv, &noprog, &fb, &gn);
 			printf("search %ld %ld %ld %ld %.17g\n", runs, conv, noprog, fb, gn);
+			{
+				long v, vg, c, r, e;
+				gpemu_host_eval_stats(&v, &vg, &c, &r, &e);
+				printf("evalstats %ld %ld %ld %ld %ld\n", v, vg, c, r, e);
+			}
 			if (cov == POWEREXPCOVFN || getenv("GPEMU_EXACT_GRAD")) {
 				gsl_vector *g = gsl_vector_alloc(nthetas - 1);
 				gradFnMulti(th, &params, g);

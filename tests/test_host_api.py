@@ -464,6 +464,102 @@ def test_training_at_n4096_where_the_reference_argmax_floor_would_fail(driver, t
 
 
 @pytest.mark.gpu
+def test_model_buffers_rewritten_in_place_are_seen(driver, tmp_path):
+    """The reference re-reads the model on every call (maxmultimin.c:317: the matrix is filled from the_model->xmodel
+    each time), so a caller may rewrite training_vector->data or xmodel->data IN PLACE -- same pointers -- between calls
+    (libRbind-style loops, an MCMC re-fit).  The device copy is keyed by a checksum of every value, not by pointer
+    identity: each step must return the likelihood of the data as they are at that call, and the per-caller value cache
+    must not survive a change of the data (tests/c/host_api_driver.c `rewrite` does the rewriting)."""
+    N, d = 200, 3
+    X, y = synth.design(N, d, 606)
+    f = tmp_path / "rw.dat"
+    _write_model_file(f, X, y)
+    th = synth.default_thetas(1, d)[1:]
+    res = parse(run([driver, "rewrite", str(f), "1", "1"] + [repr(float(v)) for v in th], env=dict(os.environ, GPEMU_DEVICES="0")))
+    y1 = 0.5 * y + 0.01 * (np.arange(N) % 7)
+    X2 = 0.9 * X + 0.003 * ((np.arange(N)[:, None] + 3 * np.arange(d)[None, :]) % 11)
+    for key, (Xs, ys) in (("step0", (X, y)), ("step1", (X, y1)), ("step2", (X2, y1))):
+        ref = O.eval_fn_multi(1, 1, Xs, ys, th)
+        assert res[key][0][0] == pytest.approx(ref["value"], rel=RTOL), key
+        assert res[key][0][1] == pytest.approx(ref["sigma2"], rel=RTOL), key
+    assert res["step2b"][0][0] == res["step2"][0][0]
+    # three data states -> three device evaluations (two value-only, one value+gradient); the other four requests -- the
+    # sigma^2 of each state and the repeated value of the last -- were answered from the caller's cache of its last results
+    assert res["evalstats"][0] == [2.0, 1.0, 4.0]
+
+
+@pytest.mark.gpu
+def test_search_result_does_not_depend_on_the_device_slots(driver, tmp_path):
+    """the run list of estimate_thetas_threaded (how many BFGS runs, where each starts) is derived from GPEMU_JOBS x
+    GPEMU_RESTARTS and the seed alone; the runs are then dealt to however many threads, lock-step groups and device slots
+    there are, and the arg-max breaks ties by run index: one slot, three slots, one or two groups per slot, groups of 16
+    or of 5 and the one-context-per-thread scheme all return the same thetas, bit for bit.  (An element of a lock-step
+    batch equals the same evaluation done alone, so a run's trajectory does not depend on its batch mates.)  The end-of-run
+    evalFnMulti / estimateSigmaFull calls never reach the device: they are answered from the member's cache."""
+    N, d = 300, 3
+    X, y = synth.design(N, d, 2718)
+    y = y + 0.2 * synth.normal(5, N)
+    f = tmp_path / "det.dat"
+    _write_model_file(f, X, y)
+    outs = {}
+    for name, extra in (("one_slot", dict(GPEMU_DEVICES="0")), ("three_slots", dict(GPEMU_DEVICES="0,0,0")),
+                        ("one_group", dict(GPEMU_DEVICES="0", GPEMU_GROUPS_PER_SLOT="1")),
+                        ("groups_of_5", dict(GPEMU_DEVICES="0", GPEMU_LOCKSTEP="5")),
+                        ("threads", dict(GPEMU_DEVICES="0", GPEMU_LOCKSTEP="1", GPEMU_NTHREADS="3"))):
+        env = dict(os.environ, GPEMU_SEED="31", GPEMU_JOBS="3", GPEMU_RESTARTS="8", GPEMU_EXACT_GRAD="1", **extra)
+        res = parse(run([driver, "train", str(f), "1", "0"], env=env))
+        outs[name] = (res["thetas"][0], res["neglogl"][0][0])
+        runs = res["search"][0][0]
+        nv, nvg, ncached = res["evalstats"][0][:3]
+        assert runs == 24
+        # per run: estimateSigmaFull + evalFnMulti at the final point, both from the cache; the driver's own evalFnMulti of
+        # the winning thetas afterwards is the one value-only evaluation on the device
+        assert ncached + (nv - 1) == 48 and nv <= 3 and nvg > 24, res["evalstats"]
+    for name in outs:
+        assert outs[name] == outs["one_slot"], (name, outs)
+    assert outs["one_slot"][1] == pytest.approx(O.eval_fn_multi(1, 0, X, y, np.array(outs["one_slot"][0][1:]))["value"], rel=1e-6)
+
+
+@pytest.mark.gpu
+def test_training_at_n8192_through_the_lockstep_groups(driver, tmp_path):
+    """estimate_thetas at the size the headline metric is quoted on (N=8192, d=8, pow-exp): 32 BFGS runs as two lock-step
+    groups of 16 on the one GPU (value+gradient batches of 16 through gpemu_loglik_grad_batch_enqueue / _collect_back), a
+    bounded number of iterations' worth of device time (a minute).  The value at the returned thetas is what gpemu_loglik
+    says there (the driver's evalFnMulti), the winning run converged, and the search's own counters show full batches."""
+    N, d = 8192, 8
+    X, y = synth.design(N, d, 20261003 + 3)
+    y = y + 0.3 * synth.normal(11, N)
+    f = tmp_path / "train8192.dat"
+    with open(f, "w") as fh:
+        fh.write(f"1\n{d}\n{N}\n")
+        np.savetxt(fh, X, fmt="%.17g")
+        np.savetxt(fh, y, fmt="%.17g")
+    env = dict(os.environ, GPEMU_SEED="7", GPEMU_JOBS="1", GPEMU_RESTARTS="32", GPEMU_EXACT_GRAD="1", GPEMU_DEVICES="0",
+               GPEMU_SEARCH_STATS="1")
+    out = subprocess.run([driver, "train", str(f), "1", "0"], env=env, capture_output=True, text=True, timeout=220)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = parse(out.stdout)
+    th = np.array(res["thetas"][0])
+    runs, conv, noprog, fallbacks, best_gnorm = res["search"][0]
+    nv, nvg, ncached, rounds, elems = res["evalstats"][0]
+    assert runs == 32 and np.all(np.isfinite(th)) and np.isfinite(res["neglogl"][0][0])
+    assert "# search stats: runs 32 threads 32 groups 2 slots 1" in out.stderr
+    assert conv >= 1 and 0.0 <= best_gnorm < 0.1
+    assert ncached + (nv - 1) == 64 and nv <= 3
+    assert elems / rounds > 8.0                      # mean requests per device round (16 while every run is alive)
+    # the returned thetas against an independent evaluation of the same likelihood on a fresh context
+    from madaiemulator_amd import abi
+    c = abi.Context(0)
+    c.set_model(1, 0, X, y)
+    full = th.copy()
+    full[0] = 0.0
+    assert c.loglik(full)["value"] == res["neglogl"][0][0]
+    g = c.loglik_grad(full)
+    c.close()
+    assert g["value"] == res["neglogl"][0][0]
+
+
+@pytest.mark.gpu
 def test_call_eval_lhood_list_without_r():
     """libRbind's batched likelihood entry (rbind.c:626-724): flat .C() signature, column-major arrays"""
     import ctypes as C
