@@ -271,7 +271,18 @@ def main():
     from madaiemulator_amd import abi, shard, synth
 
     rank, world_size, local_rank = shard.world()
-    distributed = world_size > 1
+    # BENCH_FORCE_DIST=1: initialise the process group (RCCL when BENCH_BACKEND is "nccl") even for ONE rank, so that the
+    # collective code path of an N > 1 run -- init, barrier, all_reduce, the padded all_gather -- can be rehearsed on a
+    # one-GPU box (two RCCL ranks cannot share a device)
+    distributed = world_size > 1 or bool(os.environ.get("BENCH_FORCE_DIST"))
+    if distributed and "RANK" not in os.environ:
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(so.getsockname()[1]))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("LOCAL_RANK", "0")
     backend = os.environ.get("BENCH_BACKEND", "nccl")     # "gloo": rehearse the N>1 path with ranks sharing one GPU
     ndev = max(1, torch.cuda.device_count())
     dev_index = local_rank % ndev
@@ -635,6 +646,7 @@ def main():
             "pca8": pca8,
             "single_evaluation": single,
             "rccl_ranks": (world_size if (distributed and backend == "nccl") else (1 if not distributed else 0)),
+            "process_group": (backend if distributed else None),
             "roofline": roof, "roofline_other": roof_other,
             "cpu_baseline": cpu,
             "speedup_vs_cpu_all_cores": (evals_per_s / cpu["value"]) if cpu else None,

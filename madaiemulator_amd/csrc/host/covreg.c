@@ -32,14 +32,10 @@ double covariance_fn_gaussian(gsl_vector *xm, gsl_vector *xn, gsl_vector *thetas
 	return c;
 }
 
-/* GPEMU_MATERN_FIXED=1 (the device library's GPEMU_MODE_MATERN_LOG, gpemu.h): amplitude and nugget on the log scale,
- * so that the scalar functions agree with the matrices the device builds in that mode */
-static int matern_log_scale(void)
-{
-	static int cached = -1;
-	if (cached < 0) { const char *e = getenv("GPEMU_MATERN_FIXED"); cached = (e && atoi(e) > 0) ? 1 : 0; }
-	return cached;
-}
+/* GPEMU_MODE_MATERN_LOG (gpemu.h; GPEMU_MATERN_FIXED=1, --matern_fixed, or recorded in the snapshot): amplitude and
+ * nugget on the log scale, so that the scalar functions agree with the matrices the device builds in that mode.  The
+ * flag lives in ONE place for the whole host layer (gpemu_host_modes, device_bridge.c). */
+static int matern_log_scale(void) { return (gpemu_host_modes() & GPEMU_MODE_MATERN_LOG) != 0; }
 
 static double matern_dist(gsl_vector *xm, gsl_vector *xn, int nparams, int *same)
 {

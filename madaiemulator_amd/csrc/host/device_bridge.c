@@ -58,6 +58,36 @@ void gpemu_host_thread_device(int device) { tls_device = device; }
 int gpemu_host_thread_device_get(void) { return tls_device; }
 int gpemu_host_device(void) { return tls_device >= 0 ? tls_device : gpemu_host_slot_device(0); }
 
+/* ---------------------------------------------------------------- modes
+ * ONE source of truth for the corrected forms of gpemu.h (GPEMU_MODE_EXACT_GRAD, GPEMU_MODE_MATERN_LOG) in the host
+ * layer: read from the environment once (GPEMU_EXACT_GRAD / GPEMU_MATERN_FIXED), changed by gpemu_host_set_modes (the
+ * CLI's --exact_gradient / --matern_fixed, a snapshot that records the log-scale mode), and applied to EVERY device
+ * context the layer creates or holds.  The scalar covariance functions (covreg.c: kappa = c(x*,x*)), the optimiser's
+ * line search and the device kernels therefore always agree on what the thetas mean. */
+static int g_modes = -1;
+struct entry;
+static void apply_modes_to_entries(int flags);
+
+int gpemu_host_modes(void)
+{
+	if (g_modes < 0) {
+		const char *eg = getenv("GPEMU_EXACT_GRAD"), *mf = getenv("GPEMU_MATERN_FIXED");
+		int m = 0;
+		if (eg && atoi(eg) > 0) m |= GPEMU_MODE_EXACT_GRAD;
+		if (mf && atoi(mf) > 0) m |= GPEMU_MODE_MATERN_LOG;
+		__sync_val_compare_and_swap(&g_modes, -1, m);
+	}
+	return g_modes;
+}
+
+void gpemu_host_set_modes(int flags)
+{
+	flags &= GPEMU_MODE_EXACT_GRAD | GPEMU_MODE_MATERN_LOG;
+	(void)gpemu_host_modes();
+	g_modes = flags;
+	apply_modes_to_entries(flags);
+}
+
 /* ---------------------------------------------------------------- registry */
 /* the last VCACHE_N (theta -> value, sigma^2, status) results of one caller (a `params`): evalFnMulti and estimateSigmaFull
  * are pure functions of theta and the model, and the search asks for both at the point its last evalFnGradMulti call
@@ -131,11 +161,24 @@ static struct entry *lookup(const void *key, int create)
 		e->key = key;
 		int rc = gpemu_ctx_create(&e->ctx, gpemu_host_device());
 		if (rc) { pthread_mutex_unlock(&g_lock); die(NULL, rc, "gpemu_ctx_create"); }
+		gpemu_set_mode(e->ctx, gpemu_host_modes());      /* the layer's modes, not whatever the environment says now */
 		e->next = g_entries;
 		g_entries = e;
 	}
 	pthread_mutex_unlock(&g_lock);
 	return e;
+}
+
+static void apply_modes_to_entries(int flags)
+{
+	pthread_mutex_lock(&g_lock);
+	for (struct entry *e = g_entries; e; e = e->next) {
+		if (gpemu_get_mode(e->ctx) != flags) {
+			gpemu_set_mode(e->ctx, flags);
+			vcache_clear(&e->vc);                        /* the thetas mean something else now */
+		}
+	}
+	pthread_mutex_unlock(&g_lock);
 }
 
 /* one scratch device context per host thread for the model-less low-level entries (lowlevel.c) */

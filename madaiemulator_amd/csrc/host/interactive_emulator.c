@@ -246,8 +246,8 @@ static struct cmdLineOpts *global_opt_parse(int argc, char **argv)
 			/* fall through (as the reference does) */
 		case 'z': o->pcaOutputFlag = 1; /* fall through */
 		case 'q': o->quietFlag = 1; break;
-		case 1001: setenv("GPEMU_EXACT_GRAD", "1", 1); break;
-		case 1002: setenv("GPEMU_MATERN_FIXED", "1", 1); break;
+		case 1001: gpemu_host_set_modes(gpemu_host_modes() | 1 /* GPEMU_MODE_EXACT_GRAD */); break;
+		case 1002: gpemu_host_set_modes(gpemu_host_modes() | 2 /* GPEMU_MODE_MATERN_LOG */); break;
 		case 'h':
 		case '?': exit(perr(useage));
 		default: break;

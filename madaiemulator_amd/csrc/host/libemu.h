@@ -252,6 +252,11 @@ void gpemu_host_search_stats(long *runs, long *converged, long *noprogress, long
 /* device evaluations of this process so far: value-only, value+gradient, requests answered from a caller's cache of its
  * last results, lock-step rounds and the requests they carried (GPEMU_SEARCH_STATS=1 prints the figures of a search) */
 void gpemu_host_eval_stats(long *value_evals, long *valgrad_evals, long *cached, long *rounds, long *round_elements);
+/* the corrected forms of gpemu.h (GPEMU_MODE_EXACT_GRAD = 1, GPEMU_MODE_MATERN_LOG = 2) for the WHOLE host layer: first
+ * read from GPEMU_EXACT_GRAD / GPEMU_MATERN_FIXED, set here (the CLI's --exact_gradient / --matern_fixed; a snapshot that
+ * records the log-scale mode), applied to every device context the layer holds or creates */
+int gpemu_host_modes(void);
+void gpemu_host_set_modes(int flags);
 void gpemu_host_release(void *params_or_emulator); /* drop the device context cached for a params / emulator pointer */
 /* lock-step group: n restart threads (one struct estimate_thetas_params each, same model) share one device context;
  * their concurrent evalFnMulti / gradFnMulti / evalFnGradMulti / estimateSigmaFull calls are gathered into device

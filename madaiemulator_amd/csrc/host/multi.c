@@ -187,6 +187,12 @@ void dump_multi_modelstruct(FILE *fptr, multi_modelstruct *m)
 		fprintf(fptr, "\n");
 	}
 	for (int i = 0; i < m->nr; i++) dump_modelstruct_2(fptr, m->pca_model_array[i]);
+	/* Not in the reference's grammar, and invisible to its loader (which stops reading after the last modelstruct,
+	 * multi_modelstruct.c:417-472): a Matern model trained with amplitude and nugget on the LOG scale says so.  Queried
+	 * in the raw form its thetas would silently mean amp = theta0 instead of e^theta0.  Literal-mode snapshots (and every
+	 * pow-exp one) carry no such line: they stay byte for byte what the reference writes. */
+	if (m->cov_fn_index != POWEREXPCOVFN && (gpemu_host_modes() & 2 /* GPEMU_MODE_MATERN_LOG */))
+		fprintf(fptr, "#gpemu matern_log_scale 1\n");
 }
 
 static int rd_int(FILE *f) { int v = 0; if (fscanf(f, "%d%*c", &v) != 1) { fprintf(stderr, "snapshot: read error\n"); exit(EXIT_FAILURE); } return v; }
@@ -216,6 +222,22 @@ multi_modelstruct *load_multi_modelstruct(FILE *fptr)
 	for (int i = 0; i < nt; i++) for (int j = 0; j < nr; j++) gsl_matrix_set(m->pca_evecs_r, i, j, rd_dbl(fptr));
 	for (int i = 0; i < N; i++) for (int j = 0; j < nr; j++) gsl_matrix_set(m->pca_zmatrix, i, j, rd_dbl(fptr));
 	for (int i = 0; i < nr; i++) m->pca_model_array[i] = load_modelstruct_2(fptr);
+	{
+		/* the trailer dump_multi_modelstruct writes for log-scale Matern models: switch the layer to that mode */
+		char line[128];
+		int recorded = 0;
+		while (fgets(line, sizeof line, fptr))
+			if (!strncmp(line, "#gpemu matern_log_scale 1", 25)) recorded = 1;
+		if (m->cov_fn_index != POWEREXPCOVFN) {
+			const int have = (gpemu_host_modes() & 2) != 0;
+			if (recorded && !have) {
+				fprintf(stderr, "# snapshot: Matern thetas are on the log scale (trained with --matern_fixed): using that mode\n");
+				gpemu_host_set_modes(gpemu_host_modes() | 2);
+			} else if (!recorded && have) {
+				fprintf(stderr, "# snapshot: no log-scale record in this Matern snapshot, but GPEMU_MATERN_FIXED is set: thetas are taken on the log scale\n");
+			}
+		}
+	}
 	for (int i = 0; i < nt; i++) {
 		gsl_vector_view col = gsl_matrix_column(m->training_matrix, i);
 		gsl_vector_set(m->training_mean, i, vector_elt_sum(&col.vector, N) / (double)N);

@@ -17,6 +17,7 @@
 #include <pthread.h>
 #include <sys/time.h>
 #include "libemu.h"
+#include "gpemu.h"
 
 /* The reference starts its arg-max over restarts at -2000 (maxmultimin.c:38,60,110) and over threads at -20000
  * (estimate_threaded.c:5,34): a model whose log-likelihood never exceeds that (any N of a few thousand: logL scales
@@ -122,7 +123,7 @@ static int line_search(struct fdf *F, const double *x, double f0, const double *
 	 * function and is given the sections it needs: -logL has plateaus (all length scales large) next to walls (a
 	 * vanishing nugget), so a bracket can be 10^5 times wider than the acceptable interval.  With the literal
 	 * gradient the tests cannot be trusted (see above) and the search gives up early. */
-	const int exact = env_flag("GPEMU_EXACT_GRAD");
+	const int exact = (gpemu_host_modes() & GPEMU_MODE_EXACT_GRAD) != 0;
 	const int max_zoom = exact ? 48 : 16;
 	/* no trial point further than 6 log-units from x in any hyper-parameter (a factor 400 in a length scale) */
 	double pmax = 0.0;
@@ -393,7 +394,7 @@ void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 	env = getenv("GPEMU_GROUPS_PER_SLOT");
 	if (env && atoi(env) > 0) per_slot = atoi(env) > 8 ? 8 : atoi(env);
 	/* the batched gradient exists for pow-exp (literal or exact) and for Matern with the corrected forms (gpemu.h modes) */
-	if (options->cov_fn_index != POWEREXPCOVFN && !(env_flag("GPEMU_EXACT_GRAD") && env_flag("GPEMU_MATERN_FIXED"))) lockstep = 1;
+	if (options->cov_fn_index != POWEREXPCOVFN && gpemu_host_modes() != (GPEMU_MODE_EXACT_GRAD | GPEMU_MODE_MATERN_LOG)) lockstep = 1;
 	const int total = njobs * restarts;             /* the run list */
 	/* device slots this search may use */
 	const int pinned = gpemu_host_thread_device_get();

@@ -702,20 +702,19 @@ def _sample_pairs(N, rng, n_random=10000):
     return I.astype(np.int64), J.astype(np.int64)
 
 
-@pytest.mark.parametrize("kind,N", [(3, 8192), (1, 16384)])
-def test_full_size_fill_elements_against_the_oracle(gpu_ctx, kind, N):
-    """BASELINE.json configs[2] and configs[4] sizes: > 10^4 sampled elements of the device fill -- random lower pairs,
+@pytest.mark.parametrize("kind,N,d", [(3, 8192, 8), (1, 16384, 8), (1, 4096, 16)])
+def test_full_size_fill_elements_against_the_oracle(gpu_ctx, kind, N, d):
+    """BASELINE.json configs[2], configs[4] and configs[3] (d = 16) sizes: > 10^4 sampled elements of the device fill -- random lower pairs,
     diagonal, last row, last tile column, duplicated design points (off-diagonal nugget, emulator.c:136-150) -- against
     the oracle's covariance function (emulator.c:101-152, 438-480 restated) at 1e-13, for BOTH fill paths: the 2-D
     cov_fill_kernel (gpemu_cov_matrix) and the one-launch lower-tile staging of a lock-step batch (what
     gpemu_loglik_batch factors), element 0 and the last element of a batch of 3."""
-    d = 8
-    X, y = synth.design(N, d, 20261003 + kind)
+    X, y = synth.design(N, d, 20261003 + kind + d)
     X = X.copy()
-    dups = [(N - 1, 5), (4097, 4096), (N // 2 + 63, 64), (1000, 999)]      # row i repeats row j
+    dups = [(N - 1, 5), (N // 2 + 1, N // 2), (N // 2 + 63, 64), (1000, 999)]      # row i repeats row j
     for i, j in dups:
         X[i] = X[j]
-    rng = np.random.default_rng(kind * 1000 + N)
+    rng = np.random.default_rng(kind * 1000 + N + d)
     I, J = _sample_pairs(N, rng)
     I = np.concatenate([I, [p[0] for p in dups]])
     J = np.concatenate([J, [p[1] for p in dups]])
@@ -809,6 +808,77 @@ def test_n4096_oracle_fixture(gpu_ctx):
              quad=float(f["quad"]), info=int(f["info"]))
     _check_full_evaluation(gpu_ctx, kind, order, N, d, seed, f["thetas"], qseed, o, f["mean"], f["var"], f["emu_beta"],
                            float(f["emu_logdet"]))
+
+
+def test_n8192_c3_oracle_fixture_and_a_50000_query_call(gpu_ctx):
+    """BASELINE.json configs[2] EXACTLY -- N=8192, d=8, Matern 5/2, regression order 1, the bench's own design and
+    hyper-parameters: the device against ONE full oracle evaluation (emulator_struct.c:13-37 + estimator-fns.c:38-103
+    restated: fill, unblocked Cholesky, explicit inverse, estimateBeta) and 64 oracle emulate_point calls
+    (emulator_struct.c:124-143), computed offline by tests/golden/make_golden_n8192_c3.py (most of an hour of one core,
+    LAPACK cross-checked) and committed as ~150 numbers -- one oracle number at this size, no chain through the device's
+    own fill.  Then the query-block size the bench pushes: ONE 50 000-query gpemu_predict_batch call whose first and
+    last 64 queries are the fixture's; their results match the fixture at the parity bar, equal to rounding the 64-query
+    call (which takes the split-K path: another summation order) and equal bit for bit the same queries inside a
+    1024-query call (unsplit products: one k-ordered chain per element wherever the tile sits)."""
+    import os
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_n8192_c3.npz"))
+    kind, order, N, d, seed, qseed, nq = (int(v) for v in f["meta"])
+    assert (kind, order, N, d, seed) == (3, 1, 8192, 8, 20261003 + 2)          # bench.py WORKLOADS["c3"] and its seed
+    th = f["thetas"]
+    assert np.array_equal(th, synth.default_thetas(kind, d))
+    X, y = synth.design(N, d, seed)
+    gpu_ctx.set_model(kind, order, X, y)
+    got = gpu_ctx.loglik(th)
+    gotb = gpu_ctx.loglik_batch(np.array([th, synth.perturbed_thetas(kind, d, 9, 1), th]))
+    assert got["status"] == 0
+    for k in ("value", "sigma2", "logdet", "quad"):
+        assert got[k] == pytest.approx(float(f[k]), rel=RTOL), k
+    assert relerr(got["beta"], f["beta"]) < RTOL
+    assert gotb["value"][0] == got["value"] and gotb["value"][2] == got["value"]     # batch element = single evaluation
+    assert np.array_equal(gotb["beta"][0], got["beta"])
+    gpu_ctx.predict_setup(th)
+    Xq = synth.queries(nq, d, qseed)
+    m64, v64 = gpu_ctx.predict(Xq)
+    kappa = th[0] + th[1]                                                        # raw Matern amplitude + nugget
+    assert np.max(np.abs(m64 - f["mean"])) < RTOL * max(1.0, np.abs(f["mean"]).max())
+    assert np.max(np.abs(v64 - f["var"])) < RTOL * kappa
+    big = synth.queries(50000, d, qseed + 1)
+    big[:nq] = Xq
+    big[-nq:] = Xq
+    mb, vb = gpu_ctx.predict(big)                                                # one call, 50 000 queries
+    assert np.all(np.isfinite(mb)) and np.all(np.isfinite(vb)) and np.all(vb > -RTOL * kappa)
+    for sl in (slice(0, nq), slice(50000 - nq, 50000)):
+        assert np.max(np.abs(mb[sl] - f["mean"])) < RTOL * max(1.0, np.abs(f["mean"]).max())
+        assert np.max(np.abs(vb[sl] - f["var"])) < RTOL * kappa
+        assert np.max(np.abs(mb[sl] - m64)) < 1e-11 * max(1.0, np.abs(m64).max()) and np.max(np.abs(vb[sl] - v64)) < 1e-11 * kappa
+    assert np.array_equal(mb[:nq], mb[-nq:]) and np.array_equal(vb[:nq], vb[-nq:])   # same query, different block: same bits
+    mid = synth.queries(1024, d, qseed + 2)
+    mid[:nq] = Xq
+    mm, vm = gpu_ctx.predict(mid)
+    assert np.array_equal(mm[:nq], mb[:nq]) and np.array_equal(vm[:nq], vb[:nq])
+
+
+def test_exact_gradient_against_mpmath_golden_v3():
+    """the corrected gradient forms (GPEMU_MODE_EXACT_GRAD, + GPEMU_MODE_MATERN_LOG for the Matern kernels) against an
+    independent vector: the derivative of the 50-digit mpmath value, taken numerically there
+    (tests/golden/make_golden_v3.py; N = 34, d = 3: Matern 5/2 orders 1 and 0, Matern 3/2, pow-exp).  Until round 3 the
+    analytic Matern forms were only checked against finite differences of the device's own likelihood."""
+    import os
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_v3.npz"))
+    X, y = f["X"], f["y"]
+    c = abi.Context(0)
+    for i in range(int(f["ncases"])):
+        kind, order, th = int(f[f"kind{i}"]), int(f[f"order{i}"]), f[f"th{i}"]
+        c.set_mode(abi.MODE_EXACT_GRAD | (abi.MODE_MATERN_LOG if kind != 1 else 0))
+        c.set_model(kind, order, X, y)
+        got = c.loglik_grad(th)
+        ref = f[f"grad{i}"]
+        assert got["status"] == 0
+        assert got["value"] == pytest.approx(float(f[f"value{i}"]), rel=RTOL)
+        assert np.max(np.abs(got["grad"] - ref)) < RTOL * np.max(np.abs(ref)), (i, got["grad"], ref)
+        gb = c.loglik_grad_batch(np.array([th, th]))
+        assert np.array_equal(gb["grad"][0], got["grad"]) and np.array_equal(gb["grad"][1], got["grad"])
+    c.close()
 
 
 # ------------------------------------------------------------------ ragged and extreme shapes

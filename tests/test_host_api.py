@@ -322,6 +322,17 @@ def test_cli_trains_a_matern_model_with_the_corrected_forms(driver, tmp_path):
                input="\n".join(repr(float(x)) for x in X[:5, 0]) + "\n")
     got = np.array(out2.split(), float).reshape(-1, 2)
     assert np.max(np.abs(got[:, 0] - Y[:5, 0])) < 0.05 * np.ptp(Y[:, 0])
+    # the snapshot records that its Matern thetas are on the log scale (a trailing line the reference's loader never
+    # reads): queried WITHOUT --matern_fixed it is still read in that mode, with a note -- not silently as amp = theta0
+    assert snap.read_text().rstrip().endswith("#gpemu matern_log_scale 1")
+    env2 = {k: v for k, v in os.environ.items() if k not in ("GPEMU_MATERN_FIXED", "GPEMU_EXACT_GRAD")}
+    plain = subprocess.run([cli, "interactive_mode", str(snap), "-q"], stdin=open(qpath), capture_output=True, text=True,
+                           timeout=300, env=env2)
+    assert plain.returncode == 0 and plain.stdout == out and "log scale" in plain.stderr
+    # ... and the round trip keeps the record: load -> dump gives the same bytes
+    rt = tmp_path / "matern_rt"
+    run([driver, "roundtrip", str(snap), str(rt)], env=env2)
+    assert rt.read_bytes() == snap.read_bytes()
 
 
 @pytest.mark.gpu
@@ -407,6 +418,32 @@ def test_multi_output_training_over_device_slots_writes_the_same_snapshot(driver
     preds = [run([driver, "multi", str(tmp_path / "snap_serial"), str(qf)], env=dict(os.environ, GPEMU_DEVICES=devs))
              for devs in ("0", "0,0")]
     assert preds[0] == preds[1] and "pred" in preds[0]
+
+
+@pytest.mark.gpu
+def test_eight_pca_components_over_eight_device_slots_write_the_serial_snapshot(tmp_path):
+    """BASELINE configs[3]'s shape in small (t = 9 outputs -> 8 PCA components at variance fraction 1) through the CLI:
+    GPEMU_DEVICES=0,0,0,0,0,0,0,0 -- eight device slots, here all on the one GPU of the box, component c trained by the
+    host thread of slot c (multi.c, multivar_support.c:20-28) -- writes byte for byte the snapshot of the serial loop
+    (GPEMU_DEVICES=0); so does a two-slot run.  On an 8-GPU node the same command line puts one component on each GPU."""
+    cli = build.CLI_BIN
+    N, d, nt = 160, 4, 9
+    X, y = synth.design(N, d, 8088)
+    Y = synth.multi_outputs(X, y, nt) + 0.05 * synth.normal(12, N * nt).reshape(N, nt)
+    f = tmp_path / "multi9.dat"
+    with open(f, "w") as fh:
+        fh.write(f"{nt}\n{d}\n{N}\n")
+        np.savetxt(fh, X, fmt="%.17g")
+        np.savetxt(fh, Y, fmt="%.17g")
+    snaps = {}
+    for name, devs in (("serial", "0"), ("eight_slots", "0,0,0,0,0,0,0,0"), ("two_slots", "0,0")):
+        snap = tmp_path / f"snap_{name}"
+        env = dict(os.environ, GPEMU_SEED="77", GPEMU_RESTARTS="3", GPEMU_DEVICES=devs)
+        run([cli, "estimate_thetas", str(f), str(snap), "--regression_order=0", "--pca_variance=1.0"], env=env)
+        snaps[name] = snap.read_bytes()
+    toks = snaps["serial"].split()
+    assert int(toks[0]) == nt and int(toks[1]) == 8                     # nr = nt - 1 (multi_modelstruct.c:267-272)
+    assert snaps["serial"] == snaps["eight_slots"] == snaps["two_slots"]
 
 
 def _write_model_file(path, X, y):
