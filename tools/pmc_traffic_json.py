@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""profiles/*_pmc_hbm_traffic.txt (tools/rocpd_pmc.py output of one FETCH_SIZE and one WRITE_SIZE pass) -> the JSON
+bench.py reads `roofline.traffic` from.  rocprofv3 reports both counters in KB; on gfx950 FETCH_SIZE counts half the
+bytes of the reads these kernels issue (MI355X_MICROARCH.md; profiles/r01_pmc_fetch_calibration.txt), WRITE_SIZE is exact.
+usage: python tools/pmc_traffic_json.py profiles/r03_pmc_hbm_traffic.txt "<workload note>" > profiles/r03_pmc_hbm_traffic.json"""
+import json
+import re
+import sys
+
+KEYS = [("gemm_nt_kernel<128, 128", "gemm_nt_kernel_128x128_8waves_dma"), ("gemm_nt_kernel<64, 64, 4, 2, 2, 1", "gemm_nt_kernel_64x64_factor_ahead"),
+        ("gemm_nt_kernel<64, 64, 4, 2, 2, 0", "gemm_nt_kernel_64x64"), ("cov_stage_batch_kernel", "cov_stage_batch_kernel"),
+        ("leaf_solve_kernel", "leaf_solve_kernel"), ("leaf_factor_kernel", "leaf_factor_kernel")]
+out = {"workload": sys.argv[2] if len(sys.argv) > 2 else "", "units": "rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB; converted to bytes here",
+       "correction": "FETCH_SIZE x 2 on gfx950 (MI355X_MICROARCH.md; the 8-B/lane C-tile reads calibrate to the same half, "
+                     "profiles/r01_pmc_fetch_calibration.txt); WRITE_SIZE exact; Infinity-Cache hits are counted: fabric traffic, "
+                     "an upper bound on HBM traffic", "source": sys.argv[1]}
+cur = None
+for line in open(sys.argv[1]):
+    if not line.startswith(" "):
+        cur = line.strip()
+        continue
+    m = re.match(r"\s+(.*?)\s+calls\s+(\d+)\s+sum\s+(\d+)", line)
+    if not m:
+        continue
+    name, calls, total = m.group(1), int(m.group(2)), float(m.group(3)) * 1024.0
+    for pat, key in KEYS:
+        if pat in name:
+            e = out.setdefault(key, {})
+            e["launches"] = calls
+            if cur == "FETCH_SIZE":
+                e["fetch_bytes_raw"] = total
+                e["fetch_bytes_corrected"] = 2.0 * total
+            elif cur == "WRITE_SIZE":
+                e["write_bytes"] = total
+            break
+g = [v for k, v in out.items() if k.startswith("gemm_nt_kernel_")]
+if g:
+    out["gemm_nt_kernel"] = {"launches": sum(e["launches"] for e in g), "fetch_bytes_raw": sum(e.get("fetch_bytes_raw", 0) for e in g),
+                             "fetch_bytes_corrected": sum(e.get("fetch_bytes_corrected", 0) for e in g),
+                             "write_bytes": sum(e.get("write_bytes", 0) for e in g)}
+print(json.dumps(out, indent=1))
