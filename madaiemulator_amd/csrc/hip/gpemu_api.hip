@@ -138,6 +138,7 @@ static Sched read_environment()
 	sc.factor_ahead = geti("GPEMU_FACTOR_AHEAD", 1) != 0;
 	v = geti("GPEMU_NB_TOP", 0);
 	sc.nb_top = v >= LEAF ? (v / LEAF) * LEAF : 0;
+	sc.split_rhs_rows = geti("GPEMU_SPLIT_RHS_ROWS", 1) != 0;
 	return sc;
 }
 
@@ -471,6 +472,31 @@ static hipError_t trailing_update(gpemu_ctx *ctx, int c0, int k, int ncols, int 
 	g.fa_info = ctx->dInfo;
 	*fa_done = g.fa && gemm_factor_ahead_ok(g);
 	if (!*fa_done) g.fa = 0;
+	const int c_rows = ctx->Np - r0;                              // rows of the matrix proper under r0
+	if (ctx->sched.split_rhs_rows && gemm_uses_big_tiles(g) && c_rows % GEMM_BM == 0 && c_rows >= ncols && g.m > c_rows) {
+		// 128x128 tiles: the 64 right-hand-side rows between the matrix rows and the identity rows would shift every tile row
+		// behind them by half a tile and leave the last one half empty (2-5 % of the tile slots of a big update: 48 of 1224
+		// at the first update of a batch at N = 8192).  Three launches instead: the matrix rows (triangular part, full 128-row
+		// tiles), the right-hand-side rows on 64x64 tiles, the identity rows (gradient / inverse only).  Same k-ordered chain
+		// per element whatever the tile shape: the bits do not change.
+		GemmArgs a = g;
+		a.m = c_rows;
+		hipError_t e = gemm(ctx, a);
+		if (e != hipSuccess) return e;
+		GemmArgs b = g;
+		b.C = g.C + (long)c_rows * ld; b.A = g.A + (long)c_rows * ld;
+		b.m = ctx->Rp; b.tri = 0; b.force_cfg = 2;
+		e = gemm(ctx, b);
+		if (e != hipSuccess) return e;
+		const int i_rows = g.m - c_rows - ctx->Rp;
+		if (i_rows > 0) {
+			GemmArgs c = g;
+			c.C = g.C + (long)(c_rows + ctx->Rp) * ld; c.A = g.A + (long)(c_rows + ctx->Rp) * ld;
+			c.m = i_rows; c.tri = 0;
+			e = gemm(ctx, c);
+		}
+		return e;
+	}
 	return gemm(ctx, g);
 }
 
@@ -594,8 +620,10 @@ static int stage_matrices(gpemu_ctx *ctx, const CovParams *ps, int nb, int inv)
 	{
 		const double nlow = 0.5 * (double)Np * Np * nb;
 		ProfScope ps_(ctx, GPEMU_PROF_FILL, 0.0, 8.0 * nlow);
+		bool all_gram = ctx->dXg != nullptr;
+		for (int b = 0; b < nb; b++) all_gram = all_gram && ps[b].gram;
 		HIPCHK(ctx, launch_cov_stage_batch(ctx->stream, ctx->dT, Np, (long)ctx->T_stride, nb, ctx->dX, ctx->N, Np, ctx->d,
-		                                   ctx->dParams, FILL_LOWER | FILL_IDENT_PAD, ctx->dRrows, Rp, ctx->dXg));
+		                                   ctx->dParams, FILL_LOWER | FILL_IDENT_PAD, ctx->dRrows, Rp, ctx->dXg, all_gram, ctx->kind));
 	}
 	if (inv)
 		HIPCHK(ctx, launch_set_identity_rows(ctx->stream, ctx->dT + (size_t)(Np + Rp) * Np, Np, Np, nb, (long)ctx->T_stride));

@@ -80,6 +80,7 @@ struct Sched {
 	int factor_ahead = 1;        // GPEMU_FACTOR_AHEAD: the update's tile (0,0) factors the next diagonal block
 	int fill_gram = 1;           // GPEMU_FILL_GRAM: MFMA Gram form of the training fill
 	int nb_top = 0;              // GPEMU_NB_TOP: outer panel width; 0 = automatic (512 for one matrix, 2048 / 1024 for a batch)
+	int split_rhs_rows = 1;      // GPEMU_SPLIT_RHS_ROWS: big-tile updates take the 64 right-hand-side rows in a launch of their own
 };
 
 struct ProfState {
@@ -197,7 +198,8 @@ hipError_t launch_build_rrows(hipStream_t s, double *R, int Np, int Rp, const do
                               int N, int d, int order);
 hipError_t launch_set_identity_rows(hipStream_t s, double *T, long ld, int n, int nbatch = 1, long bstride = 0);
 hipError_t launch_cov_stage_batch(hipStream_t s, double *T, long ld, long bstride, int nb, const double *X, int N, int Np, int d,
-                                  const CovParams *pp_dev, int mode, const double *Rrows, int Rp, const double *Xg = nullptr);
+                                  const CovParams *pp_dev, int mode, const double *Rrows, int Rp, const double *Xg = nullptr,
+                                  bool all_gram = false, int kind = GPEMU_POWEREXP);
 hipError_t launch_transpose(hipStream_t s, double *dst, long ldd, const double *src, long lds, int n);
 hipError_t launch_predict_finish(hipStream_t s, const double *V, long ldv, int M, int Np, int nreg, int order, int d,
                                  const double *Xq, const double *betaQ, double kappa, double *mean, double *var,

@@ -7,6 +7,10 @@
 // (:578-593).  HBM-write-bound: 64x64 output tiles, every wave writes whole
 // 512-byte row segments; design rows are staged once per tile in LDS.
 #include "gpemu_internal.hpp"
+#include <cmath>
+#include <mutex>
+#include <set>
+#include <vector>
 
 namespace gpemu {
 
@@ -39,6 +43,28 @@ __device__ __forceinline__ double fast_exp_neg(double x, const double *tab /* LD
 	p = fma(p, r, 1.0);
 	const double v = tab[ki & (EXP_TAB - 1)] * p;
 	return __hiloint2double(__double2hiint(v) + ((ki >> 6) << 20), __double2loint(v));
+}
+
+// The Gram-form fill's exp: a 1024-entry table 2^(j/1024) (8 KB, filled once per device from the host, copied to LDS per
+// workgroup ALREADY MULTIPLIED by the amplitude) leaves |r| <= ln2/2048, so a cubic suffices (truncation r^4/24 < 6e-16):
+// 8 fp64 operations instead of 11 + the amplitude product.  No clamp: the Gram form runs only while the squared scaled
+// distance is <= 64 + slack (make_cov_params), so the argument is > -150 and every intermediate stays a normal number.
+constexpr int EXP_TAB_G = 1024;
+__device__ double g_exp2_tab[EXP_TAB_G];
+
+__device__ __forceinline__ double fast_exp_neg_g(double x, const double *tab_amp /* LDS: amp * 2^(j/1024) */)
+{
+	const double magic = 6755399441055744.0;                              // 1.5 * 2^52
+	const double t = fma(x, 92.332482616893656768 * 16.0, magic);         // 1024 / ln 2
+	const int ki = __double2loint(t);
+	const double kf = t - magic;
+	double r = fma(kf, -1.08304246932675596327e-02 * 0.0625, x);          // ln2_hi / 1024 (32 significant bits: exact product)
+	r = fma(kf, -2.98158582698529346878e-12 * 0.0625, r);                 // ln2_lo / 1024
+	double p = fma(r, 1.0 / 6.0, 0.5);
+	p = fma(p, r, 1.0);
+	p = fma(p, r, 1.0);
+	const double v = tab_amp[ki & (EXP_TAB_G - 1)] * p;
+	return __hiloint2double(__double2hiint(v) + ((ki >> 10) << 20), __double2loint(v));
 }
 
 // sqrt(a), a >= 0: hardware rsqrt estimate + two Heron corrections
@@ -161,27 +187,47 @@ __device__ __forceinline__ void cov_fill_tile(double *out, long ld, const double
 // ---------------------------------------------------------------------------
 typedef double d4g_t __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ double cov_from_dist2(const CovParams &p, double a, const double *tab)
+// value of an element from u2 = (c * distance / rho)^2 (Matern; c the literal root) or the pow-exp exponent, Gram form:
+// the scaled coordinates already carry c, so u = sqrt(u2) is the exponent of the Matern kernels and their polynomial is
+// 1 + u + c2 u^2 with c2 = (5/3) / c^2 (Matern 5/2: the reference's (5.0/3.0) s^2, emulator.c:470, in terms of u = c s)
+template <int KIND>
+__device__ __forceinline__ double cov_from_u2_gram(double a, const double *tab_amp)
 {
-	if (p.kind == GPEMU_POWEREXP) return fast_exp_neg(-a, tab) * p.amp;                   // emulator.c:133,141
-	const double sdist = fast_sqrt(a);                                                    // distance / rho
-	if (p.kind == GPEMU_MATERN32) {
-		const double root3 = 1.732050808;                                                 // emulator.c:359 (literal)
-		return p.amp * (1 + root3 * sdist) * fast_exp_neg(-root3 * sdist, tab);
-	}
-	const double root5 = 2.236067978;                                                     // emulator.c:452 (literal)
-	return p.amp * (1 + root5 * sdist + (5.0 / 3.0) * sdist * sdist) * fast_exp_neg(-root5 * sdist, tab);
+	if (KIND == GPEMU_POWEREXP) return fast_exp_neg_g(-a, tab_amp);                       // emulator.c:133,141 (amp in the table)
+	const double u = fast_sqrt(a);
+	const double e = fast_exp_neg_g(-u, tab_amp);
+	if (KIND == GPEMU_MATERN32) return e * (1.0 + u);                                     // emulator.c:359-376
+	const double c2 = (5.0 / 3.0) / (2.236067978 * 2.236067978);
+	return e * fma(u, fma(u, c2, 1.0), 1.0);                                              // emulator.c:452-470
 }
 
-__device__ __forceinline__ void cov_fill_tile_gram(double *out, long ld, const double *X, const double *Xg, int n, int d,
-                                                   const CovParams &p, int mode, int tr, int tc)
+// the Matern kernels' literal root (emulator.c:359, 452) rides in the coordinate scale: the MFMA then delivers
+// (c distance / rho)^2 and no element multiplies by c
+__device__ __forceinline__ double gram_root(int kind)
 {
-	__shared__ double tab[EXP_TAB];
-	__shared__ double wsc[GPEMU_MAX_PARAMS];
+	return kind == GPEMU_POWEREXP ? 1.0 : (kind == GPEMU_MATERN32 ? 1.732050808 : 2.236067978);
+}
+
+// per-workgroup tables of the Gram form (LDS): amp * 2^(j/1024) and the per-dimension coordinate scales (root included)
+__device__ __forceinline__ void gram_tables(const CovParams &p, int d, double *tab, double *wsc)
+{
 	const int tid = threadIdx.x;
-	if (tid < EXP_TAB) tab[tid] = exp2((double)tid * (1.0 / EXP_TAB));
-	if (tid < GPEMU_MAX_PARAMS) wsc[tid] = (tid < d) ? p.w[(p.kind == GPEMU_POWEREXP) ? tid : 0] : 0.0;
-	__syncthreads();
+	const double croot = gram_root(p.kind);
+	for (int e = tid; e < EXP_TAB_G; e += 256) tab[e] = g_exp2_tab[e] * p.amp;
+	if (tid < GPEMU_MAX_PARAMS) wsc[tid] = (tid < d) ? p.w[(p.kind == GPEMU_POWEREXP) ? tid : 0] * croot : 0.0;
+}
+
+// One tile.  The element loop has no data-dependent branch on its common path: the squared distances of the lane's 16
+// elements come out of the MFMA accumulators; only if some lane of the WAVE holds a nugget-rule candidate (a squared
+// distance below cand_g: coinciding design points, the diagonal) does the wave enter the exact re-computation; only
+// edge tiles (rows / columns beyond n) take the bounds-checked store.
+template <int KIND>
+__device__ __forceinline__ void cov_fill_tile_gram_k(double *out, long ld, const double *X, const double *Xg, int n, int d,
+                                                     const CovParams &p, int mode, int tr, int tc, const double *tab, const double *wsc)
+{
+	const int tid = threadIdx.x;
+	const double croot = gram_root(KIND);
+	const double cand_g = p.cand_g * croot * croot;
 	const int lane = tid & 63, wave = tid >> 6;
 	const int q = lane & 15, g = lane >> 4;
 	const int arow = tr * FT + 16 * wave + q;                 // A operand row of this lane
@@ -225,30 +271,74 @@ __device__ __forceinline__ void cov_fill_tile_gram(double *out, long ld, const d
 			acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ea, eb, acc[j], 0, 0, 0);
 		}
 	}
+	const int row0 = tr * FT + 16 * wave + g, col0 = tc * FT + q;
+	// nugget-rule candidates (rare): distance from differences, exact "same point" test on the raw coordinates
+	// (emulator.c:136-150 / :368-384 / :462-478)
+	unsigned same = 0;
+	bool cand = false;
 #pragma unroll
-	for (int r = 0; r < 4; r++) {
-		const int row = tr * FT + 16 * wave + g + 4 * r;
+	for (int r = 0; r < 4; r++)
 #pragma unroll
-		for (int j = 0; j < 4; j++) {
-			const int col = tc * FT + 16 * j + q;
-			double v;
-			if (row < n && col < n) {
-				double a = acc[j][r];
-				bool same = false;
-				if (a <= p.cand_g) {
-					// rare: (nearly) coinciding points -> distance from differences, exact nugget test on the raw coordinates
+		for (int j = 0; j < 4; j++) cand = cand || (acc[j][r] <= cand_g);
+	if (__any(cand)) {
+		// (one copy of the slow code: the element index is a run-time value here, the accumulators go through LDS-free
+		// register selects -- this runs for the diagonal tiles and for duplicated design points only)
+#pragma unroll 1
+		for (int e = 0; e < 16; e++) {
+			const int r = e >> 2, j = e & 3;
+			double ae = 0.0;
+#pragma unroll
+			for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+				for (int jj = 0; jj < 4; jj++) ae = (rr == r && jj == j) ? acc[jj][rr] : ae;
+			{
+				const int row = row0 + 4 * r, col = col0 + 16 * j;
+				if (ae <= cand_g && row < n && col < n) {
 					int cnt = 0;
-					a = 0.0;
+					double a = 0.0;
 					for (int k = 0; k < d; k++) {
 						const double D = X[(long)row * d + k] - X[(long)col * d + k];
 						const double t = D * wsc[k];
 						a = fma(t, t, a);
 						cnt += (fabs(D) < p.eps) ? 1 : 0;
 					}
-					same = cnt == d;
+#pragma unroll
+					for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+						for (int jj = 0; jj < 4; jj++) acc[jj][rr] = (rr == r && jj == j) ? a : acc[jj][rr];
+					if (cnt == d) same |= 1u << e;
 				}
-				v = cov_from_dist2(p, a, tab);
-				if (same) v += p.nug;
+			}
+		}
+	}
+	const bool full = (tr * FT + FT <= n) && (tc * FT + FT <= n);
+	if (full && !(mode & FILL_CLAMP)) {
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			double *orow = out + (long)(row0 + 4 * r) * ld + col0;
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				double v = cov_from_u2_gram<KIND>(acc[j][r], tab);
+				if (same & (1u << (4 * r + j))) v += p.nug;
+				orow[16 * j] = v;
+				// two elements at a time: a dependent fp64 operation can issue as soon as its predecessor has gone through the
+				// pipe (16 cycles either way), so interleaving more chains buys nothing and costs registers -- sixteen
+				// interleaved exp/sqrt chains need 256 VGPRs, two fit 80 and leave six waves per SIMD to cover the loads
+				if (j & 1) __builtin_amdgcn_sched_barrier(0);
+			}
+		}
+		return;
+	}
+#pragma unroll
+	for (int r = 0; r < 4; r++) {
+		const int row = row0 + 4 * r;
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			const int col = col0 + 16 * j;
+			double v;
+			if (row < n && col < n) {
+				v = cov_from_u2_gram<KIND>(acc[j][r], tab);
+				if (same & (1u << (4 * r + j))) v += p.nug;
 				if ((mode & FILL_CLAMP) && v < 1E-10) v = 0.0;                            // emulator.c:588-590
 			} else {
 				v = ((mode & FILL_IDENT_PAD) && row == col) ? 1.0 : 0.0;
@@ -272,6 +362,7 @@ __global__ __launch_bounds__(256) void cov_fill_kernel(double *out, long ld, con
 // hyper-parameters pp[blockIdx.y] (workgroups 0 .. ntiles-1) and a copy of the shared R rows [y H]^T below it
 // (workgroups ntiles ..: one FT x FT block each).  Per-matrix launches and copies cost ~12 us each on the host and the
 // stream: 1 ms per batch of 64, which is all a batch of small models (N < 1000) takes.
+template <int KIND>
 __global__ __launch_bounds__(256) void cov_stage_batch_kernel(double *T, long ld, long bstride, const double *X, int N, int Np,
                                                               int d, const CovParams *pp, int mode, const double *Rrows, int Rp,
                                                               const double *Xg)
@@ -287,8 +378,13 @@ __global__ __launch_bounds__(256) void cov_stage_batch_kernel(double *T, long ld
 		__syncthreads();
 		int tr, tc;
 		lower_tile(blockIdx.x, tr, tc);
-		if (ps.gram && Xg) cov_fill_tile_gram(out, ld, X, Xg, N, d, ps, mode, tr, tc);
-		else cov_fill_tile(out, ld, X, N, X, N, d, ps, mode, tr, tc);
+		if (ps.gram && Xg) {
+			__shared__ double tab[EXP_TAB_G];
+			__shared__ double wsc[GPEMU_MAX_PARAMS];
+			gram_tables(ps, d, tab, wsc);
+			__syncthreads();
+			cov_fill_tile_gram_k<KIND>(out, ld, X, Xg, N, d, ps, mode, tr, tc, tab, wsc);
+		} else cov_fill_tile(out, ld, X, N, X, N, d, ps, mode, tr, tc);
 		return;
 	}
 	const long rb = blockIdx.x - ntiles;              // block (rb / nt, rb % nt) of the Rp x Np rows
@@ -300,14 +396,94 @@ __global__ __launch_bounds__(256) void cov_stage_batch_kernel(double *T, long ld
 	}
 }
 
+// The same staging when EVERY matrix of the batch takes the Gram form (the usual case: make_cov_params): no difference-
+// form code and none of its 33 KB LDS tile in the kernel, so five workgroups fit a CU instead of three, and a workgroup
+// fills GRAM_TPW tiles with one set of tables.  Workgroups beyond the tiles copy the shared R rows as above.
+constexpr int GRAM_TPW = 4;
+template <int KIND>
+__global__ __launch_bounds__(256) void cov_stage_gram_kernel(double *T, long ld, long bstride, const double *X, int N, int Np,
+                                                             int d, const CovParams *pp, int mode, const double *Rrows, int Rp,
+                                                             const double *Xg)
+{
+	double *out = T + (long)blockIdx.y * bstride;
+	const long nt = Np / FT, ntiles = nt * (nt + 1) / 2, ngroups = (ntiles + GRAM_TPW - 1) / GRAM_TPW;
+	if ((long)blockIdx.x < ngroups) {
+		__shared__ CovParams ps;
+		__shared__ double tab[EXP_TAB_G];
+		__shared__ double wsc[GPEMU_MAX_PARAMS];
+		for (int e = threadIdx.x; e < (int)(sizeof(CovParams) / sizeof(double)); e += 256)
+			reinterpret_cast<double *>(&ps)[e] = reinterpret_cast<const double *>(pp + blockIdx.y)[e];
+		__syncthreads();
+		gram_tables(ps, d, tab, wsc);
+		__syncthreads();
+		// the groups walk the tile list from its END: the last tile rows (the longest ones) first
+		for (int i = 0; i < GRAM_TPW; i++) {
+			const long t = ntiles - 1 - ((long)blockIdx.x * GRAM_TPW + i);
+			if (t < 0) break;
+			int tr, tc;
+			lower_tile(t, tr, tc);
+			cov_fill_tile_gram_k<KIND>(out, ld, X, Xg, N, d, ps, mode, tr, tc, tab, wsc);
+		}
+		return;
+	}
+	const long rb = blockIdx.x - ngroups;             // block (rb / nt, rb % nt) of the Rp x Np rows
+	const int r0 = (int)(rb / nt) * FT, c0 = (int)(rb % nt) * FT;
+	double *dst = out + (long)Np * ld;
+	for (int e = threadIdx.x; e < FT * FT; e += 256) {
+		const int r = r0 + (e >> 6), c = c0 + (e & 63);
+		if (r < Rp) dst[(long)r * ld + c] = Rrows[(long)r * Np + c];
+	}
+}
+
+// the 2^(j/1024) table of the Gram-form exp: written once per device from host-computed values (exp2 of glibc)
+static hipError_t ensure_exp_table()
+{
+	static std::mutex mu;
+	static std::set<int> done;
+	int dev = 0;
+	hipError_t e = hipGetDevice(&dev);
+	if (e != hipSuccess) return e;
+	std::lock_guard<std::mutex> lock(mu);
+	if (done.count(dev)) return hipSuccess;
+	std::vector<double> h(EXP_TAB_G);
+	for (int j = 0; j < EXP_TAB_G; j++) h[j] = std::exp2((double)j / EXP_TAB_G);
+	e = hipMemcpyToSymbol(HIP_SYMBOL(g_exp2_tab), h.data(), sizeof(double) * EXP_TAB_G);
+	if (e == hipSuccess) done.insert(dev);
+	return e;
+}
+
+// (every matrix of a batch has the model's covariance function: `kind` selects the instantiation)
 hipError_t launch_cov_stage_batch(hipStream_t s, double *T, long ld, long bstride, int nb, const double *X, int N, int Np, int d,
-                                  const CovParams *pp_dev, int mode, const double *Rrows, int Rp, const double *Xg)
+                                  const CovParams *pp_dev, int mode, const double *Rrows, int Rp, const double *Xg, bool all_gram,
+                                  int kind)
 {
 	if (Np % FT || FT != 64) return hipErrorInvalidValue;
+	if (kind < GPEMU_POWEREXP || kind > GPEMU_MATERN52) return hipErrorInvalidValue;
+	if (Xg) {
+		const hipError_t e = ensure_exp_table();
+		if (e != hipSuccess) return e;
+	}
 	const long nt = Np / FT;
+	if (Xg && all_gram) {
+		const long ntiles = nt * (nt + 1) / 2;
+		const long blocks = (ntiles + GRAM_TPW - 1) / GRAM_TPW + ((Rp + FT - 1) / FT) * nt;
+		const dim3 grid((unsigned)blocks, nb);
+		if (kind == GPEMU_POWEREXP)
+			hipLaunchKernelGGL(cov_stage_gram_kernel<GPEMU_POWEREXP>, grid, dim3(256), 0, s, T, ld, bstride, X, N, Np, d, pp_dev, mode, Rrows, Rp, Xg);
+		else if (kind == GPEMU_MATERN32)
+			hipLaunchKernelGGL(cov_stage_gram_kernel<GPEMU_MATERN32>, grid, dim3(256), 0, s, T, ld, bstride, X, N, Np, d, pp_dev, mode, Rrows, Rp, Xg);
+		else
+			hipLaunchKernelGGL(cov_stage_gram_kernel<GPEMU_MATERN52>, grid, dim3(256), 0, s, T, ld, bstride, X, N, Np, d, pp_dev, mode, Rrows, Rp, Xg);
+		return hipGetLastError();
+	}
 	const long blocks = nt * (nt + 1) / 2 + ((Rp + FT - 1) / FT) * nt;
-	hipLaunchKernelGGL(cov_stage_batch_kernel, dim3((unsigned)blocks, nb), dim3(256), 0, s, T, ld, bstride, X, N, Np, d, pp_dev,
-	                   mode, Rrows, Rp, Xg);
+	const dim3 grid((unsigned)blocks, nb);
+	if (kind == GPEMU_POWEREXP)
+		hipLaunchKernelGGL(cov_stage_batch_kernel<GPEMU_POWEREXP>, grid, dim3(256), 0, s, T, ld, bstride, X, N, Np, d, pp_dev, mode, Rrows, Rp, Xg);
+	else if (kind == GPEMU_MATERN32)
+		hipLaunchKernelGGL(cov_stage_batch_kernel<GPEMU_MATERN32>, grid, dim3(256), 0, s, T, ld, bstride, X, N, Np, d, pp_dev, mode, Rrows, Rp, Xg);
+	else
+		hipLaunchKernelGGL(cov_stage_batch_kernel<GPEMU_MATERN52>, grid, dim3(256), 0, s, T, ld, bstride, X, N, Np, d, pp_dev, mode, Rrows, Rp, Xg);
 	return hipGetLastError();
 }
 

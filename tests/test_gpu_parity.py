@@ -1038,7 +1038,8 @@ def _schedule_run(monkeypatch, env):
 @pytest.mark.parametrize("env", [{"GPEMU_NO_GRAPH": "1"}, {"GPEMU_FACTOR_AHEAD": "0"}, {"GPEMU_FILL_GRAM": "0"},
                                  {"GPEMU_NB_TOP": "256"}, {"GPEMU_NB_TOP": "2048"}, {"GPEMU_GEMM_BIG_TILES": "1"},
                                  {"GPEMU_GEMM_BIG_TILES": "1000000"}, {"GPEMU_GEMM_TABLE": "0"}, {"GPEMU_GEMM_TABLE": "5"},
-                                 {"GPEMU_FACTOR_AHEAD": "0", "GPEMU_NO_GRAPH": "1", "GPEMU_GEMM_BIG_TILES": "1"}])
+                                 {"GPEMU_FACTOR_AHEAD": "0", "GPEMU_NO_GRAPH": "1", "GPEMU_GEMM_BIG_TILES": "1"},
+                                 {"GPEMU_SPLIT_RHS_ROWS": "0", "GPEMU_GEMM_BIG_TILES": "1"}, {"GPEMU_SPLIT_RHS_ROWS": "0"}])
 def test_schedule_switches_keep_parity(monkeypatch, env):
     """the measurement switches of INTEGRATION.md (factor-ahead, panel widths, tile shapes, tile order, no graph) change the
     schedule, not the result: every switch that only moves work between launches or workgroups leaves every bit alone
