@@ -427,7 +427,7 @@ def main():
         # (profiles/r01_pmc_fetch_calibration.txt), so the whole raw fetch is doubled; WRITE_SIZE is exact.  Infinity-
         # Cache hits are included in both, i.e. this is fabric traffic, an upper bound on HBM traffic.
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")
         if args.workload == "c3" and B == 16 and os.path.exists(tpath):      # measured for batches of 16
             tj = json.load(open(tpath)).get("gemm_nt_kernel_128x128_8waves_dma")
             if tj:
