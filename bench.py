@@ -416,7 +416,7 @@ def main():
     if rank == 0:
         # the dominant kernel = gemm_nt_kernel<128,128,4,4,2,0> (128x128 tiles, 8 waves, operands by LDS-DMA): every
         # update of a lock-step batch with >= 1024 such tiles and n >= 256 (contraction lengths 256 .. 2048), 95 % of its flops and
-        # 80 % of the GPU time of this bench (profiles/r02_rocprofv3_kernel_stats_*)
+        # 79 % of the GPU time of the likelihood region (profiles/r03_kernel_stats_*)
         ctx.prof_begin(abi.PROF_GEMM_BIG)
         ctx.loglik_batch_enqueue(np.array([theta(2000 + i) for i in range(B)]))     # one lock-step batch, as timed above
         p = ctx.prof_end()
@@ -462,13 +462,23 @@ def main():
                                      "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "ms_per_eval": p["ms"] / B,
                                      "evaluations_per_factorisation": B}
         roof_other["potrf_whole"]["frac"] = roof_other["potrf_whole"]["achieved"] / PEAK_FP64_MFMA_TFLOPS
+        # covariance fill: the staging launch of a lock-step batch (what the timed region runs: ONE launch fills the B lower
+        # triangles), and beside it the one-matrix launch of a sequential caller; algorithmic bytes = the lower tiles written
         ctx.prof_begin(abi.PROF_FILL)
-        for i in range(3):
-            ctx.loglik_enqueue(theta(4000 + i))
+        for i in range(2):
+            ctx.loglik_batch_enqueue(np.array([theta(4000 + B * i + k) for k in range(B)]))
         p = ctx.prof_end()
         gbs = p["bytes"] / (p["ms"] * 1e-3) / 1e9
+        ctx.prof_begin(abi.PROF_FILL)
+        for i in range(3):
+            ctx.loglik_enqueue(theta(4100 + i))
+        p1 = ctx.prof_end()
         roof_other["cov_fill"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                  "frac": gbs / PEAK_HBM_GBS, "avg_launch_us": p["ms"] * 1e3 / max(p["n"], 1)}
+                                  "frac": gbs / PEAK_HBM_GBS, "avg_launch_us": p["ms"] * 1e3 / max(p["n"], 1),
+                                  "us_per_matrix": p["ms"] * 1e3 / max(p["n"], 1) / B, "matrices_per_launch": B,
+                                  "one_matrix_per_launch_us": p1["ms"] * 1e3 / max(p1["n"], 1),
+                                  "one_matrix_per_launch_frac": p1["bytes"] / (p1["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                  "note": "plain-fill write bandwidth of the box 6.0-6.8 TB/s (profiles/r03_write_bandwidth.txt)"}
     if rank == 0:
         ctx.sync()
     note("likelihood rooflines done")
