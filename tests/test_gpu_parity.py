@@ -881,6 +881,73 @@ def test_exact_gradient_against_mpmath_golden_v3():
     c.close()
 
 
+def test_randomised_parity_sweep(gpu_ctx):
+    """40 random configurations (covariance function, N from 2 to 900, d up to 16, regression order, batch size, thetas,
+    query counts) through the whole path -- likelihood alone and in a lock-step batch, value+gradient batches through
+    the asynchronous entry, predictions -- against the oracle at the parity bar scaled by the conditioning the oracle
+    itself sees (scratch/fuzz_parity.py is the long form: 700 cases in round 1, none above 2e-9)."""
+    rng = np.random.default_rng(20261003)
+    worst = 0.0
+    for it in range(40):
+        kind = int(rng.integers(1, 4))
+        N = int(rng.choice([rng.integers(2, 70), rng.integers(60, 140), rng.integers(120, 500), rng.integers(400, 900), rng.integers(64, 66)]))
+        d = int(rng.choice([1, 2, 3, 5, 8, 13, 16]))
+        order = int(rng.integers(0, 4))
+        while 1 + order * d >= N:
+            order -= 1
+        nb = int(rng.choice([1, 2, 3, 5, 9, 16]))
+        X, y = synth.design(N, d, int(rng.integers(1, 1 << 30)))
+        nth = d + 2 if kind == 1 else 3
+
+        def draw():
+            th = synth.default_thetas(kind, d).copy()
+            th[2:] += rng.uniform(-0.7, 0.7, size=nth - 2)
+            if kind == 1:
+                th[0], th[1] = rng.uniform(-1, 1), rng.uniform(-6, -2)
+            else:
+                th[0], th[1] = rng.uniform(0.3, 2.0), 10 ** rng.uniform(-4, -1)
+            return th
+        ths = np.array([draw() for _ in range(nb)])
+        what = dict(it=it, kind=kind, N=N, d=d, order=order, nb=nb)
+        gpu_ctx.set_model(kind, order, X, y)
+        got = gpu_ctx.loglik_batch(ths)
+        one = gpu_ctx.loglik(ths[0])
+        e = O.Emulator(kind, order, X, y, ths[0])
+        r = y - e.H @ e.beta
+        ref = -(-0.5 * e.logdet - N / 2.0 * 1.83788 - 0.5 * (r @ e.cinverse @ r))
+        cond = np.linalg.cond(O.cov_matrix(kind, X, ths[0]))
+        tol = RTOL * max(1.0, cond * 2e-16 / 1e-9)
+        if got["status"][0] != 0:
+            assert e.status != 0 or cond > 1e12, what          # only a numerically singular matrix may fail
+            continue
+        errs = [abs(got["value"][0] - ref) / abs(ref), abs(one["value"] - ref) / abs(ref),
+                abs(one["sigma2"] - y @ e.cinverse @ r / N) / abs(one["sigma2"]),
+                float(np.max(np.abs(one["beta"] - e.beta)) / max(np.max(np.abs(e.beta)), 1e-6 * np.max(np.abs(y))))]
+        assert got["value"][0] == one["value"], what           # batch element = single evaluation, bit for bit
+        if kind == 1 and N <= 400:
+            thg = ths.copy()
+            thg[:, 0] = 0.0
+            gpu_ctx.loglik_grad_batch_enqueue(thg)
+            gpu_ctx.loglik_grad_batch_enqueue(thg[::-1].copy())
+            ga, gb = gpu_ctx.loglik_grad_batch_collect_back(1, nb), gpu_ctx.loglik_grad_batch_collect_back(0, nb)
+            assert np.array_equal(ga["grad"], gb["grad"][::-1]) and np.array_equal(ga["value"], gb["value"][::-1]), what
+            gref, st = O.grad_fn_multi(kind, order, X, y, thg[0][1:])
+            if st == 0 and ga["status"][0] == 0:
+                errs.append(relerr(ga["grad"][0], gref) / 10.0)            # gradient bar 1e-7
+        M = int(rng.choice([1, 7, 16, 17, 100, 300]))
+        Xq = synth.queries(M, d, int(rng.integers(1, 1 << 30)))
+        if M > 3:
+            Xq[0] = X[0]
+        gpu_ctx.predict_setup(ths[0])
+        m, v = gpu_ctx.predict(Xq)
+        mo, vo, _ = e.emulate(Xq)
+        kappa = abs(ths[0][0]) + 1 if kind != 1 else np.exp(ths[0][0]) + np.exp(ths[0][1])
+        errs += [float(np.max(np.abs(m - mo)) / max(1.0, np.max(np.abs(mo)))), float(np.max(np.abs(v - vo)) / kappa)]
+        assert np.all(np.isfinite(errs)) and max(errs) < tol, (what, errs, cond)
+        worst = max(worst, max(errs) / max(1.0, cond * 2e-16 / 1e-9))
+    assert worst < RTOL
+
+
 # ------------------------------------------------------------------ ragged and extreme shapes
 @pytest.mark.parametrize("N", [2, 3, 63, 64, 65, 127, 129, 513])
 @pytest.mark.parametrize("kind", [1, 3])
