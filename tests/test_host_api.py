@@ -104,6 +104,11 @@ def test_host_logic_without_gpu(tmp_path):
     z0 = (Yc[0] @ E) / np.sqrt(np.array(res["evals"][0]))
     assert np.allclose(res["z0"][0], z0, rtol=1e-9, atol=1e-12)
     assert s1.read_bytes() == s2.read_bytes() and len(s1.read_bytes()) > 100
+    # the harness's own PCA (synth.pca_zmatrix: what bench.py's configs[3] region decomposes with) is the product's:
+    # same number of kept components at the same variance fraction, same eigenvalues, same z up to the eigenvector signs
+    Zs, ls, Us, ybar = synth.pca_zmatrix(Y, 0.99)
+    assert Zs.shape[1] == nr and np.allclose(ls, res["evals"][0], rtol=1e-10) and np.allclose(ybar, Y.mean(axis=0))
+    assert np.allclose(np.abs(Zs[0]), np.abs(res["z0"][0]), rtol=1e-8, atol=1e-11)
     # a6: derivative_l_matern_three / _five (emulator.c:401-433, 497-532), the literal recurrence with the carried
     # rtemp -- host code, bit for bit the oracle's restatement
     n = len(X)
