@@ -116,7 +116,7 @@ static hipError_t gemm(gpemu_ctx *ctx, const GemmArgs &a_in)
 // ---------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------
-extern "C" const char *gpemu_version(void) { return "gpemu-mi355x 0.2 (gfx950, fp64 MFMA)"; }
+extern "C" const char *gpemu_version(void) { return "gpemu-mi355x 0.3 (gfx950, fp64 MFMA)"; }
 
 extern "C" int gpemu_device_count(void)
 {

@@ -1,6 +1,6 @@
 // kernels_linalg.hip -- fp64 dense kernels for gfx950 (MI355X):
 //   * gemm_nt_kernel : C = beta*C + alpha*A*B^T on v_mfma_f64_16x16x4_f64; 128x128 / 64x64 tiles, operand chunks by
-//                      LDS-DMA into a swizzled double buffer, two fragment sets (register-staged loop for the other shapes)
+//                      LDS-DMA into a swizzled double buffer, two fragment sets
 //   * leaf_kernel    : 64x64 diagonal-block Cholesky in LDS + forward substitution of the panel rows below
 //   * gram / finish  : Z Z^T Gram matrix of the solved right-hand sides and sum(log L_ii)
 //
