@@ -160,7 +160,10 @@ def train_through_cli(N, d, seed, dev, runs, exact=True):
         if exact:
             cmd.append("--exact_gradient")
         t0 = time.perf_counter()
-        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        try:
+            out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        except (subprocess.TimeoutExpired, OSError) as ex:
+            return {"error": repr(ex)[:300]}
         wall = time.perf_counter() - t0
         if out.returncode != 0:
             return {"error": out.stderr[-600:]}
@@ -605,7 +608,7 @@ def main():
     train = None
     if rank == 0 and ngpus == 1 and not args.no_train and not args.no_grad:
         train = train_through_cli(N, d, seed + 1, dev, args.train_runs, exact=not args.train_literal)
-        if train and vg:
+        if train and vg and "value_grad_evals_per_s" in train:
             train["fraction_of_raw_value_grad"] = train["value_grad_evals_per_s"] / vg["value"]
         note("region D (estimate_thetas through the C layer) done")
 
