@@ -1247,6 +1247,7 @@ extern "C" int gpemu_loglik_grad_batch_enqueue(gpemu_ctx *ctx, int nb, const dou
 	ctx->res_kind[slot] = 1;
 	ctx->res_th[slot] = th;
 	ctx->res_nthetas[slot] = nthetas;
+	ctx->res_mode[slot] = ctx->mode;
 	const int chunk = grad_chunk_size(ctx, nb);
 	for (int b0 = 0; b0 < nb; b0 += chunk) {
 		rc = grad_enqueue_chunk(ctx, b0, std::min(chunk, nb - b0), th.data(), nthetas);
@@ -1263,7 +1264,7 @@ static int grad_collect_slot(gpemu_ctx *ctx, int slot, int nb, double *neg_logli
                              int *info, int *status)
 {
 	const int nthetas = ctx->res_nthetas[slot], ng = nthetas - 1, d = ctx->d;
-	const bool exact = (ctx->mode & GPEMU_MODE_EXACT_GRAD) != 0;
+	const bool exact = (ctx->res_mode[slot] & GPEMU_MODE_EXACT_GRAD) != 0;       // as it was when the batch was enqueued
 	const int nlen = ctx->kind == GPEMU_POWEREXP ? d : 1;
 	const double *th_all = ctx->res_th[slot].data();
 	double *saveR = ctx->hRes;

@@ -128,6 +128,7 @@ struct gpemu_ctx {
 	int res_kind[RES_RING] = {0, 0, 0, 0};          // 0: likelihood batch, 1: value+gradient batch
 	std::vector<double> res_th[RES_RING];           // value+gradient batches: the thetas they were enqueued with (theta[0] = 0)
 	int res_nthetas[RES_RING] = {0, 0, 0, 0};
+	int res_mode[RES_RING] = {0, 0, 0, 0};          // the context's mode flags when the batch was enqueued
 	static constexpr int GRAD_NP_MAX = 2 * GPEMU_MAX_PARAMS + 2;   // reduced gradient sums per batch element
 	double *dGradSum = nullptr;  // batch_cap x GRAD_NP_MAX
 	double *hGradRing = nullptr; // pinned, RES_RING x batch_cap x GRAD_NP_MAX
