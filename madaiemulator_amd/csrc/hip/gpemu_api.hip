@@ -340,6 +340,7 @@ extern "C" int gpemu_set_model(gpemu_ctx *ctx, int kind, int order, int N, int d
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 	free_model(ctx);
+	ctx->res_seq = 0;                       // batches of the previous model can no longer be collected (their sizes are gone)
 	ctx->kind = kind; ctx->order = order; ctx->N = N; ctx->d = d; ctx->nreg = nreg; ctx->nrhs = nreg + 1;
 	ctx->Np = round_up(N, LEAF);
 	ctx->Rp = 64;
