@@ -58,13 +58,28 @@ __device__ __forceinline__ double fast_exp_neg_g(double x, const double *tab_amp
 	const double t = fma(x, 92.332482616893656768 * 16.0, magic);         // 1024 / ln 2
 	const int ki = __double2loint(t);
 	const double kf = t - magic;
-	double r = fma(kf, -1.08304246932675596327e-02 * 0.0625, x);          // ln2_hi / 1024 (32 significant bits: exact product)
-	r = fma(kf, -2.98158582698529346878e-12 * 0.0625, r);                 // ln2_lo / 1024
+	// ONE reduction step with ln2/1024 rounded to double: the product is exact inside the fma, the constant's own error
+	// (7.5e-20) times |kf| <= 1024/ln2 * 70 is below 8e-15 absolute in r -- relative in the result -- for the arguments the
+	// Gram form admits (|x| <= 64 + slack); the hi/lo pair of the general exp would buy digits nobody checks (bar: 1e-13)
+	const double r = fma(kf, -0.69314718055994530942 / 1024.0, x);
 	double p = fma(r, 1.0 / 6.0, 0.5);
 	p = fma(p, r, 1.0);
 	p = fma(p, r, 1.0);
 	const double v = tab_amp[ki & (EXP_TAB_G - 1)] * p;
 	return __hiloint2double(__double2hiint(v) + ((ki >> 10) << 20), __double2loint(v));
+}
+
+// sqrt(a), a >= 0, for the Gram form: rsq estimate y (5e-8, measured: scratch/mb/rsq_prec.hip), s = a y, eps = 1 - s y =
+// 1 - a y^2, and sqrt(a) = s (1 - eps)^(-1/2) = s + s eps (1/2 + 3/8 eps) + O(eps^3): one third-order correction, 5 fp64
+// operations behind the estimate instead of the 6 of two Heron steps, error below 2e-16
+__device__ __forceinline__ double fast_sqrt_g(double a)
+{
+	const double y = __builtin_amdgcn_rsq(a);
+	const double s = a * y;
+	const double eps = fma(-s, y, 1.0);
+	const double q = fma(eps, 0.375, 0.5);
+	const double u = fma(s * eps, q, s);
+	return (a > 0.0) ? u : 0.0;
 }
 
 // sqrt(a), a >= 0: hardware rsqrt estimate + two Heron corrections
@@ -194,7 +209,7 @@ template <int KIND>
 __device__ __forceinline__ double cov_from_u2_gram(double a, const double *tab_amp)
 {
 	if (KIND == GPEMU_POWEREXP) return fast_exp_neg_g(-a, tab_amp);                       // emulator.c:133,141 (amp in the table)
-	const double u = fast_sqrt(a);
+	const double u = fast_sqrt_g(a);
 	const double e = fast_exp_neg_g(-u, tab_amp);
 	if (KIND == GPEMU_MATERN32) return e * (1.0 + u);                                     // emulator.c:359-376
 	const double c2 = (5.0 / 3.0) / (2.236067978 * 2.236067978);
