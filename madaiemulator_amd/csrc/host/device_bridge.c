@@ -195,12 +195,13 @@ void gpemu_host_release(void *key)
 	pthread_mutex_lock(&g_lock);
 	struct entry **pp = &g_entries;
 	while (*pp) {
-		if ((*pp)->key == key) {
+		/* (key + 1: the second context evalFnMultiList keeps for a params) */
+		if ((*pp)->key == key || (*pp)->key == (const void *)((const char *)key + 1)) {
 			struct entry *e = *pp;
 			*pp = e->next;
 			gpemu_ctx_destroy(e->ctx);
 			free(e);
-			break;
+			continue;
 		}
 		pp = &(*pp)->next;
 	}
@@ -559,32 +560,52 @@ void evalFnMultiList(const gsl_matrix *theta_rows_less_amp, void *params_in, dou
 	struct estimate_thetas_params *params = (struct estimate_thetas_params *)params_in;
 	const int nthetas = params->options->nthetas;
 	const int npts = (int)theta_rows_less_amp->size1;
-	gpemu_ctx *ctx = bind_model(params, params->the_model, "evalFnMultiList");
-	int maxb = 16;                                         /* workspace: maxb * (N+64) * N * 8 bytes */
+	int maxb = 16;                                         /* workspace: maxb * (N+64) * N * 8 bytes per context */
 	const char *e = getenv("GPEMU_HOST_BATCH");
 	if (e && atoi(e) >= 1) maxb = atoi(e) > GPEMU_MAX_BATCH ? GPEMU_MAX_BATCH : atoi(e);
-	double *th = (double *)calloc((size_t)maxb * nthetas, sizeof(double));
+	/* the blocks of the list alternate between TWO device contexts, each block enqueued before the previous block of the
+	 * same context is collected: one block's panel chain and the host's finishing run beside the other's trailing updates
+	 * (what bench.py's headline region does with its two contexts).  A short list stays on one context. */
+	const int nblocks = (npts + maxb - 1) / maxb;
+	const int nctx = nblocks >= 2 ? 2 : 1;
+	gpemu_ctx *ctx[2];
+	ctx[0] = bind_model(params, params->the_model, "evalFnMultiList");
+	ctx[1] = nctx > 1 ? bind_model((const char *)params + 1, params->the_model, "evalFnMultiList") : NULL;
+	double *th = (double *)calloc((size_t)nctx * maxb * nthetas, sizeof(double));
 	int *status = (int *)malloc(sizeof(int) * (size_t)maxb);
-	for (int p0 = 0; p0 < npts; p0 += maxb) {
-		const int nb = npts - p0 < maxb ? npts - p0 : maxb;
-		for (int b = 0; b < nb; b++) {
-			th[(size_t)b * nthetas] = 0.0;                    /* theta_local[0] = 0 (maxmultimin.c:322) */
-			for (int i = 1; i < nthetas; i++)
-				th[(size_t)b * nthetas + i] = gsl_matrix_get(theta_rows_less_amp, p0 + b, i - 1);
-		}
-		int rc = gpemu_loglik_batch(ctx, nb, th, nthetas, answer + p0, NULL, NULL, NULL, NULL, NULL, status);
-		if (rc) die(ctx, rc, "evalFnMultiList");
-		for (int b = 0; b < nb; b++) {
-			if (status[b] == GPEMU_ERR_NOT_PD) {
-				note_not_pd("evalFnMulti", th + (size_t)b * nthetas, nthetas);
-				answer[p0 + b] = GSL_NAN;
-			} else if (status[b] == GPEMU_ERR_REGRESSION) {
-				fprintf(stderr, "# err: estimateBeta\n# trying to cholesky a non postive def matrix, sorry...\n");
-				exit(1);                                      /* regression.c:134-160 */
-			} else if (status[b]) {
-				die(ctx, status[b], "evalFnMultiList");
+	int pend_p0[2] = {-1, -1}, pend_nb[2] = {0, 0};
+	for (int blk = 0; blk <= nblocks + nctx - 1; blk++) {
+		const int k = blk % nctx;
+		if (pend_p0[k] >= 0) {                             /* collect this context's previous block */
+			const int p0 = pend_p0[k], nb = pend_nb[k];
+			const double *tk = th + (size_t)k * maxb * nthetas;
+			int rc = gpemu_loglik_batch_collect_back(ctx[k], 0, nb, answer + p0, NULL, NULL, NULL, NULL, NULL, status);
+			if (rc) die(ctx[k], rc, "evalFnMultiList");
+			for (int b = 0; b < nb; b++) {
+				if (status[b] == GPEMU_ERR_NOT_PD) {
+					note_not_pd("evalFnMulti", tk + (size_t)b * nthetas, nthetas);
+					answer[p0 + b] = GSL_NAN;
+				} else if (status[b] == GPEMU_ERR_REGRESSION) {
+					fprintf(stderr, "# err: estimateBeta\n# trying to cholesky a non postive def matrix, sorry...\n");
+					exit(1);                                      /* regression.c:134-160 */
+				} else if (status[b]) {
+					die(ctx[k], status[b], "evalFnMultiList");
+				}
 			}
+			pend_p0[k] = -1;
 		}
+		if (blk >= nblocks) continue;
+		const int p0 = blk * maxb, nb = npts - p0 < maxb ? npts - p0 : maxb;
+		double *tk = th + (size_t)k * maxb * nthetas;
+		for (int b = 0; b < nb; b++) {
+			tk[(size_t)b * nthetas] = 0.0;                    /* theta_local[0] = 0 (maxmultimin.c:322) */
+			for (int i = 1; i < nthetas; i++)
+				tk[(size_t)b * nthetas + i] = gsl_matrix_get(theta_rows_less_amp, p0 + b, i - 1);
+		}
+		int rc = gpemu_loglik_batch_enqueue(ctx[k], nb, tk, nthetas);
+		if (rc) die(ctx[k], rc, "evalFnMultiList");
+		__sync_fetch_and_add(&g_n_value, nb);
+		pend_p0[k] = p0; pend_nb[k] = nb;
 	}
 	free(status); free(th);
 }
