@@ -261,6 +261,9 @@ void gpemu_host_release(void *params_or_emulator); /* drop the device context ca
 /* lock-step group: n restart threads (one struct estimate_thetas_params each, same model) share one device context;
  * their concurrent evalFnMulti / gradFnMulti / evalFnGradMulti / estimateSigmaFull calls are gathered into device
  * batches.  A member's thread calls gpemu_host_group_leave(params) when it will make no further calls. */
+/* how estimate_thetas_threaded deals a run list to threads, groups and slots (pure arithmetic; optimizer.c) */
+int gpemu_host_plan_groups(int total_runs, int lockstep, int per_slot, int nslots, int *nthreads_out, int *lo, int *hi, int *slot,
+                           int cap);
 void *gpemu_host_group_create(struct estimate_thetas_params **members, int n);
 void gpemu_host_group_leave(void *params);
 void gpemu_host_group_destroy(void *group);

@@ -361,6 +361,32 @@ static void *worker_main(void *arg)
 	return NULL;
 }
 
+/* How a run list is dealt to host threads, lock-step groups and device slots (pure arithmetic, no device: the CPU
+ * tests check it through this entry).  total_runs BFGS runs; groups of up to `lockstep` threads; `per_slot` groups per
+ * device slot; nslots slots.  Returns the number of groups (<= cap) and fills *nthreads and, per group, its thread range
+ * [lo, hi) and its slot (group g works for slot g mod nslots).  Full groups first -- 20 runs on one slot are a group of
+ * 16 and a group of 4, not two of 10: a batch of 16 costs less per evaluation than two of 10 side by side -- unless that
+ * would leave a slot without work: then the threads are spread evenly over one group per slot. */
+int gpemu_host_plan_groups(int total_runs, int lockstep, int per_slot, int nslots, int *nthreads_out, int *lo, int *hi, int *slot,
+                           int cap)
+{
+	if (total_runs < 1 || lockstep < 2 || per_slot < 1 || nslots < 1) return 0;
+	long want = (long)lockstep * per_slot * nslots;
+	int nthreads = want > total_runs ? total_runs : (int)want;
+	const int full = (nthreads + lockstep - 1) / lockstep;
+	int ngroups = full;
+	if (ngroups < nslots) ngroups = nslots < nthreads ? nslots : nthreads;
+	if (ngroups > cap) return 0;
+	const int even = ngroups != full;            /* spread over more slots than full groups would use */
+	for (int g = 0; g < ngroups; g++) {
+		if (even) { lo[g] = (int)((long)g * nthreads / ngroups); hi[g] = (int)((long)(g + 1) * nthreads / ngroups); }
+		else { lo[g] = g * lockstep; hi[g] = lo[g] + lockstep < nthreads ? lo[g] + lockstep : nthreads; }
+		slot[g] = g % nslots;
+	}
+	if (nthreads_out) *nthreads_out = nthreads;
+	return ngroups;
+}
+
 /* libEmu/estimate_threaded.c:78-237.  The reference starts one pthread per CPU, each running jobs of 50 restarts
  * on its own copy of the model.  Here the restarts run as LOCK-STEP GROUPS (default): up to 16 host threads per group,
  * each an ordinary sequential BFGS run, share one device context; whenever all threads of a group have asked for a
@@ -400,13 +426,10 @@ void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 	const int pinned = gpemu_host_thread_device_get();
 	const int nslots = pinned >= 0 ? 1 : gpemu_host_device_slots();
 	int ngroups = 0;
+	int glo[512], ghi[512], gslot[512];
 	if (lockstep > 1) {
-		nthreads = lockstep * per_slot * nslots;
-		if (nthreads > total) nthreads = total;
-		/* full groups first: 20 runs on one slot are a group of 16 and a group of 4, not two of 10 (a batch of 16 costs
-		 * less per evaluation than two of 10 side by side) -- unless that leaves a slot without work */
-		ngroups = (nthreads + lockstep - 1) / lockstep;
-		if (ngroups < nslots) ngroups = nslots < nthreads ? nslots : nthreads;
+		ngroups = gpemu_host_plan_groups(total, lockstep, per_slot, nslots, &nthreads, glo, ghi, gslot, 512);
+		if (ngroups < 1) { fprintf(stderr, "estimate_thetas_threaded: cannot lay out the lock-step groups\n"); exit(EXIT_FAILURE); }
 	} else if (nthreads > total) nthreads = total;
 	unsigned long seed = g_seed;
 	env = getenv("GPEMU_SEED");
@@ -443,16 +466,12 @@ void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 	}
 	void **groups = NULL;
 	if (lockstep > 1) {
-		/* group g = threads [g nthreads / ngroups, (g+1) nthreads / ngroups) when the groups are even, else full groups of
-		 * `lockstep` and a remainder; group g works for device slot g mod nslots */
+		/* group g = threads [glo[g], ghi[g]) on device slot gslot[g] (gpemu_host_plan_groups) */
 		groups = (void **)calloc((size_t)ngroups, sizeof(void *));
 		struct estimate_thetas_params **members = (struct estimate_thetas_params **)malloc(sizeof(void *) * (size_t)nthreads);
-		const int even = ngroups != (nthreads + lockstep - 1) / lockstep;    /* spread over more slots than full groups would use */
 		for (int g = 0; g < ngroups; g++) {
-			int lo, hi;
-			if (even) { lo = (int)((long)g * nthreads / ngroups); hi = (int)((long)(g + 1) * nthreads / ngroups); }
-			else { lo = g * lockstep; hi = lo + lockstep < nthreads ? lo + lockstep : nthreads; }
-			const int dev = pinned >= 0 ? pinned : gpemu_host_slot_device(g % nslots);
+			const int lo = glo[g], hi = ghi[g];
+			const int dev = pinned >= 0 ? pinned : gpemu_host_slot_device(gslot[g]);
 			for (int i = lo; i < hi; i++) { members[i - lo] = &W[i].params; W[i].in_group = 1; W[i].device = dev; }
 			gpemu_host_thread_device(dev);            /* the group's context is created on the creator's device */
 			groups[g] = gpemu_host_group_create(members, hi - lo);

@@ -118,6 +118,36 @@ def test_host_logic_without_gpu(tmp_path):
     assert not np.allclose(dd[0], dd[0].T)               # path dependent: not even symmetric
 
 
+def test_run_list_layout_over_threads_groups_and_slots():
+    """how estimate_thetas_threaded deals a run list to host threads, lock-step groups and device slots
+    (optimizer.c gpemu_host_plan_groups: pure arithmetic, no GPU): full groups of 16 first, two groups per slot, every slot
+    gets work, thread ranges tile [0, nthreads) without gaps"""
+    import ctypes as C
+    build.build_all()
+    C.CDLL(build.HIP_LIB, mode=C.RTLD_GLOBAL)
+    lib = C.CDLL(build.HOST_LIB)
+    ia = C.c_int * 512
+
+    def plan(total, lockstep, per_slot, nslots):
+        lo, hi, slot, nt = ia(), ia(), ia(), C.c_int(0)
+        g = lib.gpemu_host_plan_groups(total, lockstep, per_slot, nslots, C.byref(nt), lo, hi, slot, 512)
+        groups = [(lo[i], hi[i], slot[i]) for i in range(g)]
+        assert groups[0][0] == 0 and groups[-1][1] == nt.value and all(a[1] == b[0] for a, b in zip(groups, groups[1:]))
+        assert all(0 < h - l <= lockstep for l, h, _ in groups)
+        return nt.value, groups
+    assert plan(50, 16, 2, 1) == (32, [(0, 16, 0), (16, 32, 0)])                 # the default search on one GPU
+    assert plan(20, 16, 2, 1) == (20, [(0, 16, 0), (16, 20, 0)])                 # full group first, then the remainder
+    assert plan(3, 16, 2, 1) == (3, [(0, 3, 0)])
+    nt, g = plan(50, 16, 2, 8)                                                   # 8 GPUs: every slot gets a group
+    assert nt == 50 and len(g) == 8 and sorted(s for _, _, s in g) == list(range(8)) and {h - l for l, h, _ in g} <= {6, 7}
+    nt, g = plan(400, 16, 2, 8)                                                  # enough runs: two full groups per GPU
+    assert nt == 256 and len(g) == 16 and [s for _, _, s in g] == list(range(8)) * 2 and all(h - l == 16 for l, h, _ in g)
+    nt, g = plan(300, 16, 2, 2)
+    assert nt == 64 and [s for _, _, s in g] == [0, 1, 0, 1]
+    assert plan(24, 5, 2, 1) == (10, [(0, 5, 0), (5, 10, 0)])
+    assert lib.gpemu_host_plan_groups(0, 16, 2, 1, None, ia(), ia(), ia(), 512) == 0
+
+
 def test_device_slots_from_the_environment():
     """GPEMU_DEVICES parsing and the slot -> device map of the host layer (device_bridge.c "devices"): host logic, no GPU"""
     import sys
