@@ -1063,6 +1063,23 @@ def test_chol_inverse_and_symm_apply_on_host_matrices(gpu_ctx, n):
     assert relerr(gpu_ctx.symm_apply(ref, V), V @ ref) < 1e-12
     gpu_ctx.symm_invalidate()
     assert relerr(gpu_ctx.symm_apply(ref, V), V @ ref) < 1e-12
+    # gpemu_symm_pin: the caller's promise that the buffer stays as it is -- the per-call checksum pass is skipped, so an
+    # in-place change made under the promise is (by contract) NOT seen; unpinning restores the check, a new pointer or
+    # gpemu_symm_invalidate always uploads
+    gpu_ctx.symm_pin(True)
+    before = gpu_ctx.symm_apply(ref, V)
+    ref[i, j] += 0.5
+    assert np.array_equal(gpu_ctx.symm_apply(ref, V), before)             # pinned: the device copy is trusted
+    gpu_ctx.symm_pin(False)
+    after = gpu_ctx.symm_apply(ref, V)                                     # checked again: the change is seen
+    assert relerr(after, V @ ref.T) < 1e-12 and not np.array_equal(after, before)
+    gpu_ctx.symm_pin(True)
+    other = ref.copy()
+    other[0, 0] += 1.0
+    assert relerr(gpu_ctx.symm_apply(other, V), V @ other.T) < 1e-12      # another buffer: uploaded whatever the pin says
+    gpu_ctx.symm_invalidate()                                              # (also drops the pin)
+    ref[i, j] -= 0.5
+    assert relerr(gpu_ctx.symm_apply(ref, V), V @ ref.T) < 1e-12
     bad = A.copy()
     bad[n // 2, n // 2] = -1.0
     _, _, info, rc = gpu_ctx.chol_inverse(bad)
