@@ -1015,6 +1015,7 @@ extern "C" int gpemu_predict_batch_dev(gpemu_ctx *ctx, int M, const double *xq_d
 		g.B = ctx->dLinvAug; g.ldb = Np;
 		g.m = mb; g.n = Np + Rp; g.k0 = 0; g.k1 = Np; g.alpha = 1.0; g.beta = 0;
 		g.kend_mode = 1; g.kend_off = 0;
+		g.big_tiles = ctx->sched.gemm_big_tiles;
 		// a few queries (emulate_point: ONE) give one or two tile rows with K = N each: split K over the chip
 		// (0.46 -> 0.1 ms per call at N=8192); the slices are summed in order by the finishing kernel
 		int nslice = 1;
@@ -1031,6 +1032,17 @@ extern "C" int gpemu_predict_batch_dev(gpemu_ctx *ctx, int M, const double *xq_d
 			ProfScope ps(ctx, GPEMU_PROF_GEMM, gemm_flops(g), 0.0);
 			HIPCHK(ctx, launch_skinny_nt(ctx->stream, ctx->dKq, Np, ctx->dLinvAug, Np, ctx->dV, Np + Rp, (long)mbp * (Np + Rp),
 			                             1, Np + Rp, Np, Np, nslice, klen));
+		} else if (nslice == 1 && ctx->sched.split_rhs_rows && gemm_uses_big_tiles(g)) {
+			// 128x128 tiles: the 64 columns of gamma and W^T behind the Np triangular ones would make a 65th tile column that is
+			// half empty at the full contraction length (1.5 % of the sweep's tile time): they go to a 64x64-tile launch of
+			// their own, as the right-hand-side rows of the factorisation's updates do.  Same chain per element, same bits.
+			GemmArgs a = g;
+			a.n = Np;
+			HIPCHK(ctx, gemm(ctx, a));
+			GemmArgs b = g;
+			b.C = ctx->dV + Np; b.B = ctx->dLinvAug + (size_t)Np * Np;
+			b.n = Rp; b.kend_mode = 0; b.force_cfg = 2;
+			HIPCHK(ctx, gemm(ctx, b));
 		} else
 		HIPCHK(ctx, gemm(ctx, g));
 		HIPCHK(ctx, launch_predict_finish(ctx->stream, ctx->dV, Np + Rp, mb, Np, ctx->nreg, ctx->order, d,
