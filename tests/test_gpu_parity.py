@@ -885,7 +885,7 @@ def test_randomised_parity_sweep(gpu_ctx):
     """40 random configurations (covariance function, N from 2 to 900, d up to 16, regression order, batch size, thetas,
     query counts) through the whole path -- likelihood alone and in a lock-step batch, value+gradient batches through
     the asynchronous entry, predictions -- against the oracle at the parity bar scaled by the conditioning the oracle
-    itself sees (scratch/fuzz_parity.py is the long form: 700 cases in round 1, none above 2e-9)."""
+    itself sees (tests/tools/fuzz_parity.py is the long form: 700 cases in round 1, none above 2e-9)."""
     rng = np.random.default_rng(20261003)
     worst = 0.0
     for it in range(40):

@@ -1,8 +1,8 @@
 """randomised parity sweep of the HIP path against the oracle: random (kind, N, d, order, batch, thetas), likelihood
 (single + batch), gradient (pow-exp) and predictions; prints the worst relative errors and every failure.
-usage: python scratch/fuzz_parity.py [cases] [seed]"""
+usage: python tests/tools/fuzz_parity.py [cases] [seed]"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from madaiemulator_amd import abi, synth
 from oracle import oracle as O
