@@ -184,6 +184,98 @@ def train_through_cli(N, d, seed, dev, runs, exact=True):
                 "workload": f"pow-exp, N={N}, d={d}, regression_order=0; lib/interactive_emulator estimate_thetas, GPEMU_RESTARTS={runs}"}
 
 
+def _io_stats(stderr_text):
+    import re
+    m = re.search(r"# interactive stats: points (\d+) batches (\d+) max_batch (\d+) parse_s ([0-9.]+) device_s ([0-9.]+) "
+                  r"format_s ([0-9.]+) wall_s ([0-9.]+) load_snapshot_s ([0-9.]+) alloc_multi_emulator_s ([0-9.]+) components (\d+)",
+                  stderr_text)
+    if not m:
+        return None
+    g = m.groups()
+    return {"points": int(g[0]), "batches": int(g[1]), "max_batch": int(g[2]), "parse_s": float(g[3]), "device_s": float(g[4]),
+            "format_s": float(g[5]), "loop_wall_s": float(g[6]), "load_snapshot_s": float(g[7]),
+            "alloc_multi_emulator_s": float(g[8]), "components": int(g[9])}
+
+
+def interactive_cli_region(kind, N, d, order, seed, dev, nq, check):
+    """region F: predictions/s a user of the drop-in sees -- `lib/interactive_emulator interactive_mode -q` as a child
+    process on a MODEL_SNAPSHOT_FILE of the workload's model (supplied thetas), nq distinct points on stdin: the
+    reference's text protocol (interactive_emulator.c:414-441: "%lf" in, "%.17f\\n" out) and its BINARY_INTERACTIVE_MODE
+    framing (--binary).  The rate is points / the loop's own wall clock (start-up -- snapshot parse, alloc_multi_emulator --
+    is reported beside it); the stage times name the bound.  `check(Xq)` -> (mean, var) of the same points through the
+    C-ABI for a sanity comparison of what the CLI printed."""
+    import subprocess
+    import tempfile
+    from madaiemulator_amd import build, synth
+    X, y = synth.design(N, d, seed)
+    th = synth.default_thetas(kind, d)
+    out = {"workload": f"N={N}, d={d}, cov_fn={kind}, regression_order={order}; lib/interactive_emulator interactive_mode -q, "
+                       f"{nq} distinct points on stdin (a file), results to a file"}
+    with tempfile.TemporaryDirectory(prefix="gpemu_bench_") as tmp:
+        snap, qtxt, qbin = os.path.join(tmp, "snap.txt"), os.path.join(tmp, "q.txt"), os.path.join(tmp, "q.bin")
+        open(snap, "w").write(synth.single_output_snapshot(X, y, kind, order, th))
+        Xq = synth.queries(nq, d, seed + 31)
+        np.savetxt(qtxt, Xq, fmt="%.17g")
+        Xq.tofile(qbin)
+        env = dict(os.environ, GPEMU_DEVICE=str(dev), GPEMU_IO_STATS="1")
+        lam = float(((y - y.mean()) ** 2).mean())
+        for name, qf, extra in (("text", qtxt, []), ("binary", qbin, ["--binary"])):
+            res = os.path.join(tmp, "out." + name)
+            t0 = time.perf_counter()
+            try:
+                p = subprocess.run([build.CLI_BIN, "interactive_mode", snap, "-q"] + extra, stdin=open(qf, "rb"),
+                                   stdout=open(res, "wb"), stderr=subprocess.PIPE, env=env, timeout=600)
+            except (subprocess.TimeoutExpired, OSError) as ex:
+                out[name] = {"error": repr(ex)[:300]}
+                continue
+            wall = time.perf_counter() - t0
+            st = _io_stats(p.stderr.decode(errors="replace"))
+            if p.returncode != 0 or not st or st["points"] != nq:
+                out[name] = {"error": p.stderr.decode(errors="replace")[-600:]}
+                continue
+            if name == "text":
+                vals = np.loadtxt(res, max_rows=2 * 4096).reshape(-1, 2)
+                nnum = sum(1 for _ in open(res))
+            else:
+                raw = np.fromfile(res, dtype=np.float64)
+                nnum, vals = raw.size, raw[:2 * 4096].reshape(-1, 2)
+            assert nnum == 2 * nq, (name, nnum)
+            m, v = check(Xq[:4096])                      # PCA-space mean/variance through the C-ABI -> observable space
+            # (the CLI's GP is trained on the PCA column z = (y - ybar) / sqrt(lam) and back-projected, multivar_support.c:126-151:
+            #  the mean is the direct model's, the variance is scaled by lam)
+            assert np.max(np.abs(vals[:, 0] - m)) < 1e-7 and np.max(np.abs(vals[:, 1] - lam * v)) < 1e-7, name
+            bound = max((("read+parse", st["parse_s"]), ("device", st["device_s"]), ("format+write", st["format_s"])), key=lambda t: t[1])
+            out[name] = {"value": nq / st["loop_wall_s"], "unit": "predictions/s", "loop_wall_s": st["loop_wall_s"],
+                         "process_wall_s": wall, "stage_busy_s": {"read_parse": st["parse_s"], "device": st["device_s"],
+                                                                  "format_write": st["format_s"]},
+                         "bound": bound[0], "batches": st["batches"], "max_batch": st["max_batch"],
+                         "ns_per_number_read": st["parse_s"] / (nq * d) * 1e9, "ns_per_number_written": st["format_s"] / (2 * nq) * 1e9,
+                         "startup": {"load_snapshot_s": st["load_snapshot_s"], "alloc_multi_emulator_s": st["alloc_multi_emulator_s"]}}
+        # the MCMC pattern: one point, wait for its answer, next point (interactive_emulator.c:440 flushes per point)
+        try:
+            import select
+            q = subprocess.Popen([build.CLI_BIN, "interactive_mode", snap, "-q"], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                 stderr=subprocess.DEVNULL, env=env)
+            lat = []
+            for i in range(60):
+                line = (" ".join(repr(float(vv)) for vv in Xq[i]) + "\n").encode()
+                t0 = time.perf_counter()
+                q.stdin.write(line)
+                q.stdin.flush()
+                got = b""
+                while got.count(b"\n") < 2:
+                    if not select.select([q.stdout], [], [], 120.0)[0]:
+                        raise TimeoutError("no answer to a lone point")
+                    got += os.read(q.stdout.fileno(), 4096)
+                lat.append(time.perf_counter() - t0)
+            q.stdin.close()
+            q.wait(timeout=60)
+            out["lone_point_round_trip_ms"] = {"first": lat[0] * 1e3, "median_of_the_rest": float(np.median(lat[10:])) * 1e3}
+        except (OSError, TimeoutError, subprocess.TimeoutExpired) as ex:
+            out["lone_point_round_trip_ms"] = {"error": repr(ex)[:200]}
+    return out
+
+
 def pca8_region(abi, shard, synth, dev, rank, world_size, steps, barrier, reduce_max):
     """region E (BASELINE configs[3]): N=4096, d=16, t=9 outputs -> 8 PCA components (multi_modelstruct.c:172-338), each an
     independent scalar GP on the shared design; component c -> rank c mod W.  Every component runs `steps` lock-step
@@ -265,6 +357,8 @@ def main():
     ap.add_argument("--train-literal", action="store_true",
                     help="that region with the reference's literal gradient formulas instead of the exact gradient")
     ap.add_argument("--no-pca8", action="store_true", help="skip the 8-PCA-component region (BASELINE configs[3])")
+    ap.add_argument("--no-interactive", action="store_true", help="skip the interactive_mode-through-the-CLI region")
+    ap.add_argument("--interactive-queries", type=int, default=None, help="points piped through the CLI (default: --queries / 1e6)")
     ap.add_argument("--pca8-steps", type=int, default=8, help="lock-step batches of evaluations per PCA component")
     args = ap.parse_args()
 
@@ -371,6 +465,27 @@ def main():
                   "mean_abs": float(np.max(np.abs(m - mo))), "var_abs": float(np.max(np.abs(v - vo)))}
             assert max(gn.values()) < 1e-8, gn
             gate[f"N{Ng}"] = gn
+            g.close()
+        # the value+gradient region (C) is gated like the others: evalFnGradMulti on region C's own pow-exp design at
+        # N=512 -- a lock-step batch through the asynchronous entry against the oracle's gradFnMulti / evalFnMulti
+        # (maxmultimin.c:416-550, 288-394 restated), 1e-8 of the largest gradient component
+        if not args.no_grad:
+            Xg, yg = synth.design(512, d, seed + 1)
+            g = abi.Context(dev)
+            g.set_model(1, 0, Xg, yg)
+            thb = np.array([synth.perturbed_thetas(1, d, seed + 1, i) for i in range(3)])
+            thb[:, 0] = 0.0
+            g.loglik_grad_batch_enqueue(thb)
+            gotg = g.loglik_grad_batch_collect_back(0, 3)
+            gerr, verr = 0.0, 0.0
+            for b in (0, 2):
+                gref, st = O.grad_fn_multi(1, 0, Xg, yg, thb[b][1:])
+                vref = O.eval_fn_multi(1, 0, Xg, yg, thb[b][1:])["value"]
+                assert st == 0 and gotg["status"][b] == 0
+                gerr = max(gerr, float(np.max(np.abs(gotg["grad"][b] - gref)) / np.max(np.abs(gref))))
+                verr = max(verr, abs(gotg["value"][b] - vref) / abs(vref))
+            gate["value_grad_N512"] = {"grad_rel_to_largest_component": gerr, "value_rel": verr}
+            assert gerr < 1e-8 and verr < 1e-8, gate["value_grad_N512"]
             g.close()
 
     def note(msg):
@@ -519,6 +634,26 @@ def main():
     if not args.no_predict:
         th0 = synth.default_thetas(kind, d)
         ctx.predict_setup(th0)
+        # what a sequential caller pays ONCE per emulator (alloc_emulator_struct, emulator_struct.c:13-37: fill, factorisation
+        # with the inverse rows, L^-1 by transposition, C^-1 [y|H], host finishing): host call to host return; and what ONE
+        # emulate_point (emulator_struct.c:124-143) costs it afterwards (the skinny split-K product)
+        t0 = time.perf_counter()
+        nsu = 5
+        for i in range(nsu):
+            ctx.predict_setup(synth.perturbed_thetas(kind, d, seed, 800000 + i))
+        t_setup = (time.perf_counter() - t0) / nsu
+        ctx.predict_setup(th0)
+        one_q = synth.queries(64, d, seed + 13)
+        ctx.predict(one_q[:1])
+        t0 = time.perf_counter()
+        for i in range(64):
+            ctx.predict(one_q[i:i + 1])
+        t_one = (time.perf_counter() - t0) / 64
+        setup_info = {"predict_setup_ms": t_setup * 1e3, "flops": 2.0 * N ** 3 / 3.0,
+                      "frac_of_mfma_peak": (2.0 * N ** 3 / 3.0) / t_setup / 1e12 / PEAK_FP64_MFMA_TFLOPS,
+                      "emulate_point_latency_ms": t_one * 1e3,
+                      "note": "gpemu_predict_setup = alloc_emulator_struct (one-off per emulator); emulate_point = one query "
+                              "through gpemu_predict_batch, host buffers, host call to host result"}
         nb = 20
         per = -(-nq // nb)
         # nb * per DISTINCT query points, resident in HBM before the clock starts; every batch reads its own block
@@ -544,9 +679,24 @@ def main():
         var = ctx.download(dv, (nb * per,))
         assert np.all(np.isfinite(mean)) and np.all(np.isfinite(var)) and len(np.unique(mean[:4096])) > 4000
         pred = {"value": ngpus * nb * per / tB, "unit": "predictions/s", "points_per_rank": nb * per,
-                "distinct_points": True, "batches": nb, "ms_per_batch": tB / nb * 1e3}
+                "distinct_points": True, "batches": nb, "ms_per_batch": tB / nb * 1e3, "sequential_caller": setup_info}
+        # the same sweep through the host-buffer entry (queries uploaded, results downloaded per call: PCIe inclusive)
+        t0 = time.perf_counter()
+        hb = min(4, nb)
+        for b in range(hb):
+            ctx.predict(Xq[b * per:(b + 1) * per])
+        pred["host_buffer_entry_predictions_per_s"] = hb * per / (time.perf_counter() - t0)
 
     note("region B (predictions) done")
+    # ---- region F: interactive_mode THROUGH THE DROP-IN (the metric's "predictions/sec ... inside interactive_mode")
+    inter = None
+    if rank == 0 and ngpus == 1 and pred is not None and not args.no_interactive:
+        inter = interactive_cli_region(kind, N, d, order, seed, dev, args.interactive_queries or nq, lambda Q: ctx.predict(Q))
+        for k in ("text", "binary"):
+            if isinstance(inter.get(k), dict) and "value" in inter[k]:
+                inter[k]["fraction_of_resident_rate"] = inter[k]["value"] / pred["value"]
+                inter[k]["fraction_of_host_buffer_rate"] = inter[k]["value"] / pred["host_buffer_entry_predictions_per_s"]
+        note("region F (interactive_mode through the CLI) done")
     # ---- region C: value + gradient (evalFnGradMulti, maxmultimin.c:615-618 -- what estimate_thetas calls per BFGS
     #      step), lock-step batches of Bg on a pow-exp model of the same N and d; as in region A the batches are dealt to
     #      `--streams` contexts through the asynchronous entry (gpemu_loglik_grad_batch_enqueue / _collect_back): the panel
@@ -667,6 +817,7 @@ def main():
                        "step": f"one lock-step batch of {B} independent likelihood evaluations"},
             "evaluations_per_step": B, "ms_per_evaluation": tA / (K * B) * 1e3,
             "predictions": pred,
+            "interactive_mode_cli": inter,
             "value_grad": vg,
             "estimate_thetas_c_layer": train,
             "pca8": pca8,

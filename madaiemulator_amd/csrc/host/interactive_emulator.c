@@ -12,20 +12,22 @@
  *
  * interactive_mode is a request/response pipe (flush after every answer, :440 of the reference).
  * Points that are ALREADY waiting on stdin are answered as one GPU batch; a lone point is
- * answered immediately, so MCMC drivers that wait for each answer never dead-lock.
+ * answered immediately, so MCMC drivers that wait for each answer never dead-lock.  Reading/parsing,
+ * the device and formatting/writing run as a three-stage pipeline (interactive_io.c); --binary selects
+ * the reference's BINARY_INTERACTIVE_MODE framing (raw doubles in and out) at run time.
  */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <getopt.h>
 #include <unistd.h>
-#include <poll.h>
 #include <assert.h>
 #include <math.h>
+#include <time.h>
 #include "libemu.h"
 
 struct cmdLineOpts {
-	int regOrder, covFn, quietFlag, pcaOutputFlag;
+	int regOrder, covFn, quietFlag, pcaOutputFlag, binaryFlag;
 	double pca_variance;
 	char *run_mode, *inputfile, *statefile;
 };
@@ -47,12 +49,20 @@ static const char useage[] =
 	"options which influence interactive_mode:\n"
 	"  (-q) --quiet: run without any extraneous output\n"
 	"  (-z) --pca_output: emulator output is left in the pca space\n"
+	"  --binary: points are read and results written as raw doubles (the reference's BINARY_INTERACTIVE_MODE build)\n"
 	"general options:\n"
 	"  -h -? print this dialogue\n"
 	"environment: GPEMU_DEVICE (HIP device), GPEMU_SEED, GPEMU_RESTARTS, GPEMU_JOBS, GPEMU_LOCKSTEP (restart threads\n"
 	"sharing one device context, default 16), GPEMU_NTHREADS (with GPEMU_LOCKSTEP=1: threads with a context each)\n";
 
 static int perr(const char *s) { fprintf(stderr, "%s\n", s); return EXIT_FAILURE; }
+
+static double wall_s(void)
+{
+	struct timespec t;
+	clock_gettime(CLOCK_MONOTONIC, &t);
+	return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
 
 /* interactive_emulator.c:212-251 of the reference: "nt d N", N*d design values, N*nt outputs */
 static int open_model_file(const char *name, gsl_matrix **xmodel_ptr, gsl_matrix **training_ptr)
@@ -88,57 +98,27 @@ static int estimate_thetas(struct cmdLineOpts *o)
 	return EXIT_SUCCESS;
 }
 
-/* ---- stdin reader that knows whether more input is already waiting ---- */
-struct reader { int fd; char buf[1 << 16]; size_t len, pos; int eof; };
+/* one batch of waiting points through every component's emulator (multivar_support.c:103-157, batched) */
+struct emu_call { multi_emulator *emu; int pca_space, d; };
 
-static int reader_fill(struct reader *r, int block)
+static void emu_points(void *user, int np, const double *pts, double *mean, double *var)
 {
-	if (r->eof) return 0;
-	if (r->pos > 0) { memmove(r->buf, r->buf + r->pos, r->len - r->pos); r->len -= r->pos; r->pos = 0; }
-	if (r->len >= sizeof r->buf - 1) return 0;
-	if (!block) {
-		struct pollfd p = {r->fd, POLLIN, 0};
-		if (poll(&p, 1, 0) <= 0) return 0;
-	}
-	ssize_t n = read(r->fd, r->buf + r->len, sizeof r->buf - 1 - r->len);
-	if (n <= 0) { r->eof = 1; return 0; }
-	r->len += (size_t)n;
-	return 1;
+	struct emu_call *c = (struct emu_call *)user;
+	gsl_matrix view;
+	view.size1 = (size_t)np; view.size2 = (size_t)c->d; view.tda = (size_t)c->d; view.data = (double *)pts; view.block = NULL; view.owner = 0;
+	emulate_points_multi(c->emu, &view, c->pca_space, mean, var);
 }
-
-/* next number; block=0 never waits for more input. returns 1 ok, 0 nothing available (yet / eof) */
-static int reader_next(struct reader *r, int block, double *out)
-{
-	for (;;) {
-		while (r->pos < r->len && strchr(" \t\r\n,;", r->buf[r->pos])) r->pos++;
-		size_t e = r->pos;
-		while (e < r->len && !strchr(" \t\r\n,;", r->buf[e])) e++;
-		if (e > r->pos && (e < r->len || r->eof)) {     /* a complete token */
-			char tmp[128];
-			size_t n = e - r->pos < sizeof tmp - 1 ? e - r->pos : sizeof tmp - 1;
-			memcpy(tmp, r->buf + r->pos, n); tmp[n] = 0;
-			r->pos = e;
-			char *endp;
-			*out = strtod(tmp, &endp);
-			if (endp == tmp) return 0;                  /* not a number: stop like fscanf would */
-			return 1;
-		}
-		if (!reader_fill(r, block)) {
-			if (r->eof && e > r->pos) continue;         /* flush the last token */
-			return 0;
-		}
-	}
-}
-
-#define BATCH_MAX 16384
 
 static int interactive_mode(struct cmdLineOpts *o)
 {
 	FILE *fp = fopen(o->statefile, "r");
 	if (!fp) return perr("Error opening file");
+	const double t_start = wall_s();
 	multi_modelstruct *model = load_multi_modelstruct(fp);
 	fclose(fp);
+	const double t_loaded = wall_s();
 	multi_emulator *emu = alloc_multi_emulator(model);
+	const double t_ready = wall_s();
 	const int d = model->nparams, nt = model->nt;
 	const int nout = o->pcaOutputFlag ? model->nr : nt;
 	FILE *out = stdout;
@@ -147,41 +127,22 @@ static int interactive_mode(struct cmdLineOpts *o)
 		for (int i = 0; i < d; i++) fprintf(out, "%s%d\n", "param_", i);
 		fprintf(out, "%d\n", 2 * nt);
 		for (int i = 0; i < nt; i++) fprintf(out, "%s_%d\n%s_%d\n", "mean", i, "variance", i);
-		fflush(out);
 	}
-	struct reader *rd = (struct reader *)calloc(1, sizeof *rd);
-	rd->fd = STDIN_FILENO;
-	double *pts = (double *)malloc(sizeof(double) * (size_t)BATCH_MAX * d);
-	double *mean = (double *)malloc(sizeof(double) * (size_t)BATCH_MAX * nt), *var = (double *)malloc(sizeof(double) * (size_t)BATCH_MAX * nt);
-	for (;;) {
-		int np = 0, partial = 0;
-		/* first point: wait for it; further points: only what is already there */
-		while (np < BATCH_MAX) {
-			int k;
-			for (k = 0; k < d; k++)
-				if (!reader_next(rd, np == 0 || k > 0, &pts[(size_t)np * d + k])) break;
-			if (k < d) { partial = (k > 0); break; }
-			np++;
-		}
-		(void)partial;
-		if (np == 0) break;
-		gsl_matrix view;
-		view.size1 = (size_t)np; view.size2 = (size_t)d; view.tda = (size_t)d; view.data = pts; view.block = NULL; view.owner = 0;
-		emulate_points_multi(emu, &view, o->pcaOutputFlag, mean, var);
-		for (int q = 0; q < np; q++) {
-			for (int i = 0; i < nout; i++) {
-				fprintf(out, "%.17f\n", mean[(size_t)q * nout + i]);
-				fprintf(out, "%.17f\n", var[(size_t)q * nout + i]);
-			}
-			/* the reference always prints nt pairs; in pca mode entries nr..nt-1 are whatever the vectors held */
-			for (int i = nout; i < nt; i++) fprintf(out, "%.17f\n%.17f\n", 0.0, 0.0);
-		}
-		fflush(out);
-		if (rd->eof && rd->pos >= rd->len) break;
-	}
-	free(pts); free(mean); free(var); free(rd);
+	fflush(out);
+	/* the loop itself (interactive_emulator.c:414-441 of the reference): points already waiting on stdin are answered as
+	 * one device batch, a lone point at once; reading/parsing, the device and formatting/writing overlap (interactive_io.c).
+	 * The reference always prints nt pairs; in pca mode entries nr..nt-1 are whatever its vectors held: zeros here. */
+	struct emu_call call = {emu, o->pcaOutputFlag, d};
+	struct gpemu_io_stats st;
+	const int rc = gpemu_host_interactive_loop(STDIN_FILENO, STDOUT_FILENO, d, nout, nt, o->binaryFlag, emu_points, &call, &st);
+	const char *want = getenv("GPEMU_IO_STATS");
+	if (want && atoi(want) > 0)
+		fprintf(stderr, "# interactive stats: points %ld batches %ld max_batch %d parse_s %.6f device_s %.6f format_s %.6f wall_s %.6f "
+		        "load_snapshot_s %.6f alloc_multi_emulator_s %.6f components %d\n",
+		        st.points, st.batches, st.max_batch, st.parse_seconds, st.compute_seconds, st.format_seconds, st.wall_seconds,
+		        t_loaded - t_start, t_ready - t_loaded, model->nr);
 	free_multi_emulator(emu);
-	return 0;
+	return rc == 0 ? 0 : EXIT_FAILURE;
 }
 
 static int print_thetas(struct cmdLineOpts *o)
@@ -227,6 +188,8 @@ static struct cmdLineOpts *global_opt_parse(int argc, char **argv)
 		{"quiet", no_argument, NULL, 'q'},                    {"help", no_argument, NULL, 'h'},
 		/* not in the reference: the corrected forms of gpemu.h (same as GPEMU_EXACT_GRAD=1 / GPEMU_MATERN_FIXED=1) */
 		{"exact_gradient", no_argument, NULL, 1001},          {"matern_fixed", no_argument, NULL, 1002},
+		/* the reference's compile-time BINARY_INTERACTIVE_MODE (interactive_emulator.c:119,392-396,418-438) as a run-time flag */
+		{"binary", no_argument, NULL, 1003},
 		{NULL, no_argument, NULL, 0}};
 	struct cmdLineOpts *o = (struct cmdLineOpts *)calloc(1, sizeof *o);
 	o->pca_variance = 0.99;
@@ -248,6 +211,7 @@ static struct cmdLineOpts *global_opt_parse(int argc, char **argv)
 		case 'q': o->quietFlag = 1; break;
 		case 1001: gpemu_host_set_modes(gpemu_host_modes() | 1 /* GPEMU_MODE_EXACT_GRAD */); break;
 		case 1002: gpemu_host_set_modes(gpemu_host_modes() | 2 /* GPEMU_MODE_MATERN_LOG */); break;
+		case 1003: o->binaryFlag = 1; break;
 		case 'h':
 		case '?': exit(perr(useage));
 		default: break;

@@ -268,6 +268,17 @@ void *gpemu_host_group_create(struct estimate_thetas_params **members, int n);
 void gpemu_host_group_leave(void *params);
 void gpemu_host_group_destroy(void *group);
 
+/* interactive_mode's request/response loop (src/interactive_emulator.c:398-440) as a reader -> device -> writer pipeline
+ * (interactive_io.c): reads points of nparams numbers from fd_in -- text, the reference's fscanf("%lf%*c") framing, or raw
+ * doubles (binary != 0: the reference's BINARY_INTERACTIVE_MODE framing, :418-432) --, hands the points that are already
+ * waiting to `fn` as one batch (mean / var: npoints x nout, row-major) and writes nprint (mean, variance) pairs per point
+ * ("%.17f\n" each, or raw doubles; pairs beyond nout are zeros) in input order, one flush per batch.  A lone point is
+ * answered at once.  Returns 0 at end of input, -2 when fd_out failed. */
+typedef void (*gpemu_points_fn)(void *user, int npoints, const double *points, double *mean, double *var);
+struct gpemu_io_stats { long points, batches; int max_batch; double parse_seconds, compute_seconds, format_seconds, wall_seconds; };
+int gpemu_host_interactive_loop(int fd_in, int fd_out, int nparams, int nout, int nprint, int binary, gpemu_points_fn fn,
+                                void *user, struct gpemu_io_stats *stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -99,3 +99,37 @@ def read_input_model_file(path):
     X = vals[3:3 + N * d].reshape(N, d)
     Y = vals[3 + N * d:3 + N * d + N * nt].reshape(N, nt)
     return X, Y
+
+
+def snapshot_text(X, Y, evals, evecs, Z, cov, order, thetas_list, ranges_list=None, scales=None):
+    """MODEL_SNAPSHOT_FILE text (multi_modelstruct.c:346-401, modelstruct.c:375-409) with the
+    reference's printf formats ("%.17lf " reals, "%d\\n" ints) for a model whose thetas are SUPPLIED rather than
+    trained: what bench.py's interactive_mode region and the tests feed `interactive_emulator interactive_mode`.
+    evecs: nt x nr, Z: N x nr, thetas_list: nr vectors; grad_ranges / sample_scales are part of the file, not of the
+    prediction (defaults: the reference's start ranges and unit scales)."""
+    N, d = X.shape
+    nt, nr = evecs.shape
+    Y = np.asarray(Y, float).reshape(N, nt)
+    row = lambda vals: "".join("%.17f " % v for v in vals) + "\n"
+    xrows = "".join(row(X[i]) for i in range(N))
+    parts = ["%d\n%d\n%d\n%d\n%d\n%d\n" % (nt, nr, d, N, cov, order), xrows, "".join(row(Y[i]) for i in range(N)),
+             row(evals), "".join(row(evecs[t]) for t in range(nt)), "".join(row(Z[i]) for i in range(N))]
+    nreg = 1 + order * d
+    if scales is None:
+        scales = np.ones(d)
+    for c in range(nr):
+        th = thetas_list[c]
+        parts.append("%d\n%d\n%d\n%d\n%d\n%d\n%d\n%.17f\n%d\n%d\n" % (len(th), d, N, 0, order, nreg, 0, 0.0, cov, 1))
+        rng_c = ranges_list[c] if ranges_list is not None else [(0.0001, 5.0), (-5.0, -2.0)] + [(-2.0, 1.2)] * (len(th) - 2)
+        parts.append("".join("%.17f %.17f\n" % (lo, hi) for lo, hi in rng_c))
+        parts += [xrows, row(Z[:, c]), row(th), row(scales)]
+    return "".join(parts)
+
+
+def single_output_snapshot(X, y, cov, order, thetas):
+    """snapshot of a scalar-output model (nt = nr = 1) at supplied thetas: the PCA of one column is its centring and
+    scaling (multi_modelstruct.c:172-338: eigenvalue = the column's variance, eigenvector 1)"""
+    ybar = y.mean()
+    lam = float(((y - ybar) ** 2).mean())
+    Z = ((y - ybar) / np.sqrt(lam)).reshape(-1, 1)
+    return snapshot_text(X, y.reshape(-1, 1), np.array([lam]), np.array([[1.0]]), Z, cov, order, [np.asarray(thetas, float)])

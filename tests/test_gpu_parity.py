@@ -881,13 +881,102 @@ def test_exact_gradient_against_mpmath_golden_v3():
     c.close()
 
 
+def _check_gradient_entries(c, ths, ref_grads, ref_values, tol=RTOL):
+    """every way the library returns a value+gradient -- gpemu_loglik_grad, an element of a lock-step batch, the
+    enqueue/collect halves -- against the reference vectors at `tol` of the largest component; the three entries agree
+    bit for bit among themselves"""
+    nb = len(ths)
+    one = c.loglik_grad(ths[0])
+    assert one["status"] == 0 and one["info"] == 0
+    bat = c.loglik_grad_batch(ths)
+    assert np.all(bat["status"] == 0)
+    c.loglik_grad_batch_enqueue(ths[::-1].copy())
+    c.loglik_grad_batch_enqueue(ths)
+    late, early = c.loglik_grad_batch_collect_back(0, nb), c.loglik_grad_batch_collect_back(1, nb)
+    assert np.array_equal(one["grad"], bat["grad"][0]) and one["value"] == bat["value"][0]
+    assert np.array_equal(late["grad"], bat["grad"]) and np.array_equal(early["grad"], bat["grad"][::-1])
+    assert np.array_equal(late["value"], bat["value"])
+    errs = []
+    for b in range(nb):
+        scale = np.max(np.abs(ref_grads[b]))
+        errs.append(float(np.max(np.abs(bat["grad"][b] - ref_grads[b])) / scale))
+        assert errs[-1] < tol, (b, bat["grad"][b], ref_grads[b])
+        assert bat["value"][b] == pytest.approx(ref_values[b], rel=RTOL)
+    return errs
+
+
+@pytest.mark.parametrize("N,d,order", [(4096, 8, 0), (4096, 16, 1), (8192, 8, 1)])
+def test_gradient_at_baseline_sizes_against_numpy_lapack(N, d, order):
+    """a12/a13 at BASELINE.json sizes (configs[1], configs[3]'s N and d, configs[2]'s N): gpemu_loglik_grad, a lock-step
+    batch and the enqueue/collect entry against tests/gradref.py -- a numpy restatement of the pow-exp matrix
+    (emulator.c:101-152, itself checked here on sampled elements against the oracle's covariance function), LAPACK's
+    inverse, and the O(N^2 d) form of gradFnMulti / getGradientCn / derivative_l_gauss (maxmultimin.c:416-550, 571-608;
+    emulator.c:173-209) -- nothing in that chain comes from the device.  Literal form (the default) and exact form, 1e-8
+    of the largest component.  At N = 8192 grad_part_kernel runs 8 256 tiles and grad_reduce_kernel's stride loop makes
+    33 passes; the live oracle comparisons stop at N = 900."""
+    import gradref
+    X, y = synth.design(N, d, 20261003 + 17 + d)
+    ths = np.array([synth.perturbed_thetas(1, d, 29, i) for i in range(2)])
+    ths[:, 0] = 0.0
+    ths[1, 2:] += 0.05 * np.arange(d) - 0.2                              # distinct length scales in the second element
+    rng = np.random.default_rng(N + d)
+    I, J = _sample_pairs(N, rng, n_random=2000)
+    Cn, _ = gradref.powexp_matrix(X, ths[0])
+    refc = np.array([O.cov(1, X[a], X[b], ths[0]) for a, b in zip(I, J)])
+    assert np.max(np.abs(Cn[I, J] - refc) / refc) < ELEM_RTOL             # the numpy matrix IS the oracle's matrix
+    del Cn
+    refs = [gradref.value_and_gradients(X, y, order, th) for th in ths]
+    c = abi.Context(0)
+    c.set_model(1, order, X, y)
+    lit = _check_gradient_entries(c, ths, [r["literal"] for r in refs], [r["value"] for r in refs])
+    one = c.loglik_grad(ths[1])
+    assert one["sigma2"] == pytest.approx(refs[1]["sigma2"], rel=RTOL) and relerr(one["beta"], refs[1]["beta"]) < RTOL
+    c.set_mode(abi.MODE_EXACT_GRAD)
+    exa = _check_gradient_entries(c, ths, [r["exact"] for r in refs], [r["value"] for r in refs])
+    print(f"gradient N={N} d={d}: literal {max(lit):.2e} exact {max(exa):.2e} of the largest component")
+    c.close()
+
+
+@pytest.mark.parametrize("size", [2048, 4096])
+def test_oracle_gradient_fixtures(size):
+    """ONE oracle gradFnMulti each (maxmultimin.c:416-550 restated: fill, unblocked Cholesky, explicit inverse, then nine
+    naive N^3 products with the literal derivative matrices) at N = 2048 and at BASELINE.json configs[1]'s size N = 4096
+    (d = 8, order 1), computed offline by tests/golden/make_golden_grad_n2048.py and cross-checked there against
+    tests/gradref.py: 528 / 2 080 lower tiles, so the device's second-stage reduction (grad_reduce_kernel: thread j takes
+    tiles j, j + 256, ...) makes three / nine passes against the oracle itself."""
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_grad_n%d.npz" % size))
+    kind, order, N, d, seed = (int(v) for v in f["meta"])
+    assert N == size
+    X, y = synth.design(N, d, seed)
+    th = f["thetas"]
+    c = abi.Context(0)
+    c.set_model(kind, order, X, y)
+    got = c.loglik_grad(th)
+    ref = f["grad"]
+    assert got["status"] == 0
+    assert np.max(np.abs(got["grad"] - ref)) < RTOL * np.max(np.abs(ref)), (got["grad"], ref)
+    assert got["value"] == pytest.approx(float(f["value"]), rel=RTOL)
+    assert got["sigma2"] == pytest.approx(float(f["sigma2"]), rel=RTOL) and relerr(got["beta"], f["beta"]) < RTOL
+    g2, rc = c.grad(th)
+    assert rc == 0 and np.array_equal(g2, got["grad"])
+    bat = c.loglik_grad_batch(np.array([th, th + 0.01, th]))
+    assert np.array_equal(bat["grad"][0], got["grad"]) and np.array_equal(bat["grad"][2], got["grad"])
+    c.set_mode(abi.MODE_EXACT_GRAD)
+    ex = c.loglik_grad(th)
+    assert np.max(np.abs(ex["grad"] - f["exact_numpy"])) < RTOL * np.max(np.abs(f["exact_numpy"]))
+    c.close()
+
+
 def test_randomised_parity_sweep(gpu_ctx):
     """40 random configurations (covariance function, N from 2 to 900, d up to 16, regression order, batch size, thetas,
     query counts) through the whole path -- likelihood alone and in a lock-step batch, value+gradient batches through
-    the asynchronous entry, predictions -- against the oracle at the parity bar scaled by the conditioning the oracle
-    itself sees (tests/tools/fuzz_parity.py is the long form: 700 cases in round 1, none above 2e-9)."""
+    the asynchronous entry (every pow-exp case), predictions -- against the oracle at the parity bar; the bar is scaled
+    only for cases whose conditioning the oracle itself cannot resolve (cond > 5e6: the oracle's own explicit inverse
+    then carries more than 1e-9), and the test counts how many cases ran at the unscaled 1e-8 bar and how many were
+    skipped as numerically singular (tests/tools/fuzz_parity.py is the long form: 700 cases in round 1, none above 2e-9)."""
     rng = np.random.default_rng(20261003)
     worst = 0.0
+    n_unscaled = n_scaled = n_singular = n_grad = 0
     for it in range(40):
         kind = int(rng.integers(1, 4))
         N = int(rng.choice([rng.integers(2, 70), rng.integers(60, 140), rng.integers(120, 500), rng.integers(400, 900), rng.integers(64, 66)]))
@@ -919,12 +1008,18 @@ def test_randomised_parity_sweep(gpu_ctx):
         tol = RTOL * max(1.0, cond * 2e-16 / 1e-9)
         if got["status"][0] != 0:
             assert e.status != 0 or cond > 1e12, what          # only a numerically singular matrix may fail
+            n_singular += 1
             continue
+        if tol > RTOL:
+            n_scaled += 1
+        else:
+            n_unscaled += 1
         errs = [abs(got["value"][0] - ref) / abs(ref), abs(one["value"] - ref) / abs(ref),
                 abs(one["sigma2"] - y @ e.cinverse @ r / N) / abs(one["sigma2"]),
                 float(np.max(np.abs(one["beta"] - e.beta)) / max(np.max(np.abs(e.beta)), 1e-6 * np.max(np.abs(y))))]
         assert got["value"][0] == one["value"], what           # batch element = single evaluation, bit for bit
-        if kind == 1 and N <= 400:
+        if kind == 1:
+            n_grad += 1
             thg = ths.copy()
             thg[:, 0] = 0.0
             gpu_ctx.loglik_grad_batch_enqueue(thg)
@@ -933,7 +1028,7 @@ def test_randomised_parity_sweep(gpu_ctx):
             assert np.array_equal(ga["grad"], gb["grad"][::-1]) and np.array_equal(ga["value"], gb["value"][::-1]), what
             gref, st = O.grad_fn_multi(kind, order, X, y, thg[0][1:])
             if st == 0 and ga["status"][0] == 0:
-                errs.append(relerr(ga["grad"][0], gref) / 10.0)            # gradient bar 1e-7
+                errs.append(relerr(ga["grad"][0], gref))
         M = int(rng.choice([1, 7, 16, 17, 100, 300]))
         Xq = synth.queries(M, d, int(rng.integers(1, 1 << 30)))
         if M > 3:
@@ -946,6 +1041,10 @@ def test_randomised_parity_sweep(gpu_ctx):
         assert np.all(np.isfinite(errs)) and max(errs) < tol, (what, errs, cond)
         worst = max(worst, max(errs) / max(1.0, cond * 2e-16 / 1e-9))
     assert worst < RTOL
+    print(f"sweep: {n_unscaled} cases at the unscaled 1e-8 bar, {n_scaled} at a conditioning-scaled bar, {n_singular} singular, "
+          f"{n_grad} with the gradient")
+    # fixed seed: the counts are facts of this seed's 40 cases (cond(C) up to 4.4e5) -- all of them at the plain bar, none singular, 13 pow-exp ones with the gradient
+    assert (n_unscaled, n_scaled, n_singular, n_grad) == (40, 0, 0, 13)
 
 
 # ------------------------------------------------------------------ ragged and extreme shapes
@@ -1273,7 +1372,8 @@ def test_error_codes(gpu_ctx):
 # ------------------------------------------------------------------ BASELINE.json configs[3] and configs[4]
 def test_config4_eight_pca_components_n4096_d16(gpu_ctx):
     """N=4096, d=16, multi-output model whose PCA keeps 8 components: the 8 scalar GPs share the design (one
-    upload) and differ in the training vector; each likelihood is checked against one LAPACK factorisation."""
+    upload) and differ in the training vector; each likelihood is checked against one LAPACK factorisation of a
+    numpy-built matrix (tests/gradref.py; the device's own fill is not part of the reference chain)."""
     from madaiemulator_amd import shard
     N, d, nt = 4096, 16, 9
     X, y = synth.design(N, d, 20261003 + 3)
@@ -1284,7 +1384,8 @@ def test_config4_eight_pca_components_n4096_d16(gpu_ctx):
     Z = Yc @ U[:, order] / np.sqrt(w[order])                 # multi_modelstruct.c:295-316
     th = synth.default_thetas(1, d)
     gpu_ctx.set_model(1, 1, X, Z[:, 0])
-    Cm = gpu_ctx.cov_matrix(th)
+    import gradref
+    Cm, _ = gradref.powexp_matrix(X, th)                     # numpy restatement of emulator.c:101-152: no device link in the chain
     cf = sl.cho_factor(Cm, lower=True, overwrite_a=True, check_finite=False)
     logdet = 2.0 * np.log(np.diag(cf[0])).sum()
     H = O.hmatrix(1, X)
@@ -1309,15 +1410,16 @@ def test_config4_eight_pca_components_n4096_d16(gpu_ctx):
 
 
 def test_config5_n16384_powexp(gpu_ctx):
-    """N=16384, d=8, pow-exp (one rank's share of the hyper-parameter search): an evaluation against LAPACK,
-    theta sensitivity, and the y-scaling property."""
+    """N=16384, d=8, pow-exp (one rank's share of the hyper-parameter search): an evaluation against LAPACK on a
+    numpy-built matrix (tests/gradref.py), theta sensitivity, and the y-scaling property."""
     N, d = 16384, 8
     X, y = synth.design(N, d, 20261003 + 4)
     gpu_ctx.set_model(1, 0, X, y)
     th = synth.default_thetas(1, d)
     a = gpu_ctx.loglik(th)
     assert a["status"] == 0 and a["info"] == 0 and np.isfinite(a["value"])
-    Cm = gpu_ctx.cov_matrix(th)
+    import gradref
+    Cm, _ = gradref.powexp_matrix(X, th)                     # numpy restatement of emulator.c:101-152, not the device's fill
     cf = sl.cho_factor(Cm, lower=True, overwrite_a=True, check_finite=False)
     logdet = 2.0 * np.log(np.diag(cf[0])).sum()
     H = np.ones((N, 1))
@@ -1327,7 +1429,8 @@ def test_config5_n16384_powexp(gpu_ctx):
     quad = r @ sl.cho_solve(cf, r, check_finite=False)
     del Cm, cf
     assert a["logdet"] == pytest.approx(logdet, rel=RTOL)
-    assert a["beta"][0] == pytest.approx(beta[0], rel=1e-7, abs=1e-9)
+    print("config5 beta", a["beta"][0], beta[0], abs(a["beta"][0] - beta[0]) / abs(beta[0]))
+    assert a["beta"][0] == pytest.approx(beta[0], rel=RTOL)
     assert a["quad"] == pytest.approx(quad, rel=RTOL)
     assert a["value"] == pytest.approx(-(-0.5 * logdet - N / 2.0 * 1.83788 - 0.5 * quad), rel=RTOL)
     b = gpu_ctx.loglik(synth.perturbed_thetas(1, d, 3, 0))

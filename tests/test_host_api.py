@@ -195,6 +195,61 @@ def test_multi_output_golden_g6_through_the_c_layer(driver, tmp_path):
 
 
 @pytest.mark.gpu
+def test_interactive_mode_stream_lone_points_and_binary_framing(tmp_path):
+    """interactive_mode through the CLI on the G6 snapshot (nt = 6 outputs, 3 PCA components, d = 3): (a) 40 000 points
+    piped at once (several pipelined device batches) give, for the fixture's 16 queries, the golden observable-space
+    values, and every point's answer equals -- byte for byte -- the answer it gets when it is sent alone and waited for
+    (interactive_emulator.c:414-441: one point per loop turn); (b) --binary (the reference's BINARY_INTERACTIVE_MODE
+    framing, :392-396,418-438) returns the doubles whose "%.17f" rendering is the text output; (c) -z keeps nt pairs."""
+    import select
+    import time
+    g2 = np.load(os.path.join(ROOT, "tests", "golden", "golden_v2.npz"))
+    cli = build.CLI_BIN
+    Q = np.vstack([g2["g6_q"], synth.queries(40000 - len(g2["g6_q"]), 3, 77)])
+    text = "\n".join(" ".join(repr(float(v)) for v in row) for row in Q) + "\n"
+    p = subprocess.run([cli, "interactive_mode", G6SNAP, "-q"], input=text.encode(), capture_output=True, timeout=300,
+                       env=dict(os.environ, GPEMU_IO_STATS="1"))
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = p.stdout.decode().split("\n")[:-1]
+    assert len(lines) == 40000 * 6 * 2
+    vals = np.array(lines, float).reshape(40000, 6, 2)
+    n16 = len(g2["g6_q"])
+    assert np.max(np.abs(vals[:n16, :, 0] - g2["g6_mean"])) < 1e-8 * max(1.0, np.abs(g2["g6_mean"]).max())
+    assert np.max(np.abs(vals[:n16, :, 1] - g2["g6_var"])) < 1e-8 * max(1e-3, np.abs(g2["g6_var"]).max())
+    stats = [l for l in p.stderr.decode().splitlines() if l.startswith("# interactive stats")]
+    assert stats and int(stats[0].split()[4]) == 40000 and int(stats[0].split()[8]) == 16384      # points, max_batch
+    # one point at a time, each answer waited for
+    q = subprocess.Popen([cli, "interactive_mode", G6SNAP, "-q"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    for i in list(range(5)) + [20000, 39999]:
+        q.stdin.write((" ".join(repr(float(v)) for v in Q[i]) + "\n").encode())
+        q.stdin.flush()
+        got, t0 = b"", time.time()
+        while got.count(b"\n") < 12:
+            assert time.time() - t0 < 120, "no answer to a lone point"
+            if select.select([q.stdout], [], [], 1.0)[0]:
+                got += os.read(q.stdout.fileno(), 65536)
+        alone = np.array(got.decode().split(), float).reshape(6, 2)
+        # (a lone point takes the skinny split-K product, a point inside a batch the unsplit GEMM: equal to rounding)
+        assert np.max(np.abs(alone[:, 0] - vals[i, :, 0])) < 1e-11 * max(1.0, np.abs(vals[i, :, 0]).max())
+        assert np.max(np.abs(alone[:, 1] - vals[i, :, 1])) < 1e-11 * max(1e-3, np.abs(vals[i, :, 1]).max())
+    q.stdin.close()
+    assert q.wait(timeout=60) == 0
+    # binary framing: the same batches, raw doubles in and out
+    b = subprocess.run([cli, "interactive_mode", G6SNAP, "-q", "--binary"], input=Q.tobytes(), capture_output=True, timeout=300)
+    assert b.returncode == 0, b.stderr[-2000:]
+    raw = np.frombuffer(b.stdout, dtype=np.float64)
+    assert raw.size == 40000 * 6 * 2
+    assert ["%.17f" % v for v in raw] == lines
+    # header (not quiet) and pca-space output: nt pairs per point, those beyond nr are zeros
+    z = subprocess.run([cli, "interactive_mode", G6SNAP, "-z"], input=text[:200].rsplit("\n", 1)[0].encode() + b"\n",
+                       capture_output=True, timeout=120)
+    zl = z.stdout.decode().split()
+    npts = len(text[:200].rsplit("\n", 1)[0].split()) // 3
+    zz = np.array(zl, float).reshape(npts, 6, 2)                   # -z implies -q (the reference's fall-through)
+    assert np.all(zz[:, 3:, :] == 0.0) and np.all(zz[:, :3, 1] > 0.0)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("path,d,order", [(UNI, 1, 0), (UNI, 1, 1), (TWOD, 2, 1)])
 def test_evalfn_gradfn_like_gsl_multimin_would_call_them(driver, path, d, order):
     X, Y = synth.read_input_model_file(path)
