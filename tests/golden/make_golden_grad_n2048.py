@@ -7,12 +7,13 @@ N = 2048, d = 8, pow-exp, regression order 1, the seeded design of madaiemulator
   * orc_evalFnMulti  (maxmultimin.c:288-394) at the same theta -- the value evalFnGradMulti (:615-618) pairs it with.
 N = 2048 has 32 x 33 / 2 = 528 lower 64x64 tiles: the device's second-stage reduction (grad_reduce_kernel, thread j takes
 tiles j, j + 256, ...) makes more than one pass, which no live oracle comparison (N <= 900) reaches.  The oracle pass is
-nine naive N^3 products (about ten minutes of one core), too long for a test: run here once, ~20 numbers committed.
+nine naive N^3 products (55 s of one core at N = 2048, measured here) next to other tests' CPU work: run here once,
+~20 numbers committed.
 
 Independent cross-check before writing: tests/gradref.py (numpy/LAPACK, O(N^2 d) form of the same formulas) at 1e-9.
 
 The same script with the argument 4096 writes golden_grad_n4096.npz: the oracle's gradFnMulti at BASELINE.json configs[1]'s
-size (N = 4096, d = 8; 2 080 tiles, nine passes of the stride loop; about ten minutes of one core).
+size (N = 4096, d = 8; 2 080 tiles, nine passes of the stride loop; 768 s of one core, measured here).
 
 Run from the repo root:  python tests/golden/make_golden_grad_n2048.py [4096]
 """
