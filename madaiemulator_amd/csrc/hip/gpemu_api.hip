@@ -135,6 +135,7 @@ static Sched read_environment()
 	v = geti("GPEMU_GEMM_TABLE", 8);
 	sc.gemm_table = v >= 0 && v <= 64 ? v : 8;
 	sc.fill_gram = geti("GPEMU_FILL_GRAM", 1) != 0;
+	sc.kvec_gram = geti("GPEMU_KVEC_GRAM", 1) != 0;
 	sc.factor_ahead = geti("GPEMU_FACTOR_AHEAD", 1) != 0;
 	v = geti("GPEMU_NB_TOP", 0);
 	sc.nb_top = v >= LEAF ? (v / LEAF) * LEAF : 0;
@@ -198,7 +199,7 @@ static void free_graphs(gpemu_ctx *ctx)
 static void free_model(gpemu_ctx *ctx)
 {
 	free_graphs(ctx);
-	double **ptrs[] = {&ctx->dX, &ctx->dXg, &ctx->dY, &ctx->dRrows, &ctx->dT, &ctx->dGramPart, &ctx->dLinvAug, &ctx->dBetaQ,
+	double **ptrs[] = {&ctx->dX, &ctx->dXg, &ctx->dMid, &ctx->dY, &ctx->dRrows, &ctx->dT, &ctx->dGramPart, &ctx->dLinvAug, &ctx->dBetaQ,
 	                   &ctx->dKq, &ctx->dV, &ctx->dXq, &ctx->dMean, &ctx->dVar, &ctx->dS, &ctx->dGradPart, &ctx->dAlpha};
 	for (auto p : ptrs) { if (*p) hipFree(*p); *p = nullptr; }
 	ctx->T_rows = 0; ctx->pred_ready = false; ctx->cinv_ready = false; ctx->pred_batch = 0; ctx->stage_cap = 0;
@@ -369,7 +370,14 @@ extern "C" int gpemu_set_model(gpemu_ctx *ctx, int kind, int order, int N, int d
 			for (int i = 0; i < N; i++)
 				for (int k = 0; k < d; k++) xg[(size_t)i * d + k] = X[(size_t)i * d + k] - 0.5 * (hi[k] + lo[k]);
 			HIPCHK(ctx, hipMalloc(&ctx->dXg, (size_t)N * d * sizeof(double)));
-			HIPCHK(ctx, hipMemcpy(ctx->dXg, xg.data(), (size_t)N * d * sizeof(double), hipMemcpyHostToDevice));
+			// (on the context's own stream, never the legacy stream: a plain hipMemcpy fails with "operation would make the
+			// legacy stream depend on a capturing blocking stream" while ANOTHER host thread records its launch graph)
+			HIPCHK(ctx, hipMemcpyAsync(ctx->dXg, xg.data(), (size_t)N * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+			std::vector<double> mid(d);
+			for (int k = 0; k < d; k++) mid[k] = 0.5 * (hi[k] + lo[k]);
+			HIPCHK(ctx, hipMalloc(&ctx->dMid, (size_t)d * sizeof(double)));
+			HIPCHK(ctx, hipMemcpyAsync(ctx->dMid, mid.data(), (size_t)d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+			HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 		}
 	}
 	HIPCHK(ctx, launch_build_rrows(ctx->stream, ctx->dRrows, ctx->Np, ctx->Rp, ctx->dX, ctx->dY, N, d, order));
@@ -873,6 +881,15 @@ extern "C" int gpemu_cov_matrix(gpemu_ctx *ctx, const double *thetas, int ntheta
 	return GPEMU_OK;
 }
 
+// k-vectors of M query rows (device) into out (Mp x Np, zero padded): Gram form when the hyper-parameters admit it
+// (make_cov_params: p.gram) and the context was not told otherwise, else the difference form
+static hipError_t fill_kvectors(gpemu_ctx *ctx, double *out, const double *xq_dev, int M, int Mp, const CovParams &p)
+{
+	if (p.gram && ctx->sched.kvec_gram && ctx->dXg && ctx->dMid)
+		return launch_cov_kvec_gram(ctx->stream, out, ctx->Np, xq_dev, M, Mp, ctx->dX, ctx->dXg, ctx->dMid, ctx->N, ctx->Np, ctx->d, p);
+	return launch_cov_fill(ctx->stream, out, ctx->Np, xq_dev, M, Mp, ctx->dX, ctx->N, ctx->Np, ctx->d, p, FILL_CLAMP);
+}
+
 extern "C" int gpemu_kvectors(gpemu_ctx *ctx, const double *thetas, int nthetas, int M, const double *xq, double *k_out)
 {
 	if (!ctx || !xq || !k_out || M < 1) return GPEMU_ERR_ARG;
@@ -886,7 +903,7 @@ extern "C" int gpemu_kvectors(gpemu_ctx *ctx, const double *thetas, int nthetas,
 	HIPCHK(ctx, hipMalloc(&buf, (size_t)Mp * Np * sizeof(double)));
 	hipError_t e = hipMalloc(&dq, (size_t)M * ctx->d * sizeof(double));
 	if (e == hipSuccess) e = hipMemcpyAsync(dq, xq, (size_t)M * ctx->d * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-	if (e == hipSuccess) e = launch_cov_fill(ctx->stream, buf, Np, dq, M, Mp, ctx->dX, N, Np, ctx->d, p, FILL_CLAMP);
+	if (e == hipSuccess) e = fill_kvectors(ctx, buf, dq, M, Mp, p);
 	if (e == hipSuccess)
 		e = hipMemcpy2DAsync(k_out, (size_t)N * sizeof(double), buf, (size_t)Np * sizeof(double),
 		                     (size_t)N * sizeof(double), M, hipMemcpyDeviceToHost, ctx->stream);
@@ -1005,8 +1022,7 @@ extern "C" int gpemu_predict_batch_dev(gpemu_ctx *ctx, int M, const double *xq_d
 		const int mbp = round_up(mb, 64);
 		{
 			ProfScope ps(ctx, GPEMU_PROF_FILL, 0.0, 8.0 * (double)mbp * Np);
-			HIPCHK(ctx, launch_cov_fill(ctx->stream, ctx->dKq, Np, xq_dev + (size_t)q0 * d, mb, mbp, ctx->dX, N, Np, d,
-			                            ctx->pred_cov, FILL_CLAMP));
+			HIPCHK(ctx, fill_kvectors(ctx, ctx->dKq, xq_dev + (size_t)q0 * d, mb, mbp, ctx->pred_cov));
 		}
 		GemmArgs g;
 		memset(&g, 0, sizeof g);
@@ -1226,9 +1242,17 @@ static int grad_enqueue_chunk(gpemu_ctx *ctx, int b0, int nbc, const double *th_
 		HIPCHK(ctx, launch_beta_solve(ctx->stream, ctx->dRes + (size_t)b0 * ctx->res_len, (long)ctx->res_len, Rp, ctx->nreg, nbc,
 		                              ctx->dAlpha, (long)gslot, ctx->Np));
 	int nparts = 0;
+	// literal form: exp(-1/2 e^{-2 theta_k} D_k^2) of every pair of design points -- when the largest such argument of the
+	// chunk stays small (|D_k| <= the coordinate's range) the kernel's exp needs no lower clamp
+	bool noclamp = !exact && (int)ctx->xhalf.size() == d;
+	for (int i = 0; noclamp && i < nbc; i++)
+		for (int k = 0; k < nlen; k++) {
+			const double range = 2.0 * ctx->xhalf[k];
+			if (!(0.5 * exp(-2.0 * th_all[(size_t)(b0 + i) * nthetas + 2 + k]) * range * range < 600.0)) noclamp = false;
+		}
 	HIPCHK(ctx, launch_grad_partials(ctx->stream, ctx->dS, (long)dim, Rp, (long)sstride, nbc, ctx->dX, N, d, ctx->dAlpha, ctx->Np,
 	                                 (long)gslot, ctx->dGradPart, (long)need, &nparts, exact ? ctx->kind : 0, ctx->nreg,
-	                                 ctx->dParams + b0));
+	                                 ctx->dParams + b0, noclamp));
 	HIPCHK(ctx, launch_grad_reduce(ctx->stream, ctx->dGradPart, (long)need, nparts, np, nbc,
 	                               ctx->dGradSum + (size_t)b0 * gpemu_ctx::GRAD_NP_MAX, (long)gpemu_ctx::GRAD_NP_MAX));
 	return GPEMU_OK;
@@ -1417,7 +1441,10 @@ extern "C" int gpemu_trace_dump(gpemu_ctx *ctx, const char *path)
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 	std::vector<unsigned long long> h(8 * (size_t)ctx->trace_next);
-	if (!h.empty()) HIPCHK(ctx, hipMemcpy(h.data(), ctx->dTrace, h.size() * 8, hipMemcpyDeviceToHost));
+	if (!h.empty()) {
+		HIPCHK(ctx, hipMemcpyAsync(h.data(), ctx->dTrace, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+		HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	}
 	FILE *f = fopen(path, "w");
 	if (!f) { ctx->err = "cannot open trace file"; return GPEMU_ERR_ARG; }
 	for (int i = 0; i < ctx->trace_next; i++) {
@@ -1653,16 +1680,17 @@ extern "C" int gpemu_test_gemm_nt(gpemu_ctx *ctx, int m, int n, int k, double al
 	HIPCHK(ctx, hipMalloc(&da, (size_t)m * k * 8));
 	HIPCHK(ctx, hipMalloc(&db, (size_t)n * k * 8));
 	HIPCHK(ctx, hipMalloc(&dc, (size_t)m * n * 8));
-	HIPCHK(ctx, hipMemcpy(da, a, (size_t)m * k * 8, hipMemcpyHostToDevice));
-	HIPCHK(ctx, hipMemcpy(db, b, (size_t)n * k * 8, hipMemcpyHostToDevice));
-	HIPCHK(ctx, hipMemcpy(dc, c, (size_t)m * n * 8, hipMemcpyHostToDevice));
+	HIPCHK(ctx, hipMemcpyAsync(da, a, (size_t)m * k * 8, hipMemcpyHostToDevice, ctx->stream));
+	HIPCHK(ctx, hipMemcpyAsync(db, b, (size_t)n * k * 8, hipMemcpyHostToDevice, ctx->stream));
+	HIPCHK(ctx, hipMemcpyAsync(dc, c, (size_t)m * n * 8, hipMemcpyHostToDevice, ctx->stream));
 	GemmArgs g;
 	memset(&g, 0, sizeof g);
 	g.C = dc; g.A = da; g.B = db; g.ldc = n; g.lda = k; g.ldb = k; g.m = m; g.n = n; g.k0 = 0; g.k1 = k;
 	g.alpha = alpha; g.beta = beta;
 	HIPCHK(ctx, gemm(ctx, g));
 	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-	HIPCHK(ctx, hipMemcpy(c, dc, (size_t)m * n * 8, hipMemcpyDeviceToHost));
+	HIPCHK(ctx, hipMemcpyAsync(c, dc, (size_t)m * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 	hipFree(da); hipFree(db); hipFree(dc);
 	return GPEMU_OK;
 }
@@ -1767,13 +1795,14 @@ extern "C" int gpemu_test_potrf(gpemu_ctx *ctx, int n, double *a, int *info)
 	hipError_t e = hipMalloc(&tmp.dT, h.size() * 8);
 	if (e == hipSuccess) e = hipMalloc(&tmp.dInfo, sizeof(int));
 	int big = INFO_NONE;
-	if (e == hipSuccess) e = hipMemcpy(tmp.dT, h.data(), h.size() * 8, hipMemcpyHostToDevice);
-	if (e == hipSuccess) e = hipMemcpy(tmp.dInfo, &big, sizeof(int), hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpyAsync(tmp.dT, h.data(), h.size() * 8, hipMemcpyHostToDevice, tmp.stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(tmp.dInfo, &big, sizeof(int), hipMemcpyHostToDevice, tmp.stream);
 	if (e == hipSuccess) e = potrf_rec(&tmp, 0, Np, 0);
 	if (e == hipSuccess) e = hipStreamSynchronize(tmp.stream);
-	if (e == hipSuccess) e = hipMemcpy(h.data(), tmp.dT, h.size() * 8, hipMemcpyDeviceToHost);
+	if (e == hipSuccess) e = hipMemcpyAsync(h.data(), tmp.dT, h.size() * 8, hipMemcpyDeviceToHost, tmp.stream);
 	int inf = 0;
-	if (e == hipSuccess) e = hipMemcpy(&inf, tmp.dInfo, sizeof(int), hipMemcpyDeviceToHost);
+	if (e == hipSuccess) e = hipMemcpyAsync(&inf, tmp.dInfo, sizeof(int), hipMemcpyDeviceToHost, tmp.stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(tmp.stream);
 	if (tmp.dT) hipFree(tmp.dT);
 	if (tmp.dInfo) hipFree(tmp.dInfo);
 	tmp.dT = nullptr; tmp.dInfo = nullptr; tmp.stream = nullptr;

@@ -79,6 +79,7 @@ struct Sched {
 	int gemm_table = 8;          // GPEMU_GEMM_TABLE (0 .. 64)
 	int factor_ahead = 1;        // GPEMU_FACTOR_AHEAD: the update's tile (0,0) factors the next diagonal block
 	int fill_gram = 1;           // GPEMU_FILL_GRAM: MFMA Gram form of the training fill
+	int kvec_gram = 1;           // GPEMU_KVEC_GRAM: MFMA Gram form of the prediction sweep's k-vectors
 	int nb_top = 0;              // GPEMU_NB_TOP: outer panel width; 0 = automatic (512 for one matrix, 2048 / 1024 for a batch)
 	int split_rhs_rows = 1;      // GPEMU_SPLIT_RHS_ROWS: big-tile updates take the 64 right-hand-side rows in a launch of their own
 };
@@ -104,6 +105,7 @@ struct gpemu_ctx {
 	int Np = 0, Rp = 0;
 	double *dX = nullptr;        // N x d
 	double *dXg = nullptr;       // N x d, centred per dimension (x - mid_k): operands of the Gram-form fill
+	double *dMid = nullptr;      // d: the centres mid_k (the Gram-form k-vectors centre their query rows with them)
 	std::vector<double> xhalf;   // d: half range of each design coordinate
 	double *dY = nullptr;        // N
 	double *dRrows = nullptr;    // Rp x Np : row 0 = y, rows 1..nreg = H columns, zero padded
@@ -195,6 +197,9 @@ namespace gpemu {
 hipError_t launch_cov_fill(hipStream_t s, double *out, long ld, const double *Xr, int nr, int nr_pad,
                            const double *Xc, int nc, int nc_pad, int d, const CovParams &p, int mode);
 constexpr int FILL_LOWER = 1, FILL_CLAMP = 2, FILL_IDENT_PAD = 4;
+// k-vectors of M query rows (padded to Mp) against the design in Gram form (p.gram set; Xg = centred design, mid = its centre)
+hipError_t launch_cov_kvec_gram(hipStream_t s, double *out, long ld, const double *Xq, int M, int Mp, const double *X, const double *Xg,
+                                const double *mid, int N, int Np, int d, const CovParams &p);
 hipError_t launch_build_rrows(hipStream_t s, double *R, int Np, int Rp, const double *X, const double *y,
                               int N, int d, int order);
 hipError_t launch_set_identity_rows(hipStream_t s, double *T, long ld, int n, int nbatch = 1, long bstride = 0);
@@ -207,7 +212,7 @@ hipError_t launch_predict_finish(hipStream_t s, const double *V, long ldv, int M
                                  int nslice = 1, long sstride = 0);
 hipError_t launch_grad_partials(hipStream_t s, const double *S, long lds, int soff, long sstride, int nb, const double *X, int N,
                                 int d, double *ag, int np_pad, long gstride, double *part, long pstride, int *nparts,
-                                int exact_kind = 0, int nbeta = 0, const CovParams *pp_dev = nullptr);
+                                int exact_kind = 0, int nbeta = 0, const CovParams *pp_dev = nullptr, bool lit_noclamp = false);
 
 hipError_t launch_beta_solve(hipStream_t s, const double *res, long rstride, int Rp, int nreg, int nb, double *ag, long gstride,
                              int np_pad);

@@ -74,12 +74,14 @@ __device__ __forceinline__ double fast_exp_neg_g(double x, const double *tab_amp
 // operations behind the estimate instead of the 6 of two Heron steps, error below 2e-16
 __device__ __forceinline__ double fast_sqrt_g(double a)
 {
+	// (a clamp instead of an `a > 0 ? u : 0` select -- one instruction for three: sqrt(1e-300) = 1e-150 gives exactly the
+	// value of a zero distance, amp * 1; the Gram form's cancellation can leave a tiny negative number here)
+	a = fmax(a, 1e-300);
 	const double y = __builtin_amdgcn_rsq(a);
 	const double s = a * y;
 	const double eps = fma(-s, y, 1.0);
 	const double q = fma(eps, 0.375, 0.5);
-	const double u = fma(s * eps, q, s);
-	return (a > 0.0) ? u : 0.0;
+	return fma(s * eps, q, s);
 }
 
 // sqrt(a), a >= 0: hardware rsqrt estimate + two Heron corrections
@@ -236,25 +238,30 @@ __device__ __forceinline__ void gram_tables(const CovParams &p, int d, double *t
 // elements come out of the MFMA accumulators; only if some lane of the WAVE holds a nugget-rule candidate (a squared
 // distance below cand_g: coinciding design points, the diagonal) does the wave enter the exact re-computation; only
 // edge tiles (rows / columns beyond n) take the bounds-checked store.
-template <int KIND>
-__device__ __forceinline__ void cov_fill_tile_gram_k(double *out, long ld, const double *X, const double *Xg, int n, int d,
+// RECT = false: the square training matrix (rows and columns are the design: Xa = Xb = X, Xag = Xbg = the centred design).
+// RECT = true: k-vectors (makeKVector_fnptr, emulator.c:578-593): rows are query points, centred on the fly with the
+// design's per-dimension centre `mid`; a wave whose query rows lie so far outside the design that the Gram form's
+// cancellation bound no longer holds (|x'|^2 > 16) recomputes its elements from differences (the candidate path below).
+template <int KIND, bool RECT = false>
+__device__ __forceinline__ void cov_fill_tile_gram_k(double *out, long ld, const double *Xa, const double *Xag, const double *mid,
+                                                     int na_rows, const double *Xb, const double *Xbg, int nb_cols, int d,
                                                      const CovParams &p, int mode, int tr, int tc, const double *tab, const double *wsc)
 {
 	const int tid = threadIdx.x;
 	const double croot = gram_root(KIND);
-	const double cand_g = p.cand_g * croot * croot;
+	double cand_g = p.cand_g * croot * croot;
 	const int lane = tid & 63, wave = tid >> 6;
 	const int q = lane & 15, g = lane >> 4;
 	const int arow = tr * FT + 16 * wave + q;                 // A operand row of this lane
-	const bool av = arow < n;
-	const double *ap = Xg + (long)(av ? arow : 0) * d;
+	const bool av = arow < na_rows;
+	const double *ap = (RECT ? Xa : Xag) + (long)(av ? arow : 0) * d;
 	const double *bp[4];
 	bool bv[4];
 #pragma unroll
 	for (int j = 0; j < 4; j++) {
 		const int bc = tc * FT + 16 * j + q;
-		bv[j] = bc < n;
-		bp[j] = Xg + (long)(bv[j] ? bc : 0) * d;
+		bv[j] = bc < nb_cols;
+		bp[j] = Xbg + (long)(bv[j] ? bc : 0) * d;
 	}
 	d4g_t acc[4];
 #pragma unroll
@@ -264,7 +271,7 @@ __device__ __forceinline__ void cov_fill_tile_gram_k(double *out, long ld, const
 		const int k = k0 + g;
 		const bool kv = k < d;
 		const double wk = wsc[kv ? k : 0];
-		const double xa = (kv && av) ? ap[k] * wk : 0.0;
+		const double xa = (kv && av) ? (RECT ? (ap[k] - mid[k]) * wk : ap[k] * wk) : 0.0;
 		na = fma(xa, xa, na);
 #pragma unroll
 		for (int j = 0; j < 4; j++) {
@@ -277,6 +284,7 @@ __device__ __forceinline__ void cov_fill_tile_gram_k(double *out, long ld, const
 	na += __shfl_xor(na, 16); na += __shfl_xor(na, 32);
 #pragma unroll
 	for (int j = 0; j < 4; j++) { nb[j] += __shfl_xor(nb[j], 16); nb[j] += __shfl_xor(nb[j], 32); }
+	if (RECT && __any(na > 16.0 * croot * croot)) cand_g = HUGE_VAL;      // query rows far outside the design: exact distances
 	// one more matrix step adds |x'_row|^2 + |y'_col|^2: k slot 0 = (|x'|^2, 1), k slot 1 = (1, |y'|^2)
 	{
 		const double ea = (g == 0) ? na : (g == 1 ? 1.0 : 0.0);
@@ -308,11 +316,11 @@ __device__ __forceinline__ void cov_fill_tile_gram_k(double *out, long ld, const
 				for (int jj = 0; jj < 4; jj++) ae = (rr == r && jj == j) ? acc[jj][rr] : ae;
 			{
 				const int row = row0 + 4 * r, col = col0 + 16 * j;
-				if (ae <= cand_g && row < n && col < n) {
+				if (ae <= cand_g && row < na_rows && col < nb_cols) {
 					int cnt = 0;
 					double a = 0.0;
 					for (int k = 0; k < d; k++) {
-						const double D = X[(long)row * d + k] - X[(long)col * d + k];
+						const double D = Xa[(long)row * d + k] - Xb[(long)col * d + k];
 						const double t = D * wsc[k];
 						a = fma(t, t, a);
 						cnt += (fabs(D) < p.eps) ? 1 : 0;
@@ -326,15 +334,33 @@ __device__ __forceinline__ void cov_fill_tile_gram_k(double *out, long ld, const
 			}
 		}
 	}
-	const bool full = (tr * FT + FT <= n) && (tc * FT + FT <= n);
-	if (full && !(mode & FILL_CLAMP)) {
+	const bool full = (tr * FT + FT <= na_rows) && (tc * FT + FT <= nb_cols);
+	if (full && (RECT || !(mode & FILL_CLAMP)) && !__any(same != 0)) {
+		// the common tile: no coinciding points anywhere in the wave -- no nugget select in the element loop (it cost 7 of
+		// the 33 vector instructions per element: mask test, both variants of the value, two selects)
 #pragma unroll
 		for (int r = 0; r < 4; r++) {
 			double *orow = out + (long)(row0 + 4 * r) * ld + col0;
 #pragma unroll
 			for (int j = 0; j < 4; j++) {
 				double v = cov_from_u2_gram<KIND>(acc[j][r], tab);
-				if (same & (1u << (4 * r + j))) v += p.nug;
+				if (RECT && v < 1E-10) v = 0.0;                                           // emulator.c:588-590 (k-vectors are always clamped)
+				orow[16 * j] = v;
+				if (j & 1) __builtin_amdgcn_sched_barrier(0);
+			}
+		}
+		return;
+	}
+	if (full && (RECT || !(mode & FILL_CLAMP))) {
+		const double nug = p.nug;
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			double *orow = out + (long)(row0 + 4 * r) * ld + col0;
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				double v = cov_from_u2_gram<KIND>(acc[j][r], tab);
+				if (same & (1u << (4 * r + j))) v += nug;
+				if (RECT && v < 1E-10) v = 0.0;                                           // emulator.c:588-590 (k-vectors are always clamped)
 				orow[16 * j] = v;
 				// two elements at a time: a dependent fp64 operation can issue as soon as its predecessor has gone through the
 				// pipe (16 cycles either way), so interleaving more chains buys nothing and costs registers -- sixteen
@@ -351,10 +377,10 @@ __device__ __forceinline__ void cov_fill_tile_gram_k(double *out, long ld, const
 		for (int j = 0; j < 4; j++) {
 			const int col = col0 + 16 * j;
 			double v;
-			if (row < n && col < n) {
+			if (row < na_rows && col < nb_cols) {
 				v = cov_from_u2_gram<KIND>(acc[j][r], tab);
 				if (same & (1u << (4 * r + j))) v += p.nug;
-				if ((mode & FILL_CLAMP) && v < 1E-10) v = 0.0;                            // emulator.c:588-590
+				if ((RECT || (mode & FILL_CLAMP)) && v < 1E-10) v = 0.0;                  // emulator.c:588-590
 			} else {
 				v = ((mode & FILL_IDENT_PAD) && row == col) ? 1.0 : 0.0;
 			}
@@ -398,7 +424,7 @@ __global__ __launch_bounds__(256) void cov_stage_batch_kernel(double *T, long ld
 			__shared__ double wsc[GPEMU_MAX_PARAMS];
 			gram_tables(ps, d, tab, wsc);
 			__syncthreads();
-			cov_fill_tile_gram_k<KIND>(out, ld, X, Xg, N, d, ps, mode, tr, tc, tab, wsc);
+			cov_fill_tile_gram_k<KIND>(out, ld, X, Xg, nullptr, N, X, Xg, N, d, ps, mode, tr, tc, tab, wsc);
 		} else cov_fill_tile(out, ld, X, N, X, N, d, ps, mode, tr, tc);
 		return;
 	}
@@ -437,7 +463,7 @@ __global__ __launch_bounds__(256) void cov_stage_gram_kernel(double *T, long ld,
 			if (t < 0) break;
 			int tr, tc;
 			lower_tile(t, tr, tc);
-			cov_fill_tile_gram_k<KIND>(out, ld, X, Xg, N, d, ps, mode, tr, tc, tab, wsc);
+			cov_fill_tile_gram_k<KIND>(out, ld, X, Xg, nullptr, N, X, Xg, N, d, ps, mode, tr, tc, tab, wsc);
 		}
 		return;
 	}
@@ -451,7 +477,8 @@ __global__ __launch_bounds__(256) void cov_stage_gram_kernel(double *T, long ld,
 }
 
 // the 2^(j/1024) table of the Gram-form exp: written once per device from host-computed values (exp2 of glibc)
-static hipError_t ensure_exp_table()
+// (copied on the caller's stream: a legacy-stream copy fails while another host thread is recording a launch graph)
+static hipError_t ensure_exp_table(hipStream_t s)
 {
 	static std::mutex mu;
 	static std::set<int> done;
@@ -462,7 +489,8 @@ static hipError_t ensure_exp_table()
 	if (done.count(dev)) return hipSuccess;
 	std::vector<double> h(EXP_TAB_G);
 	for (int j = 0; j < EXP_TAB_G; j++) h[j] = std::exp2((double)j / EXP_TAB_G);
-	e = hipMemcpyToSymbol(HIP_SYMBOL(g_exp2_tab), h.data(), sizeof(double) * EXP_TAB_G);
+	e = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_exp2_tab), h.data(), sizeof(double) * EXP_TAB_G, 0, hipMemcpyHostToDevice, s);
+	if (e == hipSuccess) e = hipStreamSynchronize(s);
 	if (e == hipSuccess) done.insert(dev);
 	return e;
 }
@@ -475,7 +503,7 @@ hipError_t launch_cov_stage_batch(hipStream_t s, double *T, long ld, long bstrid
 	if (Np % FT || FT != 64) return hipErrorInvalidValue;
 	if (kind < GPEMU_POWEREXP || kind > GPEMU_MATERN52) return hipErrorInvalidValue;
 	if (Xg) {
-		const hipError_t e = ensure_exp_table();
+		const hipError_t e = ensure_exp_table(s);
 		if (e != hipSuccess) return e;
 	}
 	const long nt = Np / FT;
@@ -512,6 +540,47 @@ hipError_t launch_cov_fill(hipStream_t s, double *out, long ld, const double *Xr
 		grid = dim3((unsigned)(nt * (nt + 1) / 2), 1);
 	}
 	hipLaunchKernelGGL(cov_fill_kernel, grid, dim3(256), 0, s, out, ld, Xr, nr, Xc, nc, d, p, mode);
+	return hipGetLastError();
+}
+
+// k-vectors of a block of query points in Gram form (makeKVector_fnptr, emulator.c:578-593, clamp included): out[q][i] =
+// cov(xq_q, x_i), rows q >= M and columns i >= N of the padded block are zero.  One workgroup fills GRAM_TPW tiles of one
+// tile row (the same 64 queries against consecutive 64-point blocks of the design) with one set of tables; 9 KB of LDS,
+// d/4 + 1 matrix instructions per 256 elements instead of the difference form's 2 d subtract/FMA wave-instructions per element.
+template <int KIND>
+__global__ __launch_bounds__(256) void cov_kvec_gram_kernel(double *out, long ld, const double *Xq, int M, int Mp, const double *X,
+                                                            const double *Xg, const double *mid, int N, int Np, int d, CovParams p)
+{
+	__shared__ double tab[EXP_TAB_G];
+	__shared__ double wsc[GPEMU_MAX_PARAMS];
+	__shared__ double mid_s[GPEMU_MAX_PARAMS];
+	gram_tables(p, d, tab, wsc);
+	if (threadIdx.x < GPEMU_MAX_PARAMS) mid_s[threadIdx.x] = ((int)threadIdx.x < d) ? mid[threadIdx.x] : 0.0;
+	__syncthreads();
+	const int ntc = Np / FT, ngc = (ntc + GRAM_TPW - 1) / GRAM_TPW;
+	const int tr = blockIdx.x / ngc, tc0 = (blockIdx.x % ngc) * GRAM_TPW;
+	for (int i = 0; i < GRAM_TPW; i++) {
+		const int tc = tc0 + i;
+		if (tc >= ntc) break;
+		cov_fill_tile_gram_k<KIND, true>(out, ld, Xq, nullptr, mid_s, M, X, Xg, N, d, p, FILL_CLAMP, tr, tc, tab, wsc);
+	}
+	(void)Mp;
+}
+
+hipError_t launch_cov_kvec_gram(hipStream_t s, double *out, long ld, const double *Xq, int M, int Mp, const double *X, const double *Xg,
+                                const double *mid, int N, int Np, int d, const CovParams &p)
+{
+	if (Np % FT || Mp % FT || !p.gram || !Xg || !mid) return hipErrorInvalidValue;
+	const hipError_t e = ensure_exp_table(s);
+	if (e != hipSuccess) return e;
+	const int ntc = Np / FT, ngc = (ntc + GRAM_TPW - 1) / GRAM_TPW;
+	const dim3 grid((unsigned)((Mp / FT) * ngc));
+	if (p.kind == GPEMU_POWEREXP)
+		hipLaunchKernelGGL(cov_kvec_gram_kernel<GPEMU_POWEREXP>, grid, dim3(256), 0, s, out, ld, Xq, M, Mp, X, Xg, mid, N, Np, d, p);
+	else if (p.kind == GPEMU_MATERN32)
+		hipLaunchKernelGGL(cov_kvec_gram_kernel<GPEMU_MATERN32>, grid, dim3(256), 0, s, out, ld, Xq, M, Mp, X, Xg, mid, N, Np, d, p);
+	else
+		hipLaunchKernelGGL(cov_kvec_gram_kernel<GPEMU_MATERN52>, grid, dim3(256), 0, s, out, ld, Xq, M, Mp, X, Xg, mid, N, Np, d, p);
 	return hipGetLastError();
 }
 
@@ -711,6 +780,50 @@ __global__ void gather_alpha_kernel(const double *S, long lds_, int soff, long s
 	ag[(long)blockIdx.y * gstride + i] = a;
 }
 
+// Sum over the 256 threads of a workgroup of NV (<= 16) per-thread partials, in a fixed order: the partials go through
+// LDS (scratch: 256 x (NV + 1) doubles), the 16 threads of group g = tid >> 4 each add 16 of the 256 partials of value g
+// in thread order and a 4-step butterfly inside the group finishes.  Returns the total of value g in every thread of
+// group g (g < NV).  Two barriers per call, whatever NV: the tree reduction per value this replaces cost ten.
+template <int NV>
+__device__ __forceinline__ double block_sum(const double (&acc)[NV], double *scratch)
+{
+	static_assert(NV >= 1 && NV <= 16, "one 16-thread group per value");
+	const int tid = threadIdx.x;
+#pragma unroll
+	for (int v = 0; v < NV; v++) scratch[tid * (NV + 1) + v] = acc[v];
+	__syncthreads();
+	const int g = tid >> 4, s = tid & 15;
+	double sum = 0.0;
+	if (g < NV) {
+#pragma unroll
+		for (int j = 0; j < 16; j++) sum += scratch[(s * 16 + j) * (NV + 1) + g];
+	}
+	sum += __shfl_xor(sum, 8);
+	sum += __shfl_xor(sum, 4);
+	sum += __shfl_xor(sum, 2);
+	sum += __shfl_xor(sum, 1);
+	__syncthreads();
+	return sum;
+}
+
+// dynamic LDS of the two gradient kernels (doubles): two 64 x (d + 1) coordinate tiles, alpha of the tile's rows and
+// columns, the exp table, per-direction constants, the reduction scratch
+constexpr int GRAD_CHUNK = 8;                      // literal form: directions per reduction (2 sums each)
+__host__ __device__ inline size_t grad_lds_doubles(int d, int tab_len)
+{
+	return (size_t)128 * (d + 1) + 128 + tab_len + 2 * (size_t)((d + 1) & ~1) + 256 * 17;
+}
+
+// exp(x), x <= 0, from the 1024-entry table 2^(j/1024) in LDS (the Gram-form fill's exp with amplitude 1), arguments
+// below -700 taken as -700 (e^-700 = 2^-1010 is still a normal number for the exponent-field add)
+__device__ __forceinline__ double fast_exp_neg_t(double x, const double *tab)
+{
+	return fast_exp_neg_g(fmax(x, -700.0), tab);
+}
+
+// CLAMP = false: the host has checked that 1/2 e^{-2 theta_k} D^2 stays below 600 for every pair of design points and
+// every direction of the batch (the usual case), so the exp argument needs no lower bound
+template <bool CLAMP>
 __global__ __launch_bounds__(256) void grad_part_kernel(const double *S, long lds_, int soff, long sstride, const double *X,
                                                         int N, int d, const double *ag, int np_pad, long gstride, double *part,
                                                         long pstride)
@@ -722,84 +835,90 @@ __global__ __launch_bounds__(256) void grad_part_kernel(const double *S, long ld
 	const int np = 2 * d + 2;
 	// lower-triangular tile index -> (tr, tc)
 	const int t = blockIdx.x;
-	int tr = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-	while ((long)(tr + 1) * (tr + 2) / 2 <= t) tr++;
-	while ((long)tr * (tr + 1) / 2 > t) tr--;
-	const int tc = t - tr * (tr + 1) / 2;
+	int tr, tc;
+	lower_tile(t, tr, tc);
 
-	__shared__ double xr_s[64 * (GPEMU_MAX_PARAMS + 1)];
-	__shared__ double xc_s[64 * (GPEMU_MAX_PARAMS + 1)];
-	__shared__ double ar_s[64], ac_s[64];
-	__shared__ double red[256];
+	// coordinate tiles TRANSPOSED, [direction][64 points]: the 16 row coordinates a thread needs per direction sit 32 bytes
+	// apart (immediate offsets, no address arithmetic in the element loop) and the column coordinates of a wave are contiguous
+	extern __shared__ double grad_sm[];
+	const int dpad = (d + 1) & ~1;
+	double *xr_t = grad_sm, *xc_t = xr_t + 64 * (d + 1), *ar_s = xc_t + 64 * (d + 1), *ac_s = ar_s + 64, *tab = ac_s + 64;
+	double *hk = tab + EXP_TAB_G, *e2k = hk + dpad, *scratch = e2k + dpad;
 	const int tid = threadIdx.x;
-	const int sd = d + 1;
 	for (int e = tid; e < 64 * d; e += 256) {
 		int r = e / d, k = e % d;
 		int gr = tr * 64 + r, gc = tc * 64 + r;
-		xr_s[r * sd + k] = (gr < N) ? X[(long)gr * d + k] : 0.0;
-		xc_s[r * sd + k] = (gc < N) ? X[(long)gc * d + k] : 0.0;
+		xr_t[k * 64 + r] = (gr < N) ? X[(long)gr * d + k] : 0.0;
+		xc_t[k * 64 + r] = (gc < N) ? X[(long)gc * d + k] : 0.0;
 	}
 	if (tid < 64) {
 		int gr = tr * 64 + tid, gc = tc * 64 + tid;
 		ar_s[tid] = (gr < N) ? alpha[gr] : 0.0;
 		ac_s[tid] = (gc < N) ? alpha[gc] : 0.0;
 	}
+	for (int e = tid; e < EXP_TAB_G; e += 256) tab[e] = g_exp2_tab[e];
+	// per direction, once per workgroup: e^{-2 theta_k} (the factor exp(-2 theta) of emulator.c:203 leaves the element
+	// loop: exp(-1/2 e^{-2t} D^2 - 2t) = e^{-2t} exp(-1/2 e^{-2t} D^2)) and half of it
+	if (tid < d) {
+		const double e2 = exp(-2.0 * gp[tid]);
+		e2k[tid] = e2;
+		hk[tid] = 0.5 * e2;
+	}
 	__syncthreads();
 
 	const int c = tid & 63, rsub = tid >> 6;
 	const int gc = tc * 64 + c;
-	double a_el[16], w_el[16];
+	double wa[16], wq[16];                 // weight x A_ab and weight x alpha_a alpha_b of the thread's 16 elements
+	double tsum = 0.0;
 #pragma unroll
 	for (int u = 0; u < 16; u++) {
 		const int r = rsub + 4 * u;
 		const int gr = tr * 64 + r;
 		const bool valid = gr < N && gc < N && gc <= gr;
-		a_el[u] = valid ? S[(long)(soff + gr) * lds_ + soff + gc] : 0.0;
-		w_el[u] = valid ? ((gc == gr) ? 1.0 : 2.0) : 0.0;
+		const double a = valid ? S[(long)(soff + gr) * lds_ + soff + gc] : 0.0;
+		const double w = valid ? ((gc == gr) ? 1.0 : 2.0) : 0.0;
+		wa[u] = w * a;
+		wq[u] = w * (ar_s[r] * ac_s[c]);
+		if (gr == gc && gr < N) tsum += a;
 	}
-	// trace of A
+	// trace of A; alpha^T alpha, rows of the diagonal tiles in index order
 	{
-		double tsum = 0.0;
-#pragma unroll
-		for (int u = 0; u < 16; u++) {
-			const int gr = tr * 64 + rsub + 4 * u;
-			if (gr == gc && gr < N) tsum += a_el[u];
-		}
-		red[tid] = tsum;
-		__syncthreads();
-		for (int st = 128; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
-		if (tid == 0) part[(long)t * np + 2 * d] = red[0];
-		__syncthreads();
-		// alpha^T alpha, rows of the diagonal tiles in index order
+		const double one[1] = {tsum};
+		const double tot = block_sum<1>(one, scratch);
 		if (tid == 0) {
+			part[(long)t * np + 2 * d] = tot;
 			double aa = 0.0;
 			if (tr == tc)
 				for (int r = 0; r < 64; r++) aa += ar_s[r] * ar_s[r];
 			part[(long)t * np + 2 * d + 1] = aa;
 		}
 	}
-	for (int k = 0; k < d; k++) {
-		const double th = gp[k];
-		const double e2 = exp(-2.0 * th);
-		double s_tr = 0.0, s_q = 0.0;
+	for (int k0 = 0; k0 < d; k0 += GRAD_CHUNK) {
+		double acc[2 * GRAD_CHUNK];
 #pragma unroll
-		for (int u = 0; u < 16; u++) {
-			const int r = rsub + 4 * u;
-			const double D = xr_s[r * sd + k] - xc_s[c * sd + k];
-			const double dc = exp(-0.5 * e2 * D * D - 2 * th) * D * D;   // emulator.c:203
-			s_tr += w_el[u] * a_el[u] * dc;
-			s_q += w_el[u] * ar_s[r] * ac_s[c] * dc;
+		for (int v = 0; v < 2 * GRAD_CHUNK; v++) acc[v] = 0.0;
+#pragma unroll
+		for (int j = 0; j < GRAD_CHUNK; j++) {
+			const int k = k0 + j;
+			if (k < d) {
+				const double nh = -hk[k];
+				const double xck = xc_t[k * 64 + c];
+				const double *xrk = xr_t + k * 64 + rsub;
+#pragma unroll
+				for (int u = 0; u < 16; u++) {
+					const double D = xrk[4 * u] - xck;
+					const double uu = D * D;
+					const double x = nh * uu;
+					const double z = uu * (CLAMP ? fast_exp_neg_t(x, tab) : fast_exp_neg_g(x, tab));   // emulator.c:203 without its e^{-2 theta}
+					acc[2 * j] = fma(wa[u], z, acc[2 * j]);
+					acc[2 * j + 1] = fma(wq[u], z, acc[2 * j + 1]);
+					if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);         // four chains in flight
+				}
+			}
 		}
-		red[tid] = s_tr;
-		__syncthreads();
-		for (int st = 128; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
-		if (tid == 0) part[(long)t * np + 2 * k] = red[0];
-		__syncthreads();
-		red[tid] = s_q;
-		__syncthreads();
-		for (int st = 128; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
-		if (tid == 0) part[(long)t * np + 2 * k + 1] = red[0];
-		__syncthreads();
+		const double tot = block_sum<2 * GRAD_CHUNK>(acc, scratch);
+		const int v = tid >> 4, k = k0 + (v >> 1);
+		if ((tid & 15) == 0 && k < d) part[(long)t * np + 2 * k + (v & 1)] = e2k[k] * tot;
 	}
 }
 
@@ -830,13 +949,11 @@ __global__ __launch_bounds__(256) void grad_exact_kernel(const double *S, long l
 	const long t = blockIdx.x;
 
 	__shared__ CovParams ps;
-	__shared__ double xr_s[64 * (GPEMU_MAX_PARAMS + 1)];
-	__shared__ double xc_s[64 * (GPEMU_MAX_PARAMS + 1)];
-	__shared__ double ar_s[64], ac_s[64];
-	__shared__ double red[256];
-	__shared__ double tab[EXP_TAB];
+	extern __shared__ double grad_sm[];
+	const int sd = d + 1, dpad = (d + 1) & ~1;
+	double *xr_s = grad_sm, *xc_s = xr_s + 64 * sd, *ar_s = xc_s + 64 * sd, *ac_s = ar_s + 64, *tab = ac_s + 64;
+	double *scratch = tab + EXP_TAB + 2 * dpad;
 	const int tid = threadIdx.x;
-	const int sd = d + 1;
 	for (int e = tid; e < (int)(sizeof(CovParams) / sizeof(double)); e += 256)
 		reinterpret_cast<double *>(&ps)[e] = reinterpret_cast<const double *>(pp + blockIdx.y)[e];
 	for (int e = tid; e < 64 * d; e += 256) {
@@ -889,26 +1006,33 @@ __global__ __launch_bounds__(256) void grad_exact_kernel(const double *S, long l
 		}
 		if (same == d) s_nug += W * ps.nug;
 	}
-	for (int k = 0; k <= nd; k++) {
-		double sk = 0.0;
-		if (k == nd) {
-			sk = s_nug;
-		} else if (KIND == GPEMU_POWEREXP) {
+	// the nd + 1 sums of the tile (directions 0 .. nd-1, then the nugget), sixteen per reduction
+	for (int k0 = 0; k0 <= nd; k0 += 16) {
+		double acc[16];
 #pragma unroll
-			for (int u = 0; u < 16; u++) {
-				const int r = rsub + 4 * u;
-				const double v = (xr_s[r * sd + k] - xc_s[c * sd + k]) * ps.w[k];     // v^2 = 1/2 D^2 e^{-2 theta}
-				sk = fma(wk[u], 2.0 * v * v, sk);
+		for (int j = 0; j < 16; j++) {
+			const int k = k0 + j;
+			double sk = 0.0;
+			if (k == nd) {
+				sk = s_nug;
+			} else if (k < nd) {
+				if (KIND == GPEMU_POWEREXP) {
+					const double wkk = ps.w[k], xck = xc_s[c * sd + k];
+#pragma unroll
+					for (int u = 0; u < 16; u++) {
+						const double v = (xr_s[(rsub + 4 * u) * sd + k] - xck) * wkk;      // v^2 = 1/2 D^2 e^{-2 theta}
+						sk = fma(wk[u], 2.0 * v * v, sk);
+					}
+				} else {
+#pragma unroll
+					for (int u = 0; u < 16; u++) sk += wk[u];
+				}
 			}
-		} else {
-#pragma unroll
-			for (int u = 0; u < 16; u++) sk += wk[u];
+			acc[j] = sk;
 		}
-		red[tid] = sk;
-		__syncthreads();
-		for (int st = 128; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
-		if (tid == 0) part[t * np + k] = red[0];
-		__syncthreads();
+		const double tot = block_sum<16>(acc, scratch);
+		const int k = k0 + (tid >> 4);
+		if ((tid & 15) == 0 && k <= nd) part[t * np + k] = tot;
 	}
 }
 
@@ -995,7 +1119,7 @@ hipError_t launch_grad_reduce(hipStream_t s, const double *part, long pstride, i
 // of pstride doubles
 hipError_t launch_grad_partials(hipStream_t s, const double *S, long lds_, int soff, long sstride, int nb, const double *X, int N,
                                 int d, double *ag, int np_pad, long gstride, double *part, long pstride, int *nparts,
-                                int exact_kind, int nbeta, const CovParams *pp_dev)
+                                int exact_kind, int nbeta, const CovParams *pp_dev, bool lit_noclamp)
 {
 	const int nt = (N + 63) / 64;
 	const int ntiles = nt * (nt + 1) / 2;
@@ -1003,18 +1127,36 @@ hipError_t launch_grad_partials(hipStream_t s, const double *S, long lds_, int s
 	hipLaunchKernelGGL(gather_alpha_kernel, dim3((N + 255) / 256, nb), dim3(256), 0, s, S, lds_, soff, sstride, N, ag, gstride,
 	                   np_pad, exact_kind ? nbeta : 0);
 	const dim3 grid(ntiles, nb);
+	const size_t lds_exact = grad_lds_doubles(d, EXP_TAB) * sizeof(double), lds_lit = grad_lds_doubles(d, EXP_TAB_G) * sizeof(double);
+	// (more than 64 KB of dynamic LDS -- d beyond 20 or so -- has to be allowed per kernel)
+	auto allow = [](const void *fn, size_t bytes) {
+		return bytes <= 65536 ? hipSuccess : hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+	};
+	hipError_t ea = hipSuccess;
+	if (exact_kind == GPEMU_POWEREXP) ea = allow((const void *)grad_exact_kernel<GPEMU_POWEREXP>, lds_exact);
+	else if (exact_kind == GPEMU_MATERN32) ea = allow((const void *)grad_exact_kernel<GPEMU_MATERN32>, lds_exact);
+	else if (exact_kind == GPEMU_MATERN52) ea = allow((const void *)grad_exact_kernel<GPEMU_MATERN52>, lds_exact);
+	else ea = lit_noclamp ? allow((const void *)grad_part_kernel<false>, lds_lit) : allow((const void *)grad_part_kernel<true>, lds_lit);
+	if (ea != hipSuccess) return ea;
 	if (exact_kind == GPEMU_POWEREXP)
-		hipLaunchKernelGGL(grad_exact_kernel<GPEMU_POWEREXP>, grid, dim3(256), 0, s, S, lds_, soff, sstride, X, N, d, ag, gstride,
+		hipLaunchKernelGGL(grad_exact_kernel<GPEMU_POWEREXP>, grid, dim3(256), lds_exact, s, S, lds_, soff, sstride, X, N, d, ag, gstride,
 		                   part, pstride, pp_dev);
 	else if (exact_kind == GPEMU_MATERN32)
-		hipLaunchKernelGGL(grad_exact_kernel<GPEMU_MATERN32>, grid, dim3(256), 0, s, S, lds_, soff, sstride, X, N, d, ag, gstride,
+		hipLaunchKernelGGL(grad_exact_kernel<GPEMU_MATERN32>, grid, dim3(256), lds_exact, s, S, lds_, soff, sstride, X, N, d, ag, gstride,
 		                   part, pstride, pp_dev);
 	else if (exact_kind == GPEMU_MATERN52)
-		hipLaunchKernelGGL(grad_exact_kernel<GPEMU_MATERN52>, grid, dim3(256), 0, s, S, lds_, soff, sstride, X, N, d, ag, gstride,
+		hipLaunchKernelGGL(grad_exact_kernel<GPEMU_MATERN52>, grid, dim3(256), lds_exact, s, S, lds_, soff, sstride, X, N, d, ag, gstride,
 		                   part, pstride, pp_dev);
-	else
-		hipLaunchKernelGGL(grad_part_kernel, grid, dim3(256), 0, s, S, lds_, soff, sstride, X, N, d, ag, np_pad, gstride,
-		                   part, pstride);
+	else {
+		const hipError_t e = ensure_exp_table(s);           // the literal form's exp reads the fill's 2^(j/1024) table
+		if (e != hipSuccess) return e;
+		if (lit_noclamp)
+			hipLaunchKernelGGL(grad_part_kernel<false>, grid, dim3(256), lds_lit, s, S, lds_, soff, sstride, X, N, d, ag, np_pad, gstride,
+			                   part, pstride);
+		else
+			hipLaunchKernelGGL(grad_part_kernel<true>, grid, dim3(256), lds_lit, s, S, lds_, soff, sstride, X, N, d, ag, np_pad, gstride,
+			                   part, pstride);
+	}
 	return hipGetLastError();
 }
 

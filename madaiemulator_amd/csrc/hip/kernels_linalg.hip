@@ -166,8 +166,21 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 	const int row0 = tm * BM + wm * WM + (lane >> 4);
 	const int col0 = tn * BN + wn * WN + (lane & 15);
 	const bool full_tile = (tm * BM + BM <= g.m) && (tn * BN + BN <= g.n);
+	// a wave whose whole sub-tile lies strictly above the diagonal of a triangular update (two of the eight waves of a
+	// diagonal 128x128 tile, one of the four of a 64x64 one) computes output nobody reads: it keeps moving operand chunks
+	// and meeting the barriers, but issues no matrix instruction, no fragment read, no C access -- its SIMD's matrix pipe
+	// goes to the other workgroup of the CU.  (Not in the factor-ahead tile, whose LDS image is written by every wave.)
+	// (through readfirstlane: a wave-uniform value the compiler can branch on -- under an EXEC mask the matrix instructions
+	// would still be issued)
+	const bool idle = __builtin_amdgcn_readfirstlane((int)(g.tri && !(FA && g.fa && tm == 0 && tn == 0) &&
+	                                                     (tn * BN + wn * WN > tm * BM + wm * WM + WM - 1 + g.diag_off))) != 0;
 	d4_t acc[TM][TN];
-	if (g.beta) {
+	if (idle) {
+#pragma unroll
+		for (int i = 0; i < TM; i++)
+#pragma unroll
+			for (int j = 0; j < TN; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+	} else if (g.beta) {
 		if (full_tile) {
 #pragma unroll
 			for (int i = 0; i < TM; i++)
@@ -281,21 +294,25 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		__syncthreads();
 		if (kb + GEMM_BK < ke) GEMM_DMA(1, kb + GEMM_BK);
-		GEMM_FRAGS(xa, xb, 0, 0);
+		if (!idle) GEMM_FRAGS(xa, xb, 0, 0);
 		if (g.trace && tr0.wall) atomicAdd(g.trace + 5, (unsigned long long)clock64() - tr0.clk);   // prologue
 		int cur = 0;
 		for (int k = kb; k < ke; k += GEMM_BK) {
-			GEMM_FRAGS(ya, yb, cur, 1);
-			__builtin_amdgcn_sched_barrier(0);
-			GEMM_BLOCK(xa, xb);
+			if (!idle) {
+				GEMM_FRAGS(ya, yb, cur, 1);
+				__builtin_amdgcn_sched_barrier(0);
+				GEMM_BLOCK(xa, xb);
+			}
 			__builtin_amdgcn_sched_barrier(0);
 			// chunk k+1 (requested a k-step ago) has landed for every wave; every wave has read the last of chunk k
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			__syncthreads();
 			if (k + 2 * GEMM_BK < ke) GEMM_DMA(cur, k + 2 * GEMM_BK);
-			if (k + GEMM_BK < ke) GEMM_FRAGS(xa, xb, cur ^ 1, 0);
-			__builtin_amdgcn_sched_barrier(0);
-			GEMM_BLOCK(ya, yb);
+			if (!idle) {
+				if (k + GEMM_BK < ke) GEMM_FRAGS(xa, xb, cur ^ 1, 0);
+				__builtin_amdgcn_sched_barrier(0);
+				GEMM_BLOCK(ya, yb);
+			}
 			__builtin_amdgcn_sched_barrier(0);
 			cur ^= 1;
 		}
@@ -305,6 +322,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 #undef GEMM_BLOCK
 	}
 
+	if (idle) { trace_end(g.trace, tr0); return; }
 	// epilogue: alpha * accumulators (a sign flip or nothing for alpha = -+1, see above)
 	unsigned long long clk_loop_end = 0;
 	if (g.trace && tr0.wall) clk_loop_end = clock64();
@@ -563,7 +581,8 @@ static TileTable gemm_tile_table(hipStream_t s, int tiles_m, int tiles_n, int tr
 	const std::vector<int> table = build_tile_table(tiles_m, tiles_n, tri, sb, bm, bn);
 	TileTable tt{nullptr, (int)table.size()};
 	if (hipMalloc(&tt.dptr, table.size() * sizeof(int)) != hipSuccess ||
-	    hipMemcpy(tt.dptr, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+	    hipMemcpyAsync(tt.dptr, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess ||
+	    hipStreamSynchronize(s) != hipSuccess) {       // (the caller's stream, never the legacy one: another thread may be capturing)
 		(void)hipGetLastError();
 		return TileTable{nullptr, 0};
 	}
