@@ -557,15 +557,29 @@ def main():
         # 16-B-per-lane reads; the 8-B-per-lane C-tile reads of this kernel calibrate to the same half
         # (profiles/r01_pmc_fetch_calibration.txt), so the whole raw fetch is doubled; WRITE_SIZE is exact.  Infinity-
         # Cache hits are included in both, i.e. this is fabric traffic, an upper bound on HBM traffic.
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")
-        if args.workload == "c3" and B == 16 and os.path.exists(tpath):      # measured for batches of 16
-            tj = json.load(open(tpath)).get("gemm_nt_kernel_128x128_8waves_dma")
-            if tj:
+        traffic, traffic_src, traffic_why = None, None, "no profiles/r*_pmc_hbm_traffic.json"
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_hbm_traffic.json")))
+        if cands:
+            tpath = cands[-1]                                   # the newest round's PMC passes
+            tj_all = json.load(open(tpath))
+            tj = tj_all.get("gemm_nt_kernel_128x128_8waves_dma")
+            nbat = tj_all.get("batches_profiled", 2)
+            # the file is used only if it describes THIS run: same workload and batch size, and the dominant kernel was
+            # launched as often per batch there as here (a changed kernel split or schedule makes the file stale -> null)
+            if args.workload != "c3" or B != tj_all.get("batch_size", 16):
+                traffic_why = "PMC file is for workload c3, batches of 16"
+            elif not tj or "fetch_bytes_raw" not in tj or "write_bytes" not in tj:
+                traffic_why = f"{os.path.basename(tpath)} has no FETCH_SIZE/WRITE_SIZE entry for the dominant kernel"
+            elif tj["launches"] != nbat * p["n"]:
+                traffic_why = (f"{os.path.basename(tpath)} is stale: {tj['launches']} launches of the dominant kernel in {nbat} "
+                               f"batches there, {p['n']} per batch in this run")
+            else:
                 traffic = (2.0 * tj["fetch_bytes_raw"] + tj["write_bytes"]) / tj["launches"]
+                traffic_src, traffic_why = os.path.basename(tpath), None
         roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<128,128,4,4,2,0> (potrf trailing updates on 128x128 tiles, LDS-DMA staging, v_mfma_f64_16x16x4_f64)",
                 "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS,
-                "traffic": traffic, "traffic_source": os.path.basename(tpath) if (traffic is not None) else None,
+                "traffic": traffic, "traffic_source": traffic_src, "traffic_null_because": traffic_why,
                 "launches": p["n"], "avg_launch_us": p["ms"] * 1e3 / max(p["n"], 1),
                 "flops_per_launch": p["flops"] / max(p["n"], 1), "evaluations_per_launch": B}
         # every GEMM launch of the batch (the narrow K <= 256 updates on 64x64 tiles included; with factor-ahead their

@@ -49,6 +49,10 @@ void gpemu_ctx_destroy(gpemu_ctx *ctx);
 const char *gpemu_last_error(const gpemu_ctx *ctx);
 const char *gpemu_version(void);
 int  gpemu_device_count(void);
+/* free / total HBM of a device in bytes (hipMemGetInfo): the host layer sizes its lock-step groups with it.  A likelihood
+ * batch of nb evaluations holds nb * (N + 64) * N * 8 bytes, a value+gradient batch nb * (2 N + 64) * N * 8 plus up to
+ * 10 GB of C^-1 corners, per context. */
+int  gpemu_device_memory(int device, size_t *free_bytes, size_t *total_bytes);
 
 /* ---- model data (modelstruct.h:28-98: xmodel, training_vector) ------
  * Uploads the N x d design and the N training values to HBM and builds the

@@ -118,6 +118,20 @@ static hipError_t gemm(gpemu_ctx *ctx, const GemmArgs &a_in)
 // ---------------------------------------------------------------------------
 extern "C" const char *gpemu_version(void) { return "gpemu-mi355x 0.3 (gfx950, fp64 MFMA)"; }
 
+extern "C" int gpemu_device_memory(int device, size_t *free_bytes, size_t *total_bytes)
+{
+	int n = 0, cur = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return GPEMU_ERR_NO_DEVICE;
+	if (device < 0 || device >= n) return GPEMU_ERR_ARG;
+	size_t fr = 0, tot = 0;
+	(void)hipGetDevice(&cur);
+	if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return GPEMU_ERR_HIP; }
+	(void)hipSetDevice(cur);
+	if (free_bytes) *free_bytes = fr;
+	if (total_bytes) *total_bytes = tot;
+	return GPEMU_OK;
+}
+
 extern "C" int gpemu_device_count(void)
 {
 	int n = 0;
@@ -1281,6 +1295,10 @@ extern "C" int gpemu_loglik_grad_batch_enqueue(gpemu_ctx *ctx, int nb, const dou
 	rc = enqueue_results(ctx);                       // Gram, log det, info words -> the next slot of the pinned ring
 	if (rc) return rc;
 	const int slot = (int)((ctx->res_seq - 1) % gpemu_ctx::RES_RING);
+	// the ring entry becomes a collectable value+gradient batch only once EVERYTHING of it is on the stream: until then it
+	// is marked empty (res_nb = 0), so that after a failure below a later collect of this slot is refused
+	// (GPEMU_ERR_STATE) instead of returning a gradient built from whatever the pinned ring held
+	ctx->res_nb[slot] = 0;
 	ctx->res_kind[slot] = 1;
 	ctx->res_th[slot] = th;
 	ctx->res_nthetas[slot] = nthetas;
@@ -1293,6 +1311,7 @@ extern "C" int gpemu_loglik_grad_batch_enqueue(gpemu_ctx *ctx, int nb, const dou
 	HIPCHK(ctx, hipMemcpyAsync(ctx->hGradRing + (size_t)slot * ctx->batch_cap * gpemu_ctx::GRAD_NP_MAX, ctx->dGradSum,
 	                           (size_t)nb * gpemu_ctx::GRAD_NP_MAX * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
 	HIPCHK(ctx, hipEventRecord(ctx->res_ev[slot], ctx->stream));     // (re-recorded: now behind the gradient sums as well)
+	ctx->res_nb[slot] = nb;
 	return GPEMU_OK;
 }
 
@@ -1642,7 +1661,8 @@ extern "C" int gpemu_derivative_gauss(gpemu_ctx *ctx, int n, const double *xcol,
 
 // trace(A B) = sum_ij A[i][j] B[j][i] of two host-resident n x n matrices (row strides lda, ldb): getGradientCn's
 // trace(C^-1 dC/dtheta) (libEmu/maxmultimin.c:583-588) as one pass over the two matrices instead of an N^3 dgemm.
-// A goes through the same cache as gpemu_symm_apply (it is the C^-1 of the surrounding calls).
+// A goes through the same cache as gpemu_symm_apply -- literally: the gpemu_symm_apply call below is what makes it
+// resident, with that entry's (pointer, size, checksum, pin) rules; B is uploaded on every call.
 extern "C" int gpemu_trace_product(gpemu_ctx *ctx, int n, const double *a, int lda, const double *b, int ldb, double *trace)
 {
 	if (!ctx || n < 1 || !a || !b || lda < n || ldb < n || !trace) return GPEMU_ERR_ARG;

@@ -326,6 +326,10 @@ struct group {
 	double *th, *val, *sigma2, *grad;
 	int *want_grad, *status, *who;   /* who[slot]: member index of the request deposited in that slot */
 	struct vcache *vc;               /* one per member */
+	/* what the members' caches were computed FOR: checksums of the model's design and training values and the layer's
+	 * mode flags at the last device round (a caller may rewrite the buffers in place or switch modes while the group lives) */
+	unsigned long long vc_xsum, vc_ysum;
+	int vc_modes, vc_bound;
 	struct group *next;
 };
 static struct group *g_groups = NULL;
@@ -395,9 +399,12 @@ static void group_run_round(struct group *G)
 	const int saved_device = tls_device;          /* the round runs on whichever member arrived last: use the group's device */
 	tls_device = G->device;
 	int changed = 0;
-	gpemu_ctx *ctx = bind_model_entry(G, G->model, "lock-step group", &changed)->ctx;
+	struct entry *bound = bind_model_entry(G, G->model, "lock-step group", &changed);
+	gpemu_ctx *ctx = bound->ctx;
 	tls_device = saved_device;
-	if (changed) for (int i = 0; i < G->nmembers; i++) vcache_clear(&G->vc[i]);
+	if (changed || !G->vc_bound || G->vc_modes != gpemu_host_modes())
+		for (int i = 0; i < G->nmembers; i++) vcache_clear(&G->vc[i]);
+	G->vc_xsum = bound->xsum; G->vc_ysum = bound->ysum; G->vc_modes = gpemu_host_modes(); G->vc_bound = 1;
 	double *th = (double *)malloc(sizeof(double) * (size_t)n * nt * 2);
 	double *val = (double *)malloc(sizeof(double) * (size_t)n), *s2 = (double *)malloc(sizeof(double) * (size_t)n);
 	double *gr = (double *)malloc(sizeof(double) * (size_t)n * nt);
@@ -453,8 +460,15 @@ static int group_eval(struct group *G, const void *params, const double *th, int
 	pthread_mutex_lock(&G->mu);
 	const int me = group_member_index(G, params);
 	if (!want_grad) {
-		/* value / sigma^2 at a point this member has already evaluated: no device work, no round */
-		const int c = vcache_find(&G->vc[me], th, G->nthetas);
+		/* value / sigma^2 at a point this member has already evaluated: no device work, no round -- provided the cached
+		 * numbers still belong to the model as it is NOW (same checksums of design and training values, same modes: the
+		 * check bind_model_entry makes in front of every device round is made here in front of every cache answer) */
+		if (G->vc_bound && (G->vc_modes != gpemu_host_modes() || G->vc_xsum != sum_matrix(G->model->xmodel) ||
+		                    G->vc_ysum != sum_vector(G->model->training_vector))) {
+			for (int i = 0; i < G->nmembers; i++) vcache_clear(&G->vc[i]);
+			G->vc_bound = 0;
+		}
+		const int c = G->vc_bound ? vcache_find(&G->vc[me], th, G->nthetas) : -1;
 		if (c >= 0) {
 			if (val) *val = G->vc[me].val[c];
 			if (sigma2) *sigma2 = G->vc[me].sigma2[c];

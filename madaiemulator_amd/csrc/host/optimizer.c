@@ -419,6 +419,27 @@ void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 	int per_slot = 2;
 	env = getenv("GPEMU_GROUPS_PER_SLOT");
 	if (env && atoi(env) > 0) per_slot = atoi(env) > 8 ? 8 : atoi(env);
+	else if (lockstep > 1) {
+		/* every group holds a value+gradient workspace on its slot's device: lockstep x (2 Np + 64) x Np x 8 bytes plus up
+		 * to 10 GB of C^-1 corners (gpemu.h).  Two groups per slot are the default only while they fit the device's FREE
+		 * memory with a margin (at N ~ 24 000 one group of 16 needs ~155 GB: one fits 288 GB, two do not); the result of
+		 * a search does not depend on the number of groups, only its speed does. */
+		const double Np = 64.0 * ceil(options->nmodel_points / 64.0);
+		const double corner = (Np + 64.0) * (Np + 64.0) * 8.0;
+		double corners = floor(10.0e9 / corner);
+		if (corners < 1.0) corners = 1.0;
+		if (corners > lockstep) corners = lockstep;
+		const double need = lockstep * (2.0 * Np + 64.0) * Np * 8.0 + corners * corner + 64.0e6;
+		const int dev0 = gpemu_host_thread_device_get() >= 0 ? gpemu_host_thread_device_get() : gpemu_host_slot_device(0);
+		const int nsl = gpemu_host_thread_device_get() >= 0 ? 1 : gpemu_host_device_slots();
+		int sharing = 0;                               /* slots that live on the same physical device as slot 0 */
+		for (int s_ = 0; s_ < nsl; s_++) sharing += (gpemu_host_thread_device_get() >= 0 ? dev0 : gpemu_host_slot_device(s_)) == dev0;
+		size_t fr = 0, tot = 0;
+		if (gpemu_device_memory(dev0, &fr, &tot) == GPEMU_OK && fr > 0)
+			while (per_slot > 1 && (double)per_slot * sharing * need > 0.9 * (double)fr) per_slot--;
+		if (per_slot < 2 && getenv("GPEMU_SEARCH_STATS"))
+			fprintf(stderr, "# search: one lock-step group per device slot (a group needs %.1f GB, %.1f GB are free)\n", need / 1e9, (double)fr / 1e9);
+	}
 	/* the batched gradient exists for pow-exp (literal or exact) and for Matern with the corrected forms (gpemu.h modes) */
 	if (options->cov_fn_index != POWEREXPCOVFN && gpemu_host_modes() != (GPEMU_MODE_EXACT_GRAD | GPEMU_MODE_MATERN_LOG)) lockstep = 1;
 	const int total = njobs * restarts;             /* the run list */

@@ -2,7 +2,9 @@
 """profiles/*_pmc_hbm_traffic.txt (tools/rocpd_pmc.py output of one FETCH_SIZE and one WRITE_SIZE pass) -> the JSON
 bench.py reads `roofline.traffic` from.  rocprofv3 reports both counters in KB; on gfx950 FETCH_SIZE counts half the
 bytes of the reads these kernels issue (MI355X_MICROARCH.md; profiles/r01_pmc_fetch_calibration.txt), WRITE_SIZE is exact.
-usage: python tools/pmc_traffic_json.py profiles/r03_pmc_hbm_traffic.txt "<workload note>" > profiles/r03_pmc_hbm_traffic.json"""
+usage: python tools/pmc_traffic_json.py profiles/r04_pmc_hbm_traffic.txt "<workload note>" [batches profiled, default 2] > profiles/r04_pmc_hbm_traffic.json
+bench.py takes `roofline.traffic` from the newest such file only if the launch count per batch recorded here equals the
+launch count of the dominant kernel in its own run (a stale file -- kernels or schedule changed since -- gives traffic: null)."""
 import json
 import re
 import sys
@@ -13,7 +15,8 @@ KEYS = [("gemm_nt_kernel<128, 128", "gemm_nt_kernel_128x128_8waves_dma"), ("gemm
 out = {"workload": sys.argv[2] if len(sys.argv) > 2 else "", "units": "rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB; converted to bytes here",
        "correction": "FETCH_SIZE x 2 on gfx950 (MI355X_MICROARCH.md; the 8-B/lane C-tile reads calibrate to the same half, "
                      "profiles/r01_pmc_fetch_calibration.txt); WRITE_SIZE exact; Infinity-Cache hits are counted: fabric traffic, "
-                     "an upper bound on HBM traffic", "source": sys.argv[1]}
+                     "an upper bound on HBM traffic", "source": sys.argv[1],
+       "batches_profiled": int(sys.argv[3]) if len(sys.argv) > 3 else 2, "batch_size": 16, "N": 8192}
 cur = None
 for line in open(sys.argv[1]):
     if not line.startswith(" "):
