@@ -68,6 +68,7 @@ struct GemmArgs {
 	int big_tiles;       // 128x128 tiles once a lock-step launch has this many of them (0: 1024)
 	int table_sb;        // XCD-blocked tile table for launches of >= 512 tiles: side of the super-blocks (0: off)
 	int force_cfg;       // test/bench hook: 2 = 64x64 tiles, 8 = 128x128 tiles, 0 = automatic
+	int keep_idle_waves; // 1: waves above the diagonal of a triangular update's diagonal tiles compute their (unread) output anyway (A/B switch)
 };
 
 // Schedule switches of ONE context: read from the environment once, when the context is created (INTEGRATION.md lists
@@ -80,6 +81,7 @@ struct Sched {
 	int factor_ahead = 1;        // GPEMU_FACTOR_AHEAD: the update's tile (0,0) factors the next diagonal block
 	int fill_gram = 1;           // GPEMU_FILL_GRAM: MFMA Gram form of the training fill
 	int kvec_gram = 1;           // GPEMU_KVEC_GRAM: MFMA Gram form of the prediction sweep's k-vectors
+	int idle_waves = 1;          // GPEMU_IDLE_WAVES: waves wholly above the diagonal of a diagonal tile issue no matrix instructions
 	int nb_top = 0;              // GPEMU_NB_TOP: outer panel width; 0 = automatic (512 for one matrix, 2048 / 1024 for a batch)
 	int split_rhs_rows = 1;      // GPEMU_SPLIT_RHS_ROWS: big-tile updates take the 64 right-hand-side rows in a launch of their own
 };

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 	// goes to the other workgroup of the CU.  (Not in the factor-ahead tile, whose LDS image is written by every wave.)
 	// (through readfirstlane: a wave-uniform value the compiler can branch on -- under an EXEC mask the matrix instructions
 	// would still be issued)
-	const bool idle = __builtin_amdgcn_readfirstlane((int)(g.tri && !(FA && g.fa && tm == 0 && tn == 0) &&
+	const bool idle = __builtin_amdgcn_readfirstlane((int)(g.tri && !g.keep_idle_waves && !(FA && g.fa && tm == 0 && tn == 0) &&
 	                                                     (tn * BN + wn * WN > tm * BM + wm * WM + WM - 1 + g.diag_off))) != 0;
 	d4_t acc[TM][TN];
 	if (idle) {
