@@ -217,7 +217,7 @@ def test_interactive_mode_stream_lone_points_and_binary_framing(tmp_path):
     assert np.max(np.abs(vals[:n16, :, 0] - g2["g6_mean"])) < 1e-8 * max(1.0, np.abs(g2["g6_mean"]).max())
     assert np.max(np.abs(vals[:n16, :, 1] - g2["g6_var"])) < 1e-8 * max(1e-3, np.abs(g2["g6_var"]).max())
     stats = [l for l in p.stderr.decode().splitlines() if l.startswith("# interactive stats")]
-    assert stats and int(stats[0].split()[4]) == 40000 and int(stats[0].split()[8]) == 16384      # points, max_batch
+    assert stats and int(stats[0].split()[4]) == 40000 and int(stats[0].split()[8]) >= 256       # points; waiting points ride in batches
     # one point at a time, each answer waited for
     q = subprocess.Popen([cli, "interactive_mode", G6SNAP, "-q"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     for i in list(range(5)) + [20000, 39999]:
