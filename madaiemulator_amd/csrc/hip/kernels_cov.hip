@@ -17,13 +17,17 @@ namespace gpemu {
 constexpr int FT = 64;            // fill tile edge
 constexpr int DCH = 8;            // dimensions handled per register chunk
 
-// VALU fp64 issues at 16 cycles per wave-instruction on gfx950 (measured), so the fill is bound by its
-// fp64 operation count, not by the 8 bytes it writes per element.  Everything below is about fewer fp64 ops:
-// coordinates are pre-scaled while staging (2 ops per dimension), exp and sqrt are short table / Newton
-// forms, and the exact "same point" test of the nugget rule runs only for pairs whose distance makes it possible.
+// What bounds the fill is its VECTOR INSTRUCTION COUNT per element, all kinds together (fp64 arithmetic, the integer work of
+// the exponent and table index, selects, address arithmetic), not the 8 bytes it writes: an fp64 VALU instruction issues
+// every ~4.8 cycles per SIMD when enough independent work is in flight, ~10 when it depends on its predecessor
+// (scratch/mb/fma_rate.hip, profiles/r04_fp64_fma_issue_rate.txt: 58-65 TFLOP/s of FMAs with >= 4 independent chains or
+// waves per SIMD, 30 with one -- rounds 1-3 assumed 16 cycles throughout), and the Matern 5/2 element of round 3 compiled to
+// 33 vector instructions of which 17 were fp64 arithmetic.  Everything below is about fewer instructions: coordinates are
+// pre-scaled while staging, exp and sqrt are short table / Newton forms, the exact "same point" test of the nugget rule
+// runs only for pairs whose distance makes it possible, and the common path carries no select for it at all.
 
 // exp(x) for x <= 0: x = (64 m + j) ln2/64 + r, |r| <= ln2/128; exp = 2^m * 2^(j/64) * P5(r) (truncation 4e-17), ~1 ulp.
-// 11 fp64 VALU operations (16 cycles each on gfx950): the rounding to an integer is the 1.5 * 2^52 addition (the integer
+// 11 fp64 VALU operations: the rounding to an integer is the 1.5 * 2^52 addition (the integer
 // sits in the low mantissa word: no rint, no convert), the scaling by 2^m an integer add on the exponent field (no
 // ldexp).  Arguments below -700 are treated as -700 (1e-304: the result stays a normal number for the exponent add).
 constexpr int EXP_TAB = 64;
@@ -191,7 +195,7 @@ __device__ __forceinline__ void cov_fill_tile(double *out, long ld, const double
 // ---------------------------------------------------------------------------
 // Gram form of the same tile for the square training matrix (Xr = Xc = the design): the squared scaled distances of
 // a 64 x 64 tile come from the fp64 MFMA as  |x'|^2 + |y'|^2 - 2 x'.y'  -- the 2d subtract/FMA wave-instructions per
-// element of the difference form (16 of its ~45 at d = 8, each 16 cycles on the fp64 VALU) become d/4 + 1 matrix
+// element of the difference form (16 of its ~45 at d = 8) become d/4 + 1 matrix
 // instructions per 256 elements on the other pipe.  x' = (x - mid) w: Xg holds the design centred per dimension
 // (host, set_model), so |x'| is half the scaled range.  The host enables this form (p.gram) only while
 // sum_k (w_k halfrange_k)^2 <= 16: the cancellation error in the squared distance, a few ulp of |x'|^2 + |y'|^2, then
@@ -363,7 +367,7 @@ __device__ __forceinline__ void cov_fill_tile_gram_k(double *out, long ld, const
 				if (RECT && v < 1E-10) v = 0.0;                                           // emulator.c:588-590 (k-vectors are always clamped)
 				orow[16 * j] = v;
 				// two elements at a time: a dependent fp64 operation can issue as soon as its predecessor has gone through the
-				// pipe (16 cycles either way), so interleaving more chains buys nothing and costs registers -- sixteen
+				// pipe, so with six waves per SIMD interleaving more chains per wave buys nothing and costs registers -- sixteen
 				// interleaved exp/sqrt chains need 256 VGPRs, two fit 80 and leave six waves per SIMD to cover the loads
 				if (j & 1) __builtin_amdgcn_sched_barrier(0);
 			}

@@ -629,8 +629,9 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs &a_in)
 //  leaf_factor_kernel (1 workgroup, 4 waves): the block sits in LDS and is
 //    factored in four 16-column panels.  A panel is factored by wave 0, one
 //    matrix row per lane, 16 VGPR pairs, SGPR (readlane) broadcasts, no LDS in
-//    the pivot chain; VALU fp64 issues at 16 cycles per wave-instruction on
-//    gfx950 (a quarter of the MFMA rate, measured), so everything outside the
+//    the pivot chain; a DEPENDENT fp64 VALU instruction of a lone wave issues every
+//    ~10 cycles on gfx950 (scratch/mb/fma_rate.hip: 4.8 with enough independent
+//    work, which a pivot chain does not have), so everything outside the
 //    panel -- the rank-16 trailing updates -- runs on the MFMA across all four
 //    waves.  1/sqrt is the hardware estimate plus two Newton steps.  A pivot
 //    <= 0 (or NaN) records its 1-based global index in *info (atomicMin) --
@@ -768,7 +769,7 @@ __global__ __launch_bounds__(256) void leaf_factor_kernel(double *T, long ld, in
 	trace_end(trace, tr0);
 }
 
-// 1/x: hardware estimate + two Newton steps (an fp64 divide costs ~10 dependent VALU ops at 16 cycles each)
+// 1/x: hardware estimate + two Newton steps (an fp64 divide costs ~10 more dependent VALU operations of ~10 cycles each)
 __device__ __forceinline__ double fast_rcp(double x)
 {
 	double y = __builtin_amdgcn_rcp(x);
