@@ -1182,8 +1182,12 @@ extern "C" int gpemu_get_cinverse(gpemu_ctx *ctx, double *cinv_out)
 	HIPCHK(ctx, hipMemcpy2DAsync(cinv_out, (size_t)N * sizeof(double), ctx->dS + (size_t)Rp * dim + Rp,
 	                             dim * sizeof(double), (size_t)N * sizeof(double), N, hipMemcpyDeviceToHost, ctx->stream));
 	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-	for (int i = 0; i < N; i++)
-		for (int j = i + 1; j < N; j++) cinv_out[(size_t)i * N + j] = cinv_out[(size_t)j * N + i];
+	// mirror the lower triangle into the upper one, 64 x 64 blocks at a time (a plain column walk over 512 MB at N = 8192
+	// misses the cache on every element: 0.3 s of alloc_emulator_struct's 0.4)
+	for (int i0 = 0; i0 < N; i0 += 64)
+		for (int j0 = i0; j0 < N; j0 += 64)
+			for (int i = i0; i < std::min(i0 + 64, N); i++)
+				for (int j = std::max(j0, i + 1); j < std::min(j0 + 64, N); j++) cinv_out[(size_t)i * N + j] = cinv_out[(size_t)j * N + i];
 	return GPEMU_OK;
 }
 

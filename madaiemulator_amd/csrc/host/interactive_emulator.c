@@ -114,6 +114,9 @@ static int interactive_mode(struct cmdLineOpts *o)
 	FILE *fp = fopen(o->statefile, "r");
 	if (!fp) return perr("Error opening file");
 	const double t_start = wall_s();
+	/* nobody in this program reads emulator_struct.cinverse (the reference's interactive_mode does not either): spare every
+	 * component the N x N download (512 MB at N = 8192) -- the library keeps filling it for callers that link libEmu */
+	setenv("GPEMU_SKIP_CINVERSE", "1", 0);
 	multi_modelstruct *model = load_multi_modelstruct(fp);
 	fclose(fp);
 	const double t_loaded = wall_s();

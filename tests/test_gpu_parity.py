@@ -173,6 +173,37 @@ def test_kvectors_with_clamp(gpu_ctx, kind):
     assert relerr(got, ref) < ELEM_RTOL
 
 
+@pytest.mark.parametrize("kind", [1, 2, 3])
+@pytest.mark.parametrize("N,d,M", [(300, 8, 200), (130, 3, 77), (64, 1, 64)])
+def test_kvectors_gram_form(gpu_ctx, kind, N, d, M):
+    """a16 in the MFMA Gram form (cov_kvec_gram_kernel, the prediction sweep's k-vector fill since round 4) at length
+    scales that admit it: queries inside the design's box, queries EQUAL to training points (the nugget rule of
+    emulator.c:136-150 / :368-384 applies to k-vectors too), queries within 5e-11 of one (still "the same point" for
+    pow-exp), and queries far outside the box -- a wave that holds such a row leaves the Gram form and takes exact
+    differences -- against the oracle's makeKVector_fnptr (emulator.c:578-593, clamp included) at 1e-13, zero pattern
+    equal; ragged M and N (padding rows and columns stay out of the result)."""
+    X, y = synth.design(N, d, 31 + N)
+    th = thetas_for(kind, d)
+    Xq = synth.queries(M, d, 6)
+    Xq[3] = X[5]
+    Xq[4] = X[N - 1]
+    Xq[5] = X[7] + 5e-11
+    Xq[6] = X[9] + 3.0                       # outside: |x'|^2 > 16 for the default length scales
+    Xq[7] = -20.0
+    Xq[M - 1] = X[0]
+    Xq[40:44] = 1.0 + 0.5 * synth.queries(4, d, 8)     # a whole 16-row group of one wave mildly outside
+    gpu_ctx.set_model(kind, 0, X, y)
+    got = gpu_ctx.kvectors(th, Xq)
+    ref = np.vstack([O.kvector(kind, X, q, th) for q in Xq])
+    nug = np.exp(th[1]) if kind == 1 else th[1]
+    amp = np.exp(th[0]) if kind == 1 else th[0]
+    assert ref[3, 5] == pytest.approx(amp + nug, rel=1e-15) and ref[M - 1, 0] == pytest.approx(amp + nug, rel=1e-15)
+    assert np.array_equal(got == 0.0, ref == 0.0)
+    nz = ref != 0.0
+    assert np.max(np.abs(got[nz] - ref[nz]) / ref[nz]) < ELEM_RTOL
+    assert np.all(got[7] == 0.0) or kind != 1           # twenty length scales away: below the clamp (pow-exp)
+
+
 # ------------------------------------------------------------------ a7-a11: likelihood
 def check_loglik(gpu_ctx, kind, order, X, y, th_full):
     gpu_ctx.set_model(kind, order, X, y)
