@@ -276,6 +276,42 @@ def interactive_cli_region(kind, N, d, order, seed, dev, nq, check):
     return out
 
 
+def pca8_emulator_cli(dev, npts=100000):
+    """the QUERY side of BASELINE configs[3] through the drop-in: a MODEL_SNAPSHOT_FILE of the N=4096, d=16, t=9 -> 8 PCA
+    component model at supplied thetas, `interactive_emulator interactive_mode -q` on `npts` points: what
+    alloc_multi_emulator (multivar_support.c:30-52: eight alloc_emulator_struct) costs at start-up and how fast
+    emulate_point_multi's batched form (eight component sweeps + the back-projection to 9 outputs, :103-157) answers"""
+    import subprocess
+    import tempfile
+    from madaiemulator_amd import build, synth
+    N, d, nt = 4096, 16, 9
+    X, y = synth.design(N, d, 20261003 + 3)
+    Y = synth.multi_outputs(X, y, nt)
+    Z, evals, evecs, ybar = synth.pca_zmatrix(Y)
+    nr = Z.shape[1]
+    ths = [synth.perturbed_thetas(1, d, 77, c) for c in range(nr)]
+    with tempfile.TemporaryDirectory(prefix="gpemu_bench_") as tmp:
+        snap, qf, res = os.path.join(tmp, "snap.txt"), os.path.join(tmp, "q.txt"), os.path.join(tmp, "out.txt")
+        open(snap, "w").write(synth.snapshot_text(X, Y, evals, evecs, Z, 1, 0, ths))
+        np.savetxt(qf, synth.queries(npts, d, 5), fmt="%.17g")
+        env = dict(os.environ, GPEMU_DEVICE=str(dev), GPEMU_IO_STATS="1")
+        try:
+            p = subprocess.run([build.CLI_BIN, "interactive_mode", snap, "-q"], stdin=open(qf, "rb"), stdout=open(res, "wb"),
+                               stderr=subprocess.PIPE, env=env, timeout=600)
+        except (subprocess.TimeoutExpired, OSError) as ex:
+            return {"error": repr(ex)[:300]}
+        st = _io_stats(p.stderr.decode(errors="replace"))
+        if p.returncode != 0 or not st or st["points"] != npts:
+            return {"error": p.stderr.decode(errors="replace")[-600:]}
+        vals = np.loadtxt(res, max_rows=2 * nt * 256).reshape(-1, nt, 2)
+        assert np.all(np.isfinite(vals)) and np.all(vals[:, :, 1] > 0.0)
+        return {"components": st["components"], "outputs": nt, "load_snapshot_s": st["load_snapshot_s"],
+                "alloc_multi_emulator_s": st["alloc_multi_emulator_s"], "points": npts,
+                "points_per_s": npts / st["loop_wall_s"], "component_predictions_per_s": nr * npts / st["loop_wall_s"],
+                "stage_busy_s": {"read_parse": st["parse_s"], "device": st["device_s"], "format_write": st["format_s"]},
+                "workload": f"N={N}, d={d}, {nt} outputs back-projected from {nr} PCA components; interactive_mode -q, text protocol"}
+
+
 def pca8_region(abi, shard, synth, dev, rank, world_size, steps, barrier, reduce_max):
     """region E (BASELINE configs[3]): N=4096, d=16, t=9 outputs -> 8 PCA components (multi_modelstruct.c:172-338), each an
     independent scalar GP on the shared design; component c -> rank c mod W.  Every component runs `steps` lock-step
@@ -797,6 +833,8 @@ def main():
     if not args.no_pca8:
         pca8 = pca8_region(abi, shard, synth, dev, rank, world_size, args.pca8_steps, barrier,
                            (lambda t: allreduce_max(t)) if distributed else (lambda t: t))
+        if rank == 0 and ngpus == 1 and not args.no_interactive:
+            pca8["emulator_through_cli"] = pca8_emulator_cli(dev)
         note("region E (8 PCA components) done")
     # ---- roofline of the prediction GEMM (the likelihood rooflines were taken right behind region A)
     if rank == 0:

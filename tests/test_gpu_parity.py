@@ -1130,6 +1130,25 @@ def test_maximum_dimensions(gpu_ctx):
     th = thetas_for(1, 31)
     th[2:] = np.log(2.0)
     check_loglik(gpu_ctx, 1, 2, X, y, th)                 # nreg = 1 + 2*31 = 63: y and H fill all 64 augmented rows
+    # the gradient kernels at d = 64: 130 sums per tile (nine block sums of 8 directions), 111 KB of dynamic LDS (beyond the
+    # 64 KB a kernel gets without asking), literal and exact form against the oracle / tests/gradref.py; Gram-form k-vectors
+    import gradref
+    X, y = synth.design(200, 64, 77)
+    th = thetas_for(1, 64)
+    th[2:] = np.log(3.0) + 0.01 * np.arange(64)
+    c = abi.Context(0)
+    c.set_model(1, 1, X, y)
+    g, rc = c.grad(th)
+    ref, st = O.grad_fn_multi(1, 1, X, y, th[1:])
+    assert rc == 0 and st == 0 and np.max(np.abs(g - ref)) < RTOL * np.max(np.abs(ref))
+    c.set_mode(abi.MODE_EXACT_GRAD)
+    ge, rc = c.grad(th)
+    assert rc == 0 and np.max(np.abs(ge - gradref.value_and_gradients(X, y, 1, th)["exact"])) < RTOL * np.max(np.abs(ge))
+    Xq = synth.queries(70, 64, 3)
+    kv = c.kvectors(th, Xq)
+    kref = np.vstack([O.kvector(1, X, q, th) for q in Xq])
+    assert np.array_equal(kv == 0.0, kref == 0.0) and relerr(kv, kref) < ELEM_RTOL
+    c.close()
 
 def test_predict_enqueue_collect_on_several_contexts(gpu_ctx):
     """the asynchronous halves of gpemu_predict_batch: three contexts (PCA components of one design) are all started

@@ -181,6 +181,25 @@ def test_snapshot_golden_g7_roundtrips_byte_for_byte(driver, tmp_path):
     assert out.read_bytes() == open(G6SNAP, "rb").read()
 
 
+def test_harness_snapshot_writer_is_the_products_dump_byte_for_byte(driver, tmp_path):
+    """synth.snapshot_text / single_output_snapshot (what bench.py's interactive_mode regions feed the CLI: a
+    MODEL_SNAPSHOT_FILE at SUPPLIED thetas) written in the reference's grammar and printf formats
+    (multi_modelstruct.c:346-401, modelstruct.c:375-409): load_multi_modelstruct -> dump_multi_modelstruct reproduces the
+    file byte for byte, for a 4-component multi-output model and for a scalar Matern model.  Host code only."""
+    X, y = synth.design(256, 4, 3)
+    Y = synth.multi_outputs(X, y, 5)
+    Z, evals, evecs, _ = synth.pca_zmatrix(Y)
+    ths = [synth.perturbed_thetas(1, 4, 77, c) for c in range(Z.shape[1])]
+    a, b = tmp_path / "multi.txt", tmp_path / "multi_again.txt"
+    a.write_text(synth.snapshot_text(X, Y, evals, evecs, Z, 1, 0, ths))
+    assert "nt 5 nr 4 N 256 d 4" in run([driver, "roundtrip", str(a), str(b)])
+    assert a.read_bytes() == b.read_bytes()
+    c, d_ = tmp_path / "single.txt", tmp_path / "single_again.txt"
+    c.write_text(synth.single_output_snapshot(X, y, 3, 1, synth.default_thetas(3, 4)))
+    assert "nt 1 nr 1 N 256 d 4" in run([driver, "roundtrip", str(c), str(d_)])
+    assert c.read_bytes() == d_.read_bytes()
+
+
 @pytest.mark.gpu
 def test_multi_output_golden_g6_through_the_c_layer(driver, tmp_path):
     """G6: load the fixture snapshot, alloc_multi_emulator, emulate_point_multi at the fixture's 16 queries (13 random +
