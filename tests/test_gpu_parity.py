@@ -1137,13 +1137,13 @@ def test_maximum_dimensions(gpu_ctx):
     th = thetas_for(1, 64)
     th[2:] = np.log(3.0) + 0.01 * np.arange(64)
     c = abi.Context(0)
-    c.set_model(1, 1, X, y)
+    c.set_model(1, 0, X, y)
     g, rc = c.grad(th)
-    ref, st = O.grad_fn_multi(1, 1, X, y, th[1:])
+    ref, st = O.grad_fn_multi(1, 0, X, y, th[1:])
     assert rc == 0 and st == 0 and np.max(np.abs(g - ref)) < RTOL * np.max(np.abs(ref))
     c.set_mode(abi.MODE_EXACT_GRAD)
     ge, rc = c.grad(th)
-    assert rc == 0 and np.max(np.abs(ge - gradref.value_and_gradients(X, y, 1, th)["exact"])) < RTOL * np.max(np.abs(ge))
+    assert rc == 0 and np.max(np.abs(ge - gradref.value_and_gradients(X, y, 0, th)["exact"])) < RTOL * np.max(np.abs(ge))
     Xq = synth.queries(70, 64, 3)
     kv = c.kvectors(th, Xq)
     kref = np.vstack([O.kvector(1, X, q, th) for q in Xq])
