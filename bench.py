@@ -89,22 +89,34 @@ def usable_cores():
     return n, quota
 
 
-def cpu_baseline(kind, order, N, d, seed):
+def cpu_baseline(kind, order, N, d, seed, sizes=(1024, 1536, 2048)):
     """Reference-faithful CPU restatement (oracle/, kind "port") on the host cores: one independent evaluation
     per core, the reference's own parallelisation (estimate_threaded.c:97,172).  Bounded samples at N_s < N
-    (1024, 1536, 2048: about a minute of wall time), a power-law fit over them, and the N^3 extrapolation from the
-    largest one (the path is N^3: unblocked Cholesky + explicit inverse) as the reported value."""
+    (default 1024, 1536, 2048: about a minute of wall time; `--cpu-sizes` adds larger ones for a one-off run), a power-law
+    fit over them, and the N^3 extrapolation from the largest one (the path is N^3: unblocked Cholesky + explicit
+    inverse) as the reported value."""
     from oracle import oracle as O
     O.build()
     cores, quota = usable_cores()
-    sizes = [1024, 1536, 2048]
+    sizes = sorted(int(v) for v in sizes)
     t0 = time.perf_counter()
     per = {}
+
+    def wait(res, what):
+        # (a heartbeat on stderr: a sample at N = 4096 runs for many minutes and a silent command is taken for hung)
+        t_ = time.perf_counter()
+        while not res.ready():
+            res.wait(60.0)
+            if not res.ready():
+                print(f"[bench] cpu baseline: {what} still running after {time.perf_counter() - t_:.0f} s", file=sys.stderr, flush=True)
+        return res.get()
     with mp.get_context("spawn").Pool(cores) as pool:
-        alone = pool.map(_cpu_eval_worker, [(kind, order, sizes[1], d, seed, 0)])[0]      # one core, the others idle
-        print(f"[bench] cpu baseline: one evaluation alone at N={sizes[1]}: {alone:.1f} s", file=sys.stderr, flush=True)
+        mid = sizes[min(1, len(sizes) - 1)]
+        alone = wait(pool.map_async(_cpu_eval_worker, [(kind, order, mid, d, seed, 0)]), f"one alone at N={mid}")[0]      # one core, the others idle
+        print(f"[bench] cpu baseline: one evaluation alone at N={mid}: {alone:.1f} s", file=sys.stderr, flush=True)
         for Ns in sizes:
-            per[Ns] = float(np.mean(pool.map(_cpu_eval_worker, [(kind, order, Ns, d, seed, i) for i in range(cores)])))
+            per[Ns] = float(np.mean(wait(pool.map_async(_cpu_eval_worker, [(kind, order, Ns, d, seed, i) for i in range(cores)]),
+                                         f"{cores} concurrent at N={Ns}")))
             print(f"[bench] cpu baseline: {cores} concurrent at N={Ns}: {per[Ns]:.1f} s each", file=sys.stderr, flush=True)
     wall = time.perf_counter() - t0
     Ns = sizes[-1]
@@ -112,6 +124,7 @@ def cpu_baseline(kind, order, N, d, seed):
     scale = (N / Ns) ** 3
     evals_per_s = cores / (per_eval * scale)
     # t = c N^p over the three samples (least squares in log-log): p > 3 once the matrices leave the caches
+    sizes = list(sizes)
     lx, ly = np.log(np.array(sizes, float)), np.log(np.array([per[n] for n in sizes]))
     pfit, cfit = np.polyfit(lx, ly, 1)
     fit_eval_s = float(np.exp(cfit) * N ** pfit)
@@ -127,13 +140,13 @@ def cpu_baseline(kind, order, N, d, seed):
         "value": evals_per_s, "unit": "likelihood-evals/s", "cores": cores, "nproc": os.cpu_count(),
         "cgroup_cpu_quota": quota, "kind": "port",
         "sample": (f"{cores} concurrent oracle evaluations (one per core) at N={sizes}, d={d}: "
-                   f"{', '.join('%.2f' % per[n] for n in sizes)} s each ({wall:.1f} s wall in all); one alone at N={sizes[1]}: "
-                   f"{alone:.2f} s; value = N={Ns} sample extrapolated to N={N} by (N/{Ns})^3; power-law fit over the three "
+                   f"{', '.join('%.2f' % per[n] for n in sizes)} s each ({wall:.1f} s wall in all); one alone at N={mid}: "
+                   f"{alone:.2f} s; value = N={Ns} sample extrapolated to N={N} by (N/{Ns})^3; power-law fit over the {len(sizes)} "
                    f"samples t ~ N^{pfit:.2f} gives {fit_eval_s:.0f} s per evaluation at N={N}; predictions: 4 oracle "
                    f"emulate_point calls at N={Ns} ({per_q*1e3:.1f} ms each) scaled by (N/{Ns})^2"),
         "seconds_per_eval_at_samples": {str(n): per[n] for n in sizes}, "fit_exponent": float(pfit),
         "value_from_fit": cores / fit_eval_s,
-        "value_1core": 1.0 / (alone * (N / sizes[1]) ** 3), "seconds_per_eval_alone": {str(sizes[1]): alone},
+        "value_1core": 1.0 / (alone * (N / mid) ** 3), "seconds_per_eval_alone": {str(mid): alone},
         "predictions_per_s_1core": 1.0 / (per_q * (N / Ns) ** 2),
         "predictions_per_s": preds_per_s,
     }
@@ -383,6 +396,9 @@ def main():
                          "form of the reference's restart threads / callEvalLhoodList); 1 = one matrix per launch; "
                          "default 16 at N >= 8192, up to 64 for smaller models (the panel chain weighs more there)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sizes", default="1024,1536,2048",
+                    help="sample sizes of the CPU baseline (one oracle evaluation per core at each); the default takes about a "
+                         "minute, adding 4096 about a quarter of an hour")
     ap.add_argument("--no-predict", action="store_true")
     ap.add_argument("--no-grad", action="store_true", help="skip the value+gradient region")
     ap.add_argument("--no-single", action="store_true", help="skip the one-evaluation-at-a-time latency figure")
@@ -851,7 +867,7 @@ def main():
     note("roofline sections done")
     cpu = None
     if rank == 0 and ngpus == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(kind, order, N, d, seed)
+        cpu = cpu_baseline(kind, order, N, d, seed, [int(v) for v in args.cpu_sizes.split(",")])
 
     if rank == 0:
         out = {
