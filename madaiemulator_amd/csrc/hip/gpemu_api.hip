@@ -151,6 +151,7 @@ static Sched read_environment()
 	sc.gemm_table = v >= 0 && v <= 64 ? v : 8;
 	sc.fill_gram = geti("GPEMU_FILL_GRAM", 1) != 0;
 	sc.kvec_gram = geti("GPEMU_KVEC_GRAM", 1) != 0;
+	sc.gemv_point = geti("GPEMU_GEMV_POINT", 1) != 0;
 	sc.idle_waves = geti("GPEMU_IDLE_WAVES", 1) != 0;
 	sc.factor_ahead = geti("GPEMU_FACTOR_AHEAD", 1) != 0;
 	v = geti("GPEMU_NB_TOP", 0);
@@ -216,8 +217,9 @@ static void free_model(gpemu_ctx *ctx)
 {
 	free_graphs(ctx);
 	double **ptrs[] = {&ctx->dX, &ctx->dXg, &ctx->dMid, &ctx->dY, &ctx->dRrows, &ctx->dT, &ctx->dGramPart, &ctx->dLinvAug, &ctx->dBetaQ,
-	                   &ctx->dKq, &ctx->dV, &ctx->dXq, &ctx->dMean, &ctx->dVar, &ctx->dS, &ctx->dGradPart, &ctx->dAlpha};
+	                   &ctx->dKq, &ctx->dV, &ctx->dXq, &ctx->dMean, &ctx->dS, &ctx->dGradPart, &ctx->dAlpha};
 	for (auto p : ptrs) { if (*p) hipFree(*p); *p = nullptr; }
+	ctx->dVar = nullptr;                      // (the second half of dMean's allocation)
 	ctx->T_rows = 0; ctx->pred_ready = false; ctx->cinv_ready = false; ctx->pred_batch = 0; ctx->stage_cap = 0;
 	ctx->pred_pending = 0;
 	ctx->S_dim = 0; ctx->S_cap = 0; ctx->gradpart_len = 0; ctx->alpha_cap = 0;
@@ -1036,10 +1038,6 @@ extern "C" int gpemu_predict_batch_dev(gpemu_ctx *ctx, int M, const double *xq_d
 	for (int q0 = 0; q0 < M; q0 += cap) {
 		const int mb = std::min(cap, M - q0);
 		const int mbp = round_up(mb, 64);
-		{
-			ProfScope ps(ctx, GPEMU_PROF_FILL, 0.0, 8.0 * (double)mbp * Np);
-			HIPCHK(ctx, fill_kvectors(ctx, ctx->dKq, xq_dev + (size_t)q0 * d, mb, mbp, ctx->pred_cov));
-		}
 		GemmArgs g;
 		memset(&g, 0, sizeof g);
 		g.C = ctx->dV; g.ldc = Np + Rp;
@@ -1056,14 +1054,32 @@ extern "C" int gpemu_predict_batch_dev(gpemu_ctx *ctx, int M, const double *xq_d
 			if (tiles < 1024) nslice = (int)std::max(1L, std::min((long)std::min(PRED_SPLIT_MAX, Np / 512), 2048 / tiles));
 			if ((long)nslice * mbp > 128L * PRED_SPLIT_MAX) nslice = 1;       // capacity of dV for the partial products
 		}
+		// up to 16 queries with a long contraction (emulate_point: ONE query): the few-queries path -- a one-thread-per-design-
+		// point k-vector kernel, the skinny split-K product, an epilogue with the slice sums fused in (three launches; the batch
+		// kernels would set up their tables and tiles for 63 padding rows: 16 + 93 + 6 + 20 us of kernels at N = 8192)
+		const bool few = mb <= 16 && nslice > 1;
+		if (!few) {
+			ProfScope ps(ctx, GPEMU_PROF_FILL, 0.0, 8.0 * (double)mbp * Np);
+			HIPCHK(ctx, fill_kvectors(ctx, ctx->dKq, xq_dev + (size_t)q0 * d, mb, mbp, ctx->pred_cov));
+		} else {
+			HIPCHK(ctx, launch_kvec_small(ctx->stream, ctx->dKq, Np, xq_dev + (size_t)q0 * d, mb, ctx->dX, N, Np, d, ctx->pred_cov));
+		}
 		if (nslice > 1) { g.ksplit = nslice; g.bsC = (long)mbp * (Np + Rp); }
-		if (mb <= 16 && nslice > 1) {
+		if (few) {
 			// up to 16 queries (emulate_point: one): the skinny kernel, one 16-row query tile, instead of 64-row GEMM
 			// tiles (97 vs 115 us at N=8192; from 17 queries on the split-K GEMM is as fast)
 			const int klen = (((Np + nslice - 1) / nslice) + 15) & ~15;
 			ProfScope ps(ctx, GPEMU_PROF_GEMM, gemm_flops(g), 0.0);
+			if (mb == 1 && ctx->sched.gemv_point)
+				// ONE query: a matrix-vector stream over whole rows of L^-1 instead of the matrix unit's 16-row reads
+				HIPCHK(ctx, launch_gemv_tri(ctx->stream, ctx->dKq, Np, ctx->dLinvAug, Np, ctx->dV, Np + Rp, (long)mbp * (Np + Rp),
+				                            1, Np + Rp, Np, Np, nslice, klen));
+			else
 			HIPCHK(ctx, launch_skinny_nt(ctx->stream, ctx->dKq, Np, ctx->dLinvAug, Np, ctx->dV, Np + Rp, (long)mbp * (Np + Rp),
 			                             1, Np + Rp, Np, Np, nslice, klen));
+			HIPCHK(ctx, launch_predict_finish_small(ctx->stream, ctx->dV, Np + Rp, (long)mbp * (Np + Rp), nslice, mb, Np, ctx->nreg, d,
+			                                        xq_dev + (size_t)q0 * d, ctx->dBetaQ, ctx->kappa, mean_dev + q0, var_dev + q0));
+			continue;
 		} else if (nslice == 1 && ctx->sched.split_rhs_rows && gemm_uses_big_tiles(g)) {
 			// 128x128 tiles: the 64 columns of gamma and W^T behind the Np triangular ones would make a 65th tile column that is
 			// half empty at the full contraction length (1.5 % of the sweep's tile time): they go to a 64x64-tile launch of
@@ -1098,13 +1114,12 @@ extern "C" int gpemu_predict_batch_enqueue(gpemu_ctx *ctx, int M, const double *
 		HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 		if (ctx->dXq) hipFree(ctx->dXq);
 		if (ctx->dMean) hipFree(ctx->dMean);
-		if (ctx->dVar) hipFree(ctx->dVar);
 		if (ctx->hStage) hipHostFree(ctx->hStage);
 		ctx->dXq = ctx->dMean = ctx->dVar = nullptr; ctx->hStage = nullptr; ctx->stage_cap = 0;
 		const int cap = std::max(M, 64);
 		HIPCHK(ctx, hipMalloc(&ctx->dXq, (size_t)cap * d * sizeof(double)));
-		HIPCHK(ctx, hipMalloc(&ctx->dMean, (size_t)cap * sizeof(double)));
-		HIPCHK(ctx, hipMalloc(&ctx->dVar, (size_t)cap * sizeof(double)));
+		HIPCHK(ctx, hipMalloc(&ctx->dMean, (size_t)2 * cap * sizeof(double)));    // means, then variances (one allocation: a small
+		ctx->dVar = ctx->dMean + cap;                                             // batch comes back in ONE copy)
 		HIPCHK(ctx, hipHostMalloc((void **)&ctx->hStage, (size_t)cap * (d + 2) * sizeof(double)));
 		ctx->stage_cap = cap;
 	}
@@ -1113,8 +1128,13 @@ extern "C" int gpemu_predict_batch_enqueue(gpemu_ctx *ctx, int M, const double *
 	HIPCHK(ctx, hipMemcpyAsync(ctx->dXq, hx, (size_t)M * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
 	int rc = gpemu_predict_batch_dev(ctx, M, ctx->dXq, ctx->dMean, ctx->dVar);
 	if (rc) return rc;
-	HIPCHK(ctx, hipMemcpyAsync(hm, ctx->dMean, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-	HIPCHK(ctx, hipMemcpyAsync(hv, ctx->dVar, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+	if (ctx->stage_cap <= 1024) {
+		// (hm | hv on the host and dMean | dVar on the device have the same layout, stage_cap entries apart)
+		HIPCHK(ctx, hipMemcpyAsync(hm, ctx->dMean, ((size_t)ctx->stage_cap + M) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+	} else {
+		HIPCHK(ctx, hipMemcpyAsync(hm, ctx->dMean, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+		HIPCHK(ctx, hipMemcpyAsync(hv, ctx->dVar, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+	}
 	ctx->pred_pending = M;
 	return GPEMU_OK;
 }

@@ -81,6 +81,7 @@ struct Sched {
 	int factor_ahead = 1;        // GPEMU_FACTOR_AHEAD: the update's tile (0,0) factors the next diagonal block
 	int fill_gram = 1;           // GPEMU_FILL_GRAM: MFMA Gram form of the training fill
 	int kvec_gram = 1;           // GPEMU_KVEC_GRAM: MFMA Gram form of the prediction sweep's k-vectors
+	int gemv_point = 1;          // GPEMU_GEMV_POINT: ONE query takes the matrix-vector kernel instead of the skinny MFMA product
 	int idle_waves = 1;          // GPEMU_IDLE_WAVES: waves wholly above the diagonal of a diagonal tile issue no matrix instructions
 	int nb_top = 0;              // GPEMU_NB_TOP: outer panel width; 0 = automatic (512 for one matrix, 2048 / 1024 for a batch)
 	int split_rhs_rows = 1;      // GPEMU_SPLIT_RHS_ROWS: big-tile updates take the 64 right-hand-side rows in a launch of their own
@@ -212,6 +213,12 @@ hipError_t launch_transpose(hipStream_t s, double *dst, long ldd, const double *
 hipError_t launch_predict_finish(hipStream_t s, const double *V, long ldv, int M, int Np, int nreg, int order, int d,
                                  const double *Xq, const double *betaQ, double kappa, double *mean, double *var,
                                  int nslice = 1, long sstride = 0);
+// the few-queries path of the prediction sweep (emulate_point): k-vectors of up to 16 queries, one thread per design point; the
+// epilogue with the slice sums fused in, one workgroup per query
+hipError_t launch_kvec_small(hipStream_t s, double *Kq, long ld, const double *Xq, int M, const double *X, int N, int Np, int d,
+                             const CovParams &p);
+hipError_t launch_predict_finish_small(hipStream_t s, const double *Vp, long ldv, long sstride, int nslice, int M, int Np, int nreg,
+                                       int d, const double *Xq, const double *betaQ, double kappa, double *mean, double *var);
 hipError_t launch_grad_partials(hipStream_t s, const double *S, long lds, int soff, long sstride, int nb, const double *X, int N,
                                 int d, double *ag, int np_pad, long gstride, double *part, long pstride, int *nparts,
                                 int exact_kind = 0, int nbeta = 0, const CovParams *pp_dev = nullptr, bool lit_noclamp = false);
@@ -227,6 +234,8 @@ hipError_t launch_trace_product(hipStream_t s, const double *A, const double *B,
 hipError_t launch_gemm(hipStream_t s, const GemmArgs &a);
 hipError_t launch_skinny_nt(hipStream_t s, const double *Kq, long ldk, const double *L, long ldl, double *Vp, long ldv,
                             long sstride, int tq, int ntot, int K, int ntri, int nslice, int klen);
+hipError_t launch_gemv_tri(hipStream_t s, const double *Kq, long ldk, const double *L, long ldl, double *Vp, long ldv,
+                           long sstride, int mq, int ntot, int K, int ntri, int nslice, int klen);
 std::vector<int> build_tile_table(int tiles_m, int tiles_n, int tri, int S, int bm = 128, int bn = 128);
 hipError_t launch_leaf(hipStream_t s, double *T, long ld, int c0, int m_below, int *info,
                        unsigned long long *trace_factor = nullptr, unsigned long long *trace_solve = nullptr,

@@ -722,6 +722,129 @@ __global__ __launch_bounds__(256) void predict_finish_kernel(const double *V, lo
 	}
 }
 
+// ---------------------------------------------------------------------------
+// A handful of queries (emulate_point: ONE -- the call an MCMC driver makes per sample, emulator_struct.c:124-143): the
+// 64-row tiles of the batch path would spend a table set-up and 63 padding rows on it.  One thread per design point instead
+// computes k_i = cov(x_i, x*_q) for the up to 16 queries (difference form, exact nugget test, clamp: makeKVector_fnptr,
+// emulator.c:578-593) and writes the 16 rows the skinny product reads (rows beyond M: zeros).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kvec_small_kernel(double *Kq, long ld, const double *Xq, int M, const double *X, int N, int Np,
+                                                         int d, CovParams p)
+{
+	__shared__ double xq_s[16 * GPEMU_MAX_PARAMS];
+	__shared__ double tab[EXP_TAB];
+	const int tid = threadIdx.x;
+	for (int e = tid; e < M * d; e += 256) xq_s[e] = Xq[e];
+	if (tid < EXP_TAB) tab[tid] = exp2((double)tid * (1.0 / EXP_TAB));
+	__syncthreads();
+	const int i = blockIdx.x * 256 + tid;
+	if (i >= Np) return;
+	for (int q = 0; q < 16; q++) {
+		double v = 0.0;
+		if (q < M && i < N) {
+			double a = 0.0;
+			int same = 0;
+			for (int k = 0; k < d; k++) {
+				const double D = X[(long)i * d + k] - xq_s[q * d + k];
+				const double t = D * p.w[(p.kind == GPEMU_POWEREXP) ? k : 0];
+				a = fma(t, t, a);
+				same += (fabs(D) < p.eps) ? 1 : 0;
+			}
+			if (p.kind == GPEMU_POWEREXP) {
+				v = fast_exp_neg(-a, tab) * p.amp;                                  // emulator.c:133,141
+			} else {
+				const double sdist = fast_sqrt(a);                                  // distance / rho
+				if (p.kind == GPEMU_MATERN32) {
+					const double root3 = 1.732050808;                               // emulator.c:359 (literal)
+					v = p.amp * (1 + root3 * sdist) * fast_exp_neg(-root3 * sdist, tab);
+				} else {
+					const double root5 = 2.236067978;                               // emulator.c:452 (literal)
+					v = p.amp * (1 + root5 * sdist + (5.0 / 3.0) * sdist * sdist) * fast_exp_neg(-root5 * sdist, tab);
+				}
+			}
+			if (same == d) v += p.nug;                                              // emulator.c:136-150 / :368-384 / :462-478
+			if (v < 1E-10) v = 0.0;                                                 // emulator.c:588-590
+		}
+		Kq[(long)q * ld + i] = v;
+	}
+}
+
+hipError_t launch_kvec_small(hipStream_t s, double *Kq, long ld, const double *Xq, int M, const double *X, int N, int Np, int d,
+                             const CovParams &p)
+{
+	if (M < 1 || M > 16) return hipErrorInvalidValue;
+	hipLaunchKernelGGL(kvec_small_kernel, dim3((Np + 255) / 256), dim3(256), 0, s, Kq, ld, Xq, M, X, N, Np, d, p);
+	return hipGetLastError();
+}
+
+__global__ void sum_slices_kernel(double *V, long n, int nslice, long sstride);
+
+// the epilogue for those few queries, one workgroup per query: the split-K slices of V are summed in slice order while the
+// squared norm of the first Np entries is taken (256 threads instead of one wave), the regression part (nreg x nreg) is
+// spread over the threads instead of lane 0 walking it with an integer division per basis function.
+// mean = h.beta + k*.gamma ;  var = kappa - |L^-1 k*|^2 + q^T Q q,  q = h - W^T k*   (emulator.c:672-704, 720-785)
+__global__ __launch_bounds__(256) void predict_finish_small_kernel(const double *Vp, long ldv, long sstride, int nslice, int Np,
+                                                                   int nreg, int d, const double *Xq, const double *betaQ, double kappa,
+                                                                   double *mean, double *var)
+{
+	__shared__ double red[256];
+	__shared__ double tail[64];          // V[q][Np .. Np+63]: k*.gamma, then (W^T k*)_a
+	__shared__ double qv[64], tv[64], hs[64];
+	const int q = blockIdx.x, tid = threadIdx.x;
+	const double *v0 = Vp + (long)q * ldv;
+	double ss = 0.0;
+	for (int n = tid; n < Np + 64; n += 256) {
+		double v = v0[n];
+		for (int s_ = 1; s_ < nslice; s_++) v += v0[(long)s_ * sstride + n];
+		if (n < Np) ss = fma(v, v, ss);
+		else tail[n - Np] = v;
+	}
+	red[tid] = ss;
+	__syncthreads();
+	for (int st = 128; st > 0; st >>= 1) {
+		if (tid < st) red[tid] += red[tid + st];
+		__syncthreads();
+	}
+	const double *x = Xq + (long)q * d;
+	const double *beta = betaQ, *Q = betaQ + nreg;
+	if (tid < nreg) {
+		hs[tid] = hfun(tid, x, d);
+		qv[tid] = hs[tid] - tail[1 + tid];
+	}
+	__syncthreads();
+	if (tid < nreg) {
+		double t = 0.0;
+		for (int b = 0; b < nreg; b++) t += Q[tid * nreg + b] * qv[b];
+		tv[tid] = t;
+	}
+	__syncthreads();
+	if (tid == 0) {
+		double m = tail[0], reg = 0.0;
+		for (int a = 0; a < nreg; a++) {
+			m += hs[a] * beta[a];
+			reg += qv[a] * tv[a];
+		}
+		mean[q] = m;
+		var[q] = kappa - red[0] + reg;
+	}
+}
+
+hipError_t launch_predict_finish_small(hipStream_t s, const double *Vp, long ldv, long sstride, int nslice, int M, int Np, int nreg,
+                                       int d, const double *Xq, const double *betaQ, double kappa, double *mean, double *var)
+{
+	if (nreg > 63 || M < 1) return hipErrorInvalidValue;
+	if (nslice > 1) {
+		// the slices are summed by the whole chip first (one workgroup per query reading nslice x 66 KB alone measured 60 us
+		// against 6 for this launch); the epilogue below then reads ONE row per query
+		const long n = (long)M * ldv;
+		hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, s, const_cast<double *>(Vp), n, nslice, sstride);
+		nslice = 1;
+	}
+	hipLaunchKernelGGL(predict_finish_small_kernel, dim3(M), dim3(256), 0, s, Vp, ldv, sstride, nslice, Np, nreg, d, Xq, betaQ, kappa,
+	                   mean, var);
+	return hipGetLastError();
+}
+
 // split-K partial products -> V (slice 0), summed in slice order: V[e] = sum_s V[s*sstride + e]
 __global__ __launch_bounds__(256) void sum_slices_kernel(double *V, long n, int nslice, long sstride)
 {

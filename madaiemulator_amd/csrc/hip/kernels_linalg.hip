@@ -469,6 +469,87 @@ __global__ __launch_bounds__(256) void skinny_nt_kernel(const double *Kq, long l
 			vp[(long)(16 * t + g + 4 * r) * ldv] = (acc[t][0][r] + acc[t][1][r]) + (acc[t][2][r] + acc[t][3][r]);
 }
 
+// ---------------------------------------------------------------------------
+// ONE query (emulate_point, the call an MCMC driver makes per sample): the same product as a matrix-VECTOR stream.  The skinny kernel above feeds the matrix unit and therefore reads 16 rows of L per wave-instruction, 64 bytes of
+// each (2.9 TB/s at N = 8192); here a wave walks its 16 rows one after the other and a wave-instruction reads 2 KB of ONE
+// row (32 contiguous bytes per lane), the k-vector values of the lane's columns sit in registers, every lane keeps a
+// partial sum per row and query, and a butterfly over the 64 lanes ends the slice.  Same grid and output layout as the
+// skinny kernel (row block x k-slice; Vp[slice][query][n]); MQ = queries held per lane (1).  fp64 FMAs on the vector unit:
+// 2 flops per 8 bytes streamed, far below its rate.
+// ---------------------------------------------------------------------------
+template <int MQ>
+__global__ __launch_bounds__(256) void gemv_tri_kernel(const double *Kq, long ldk, const double *L, long ldl, double *Vp,
+                                                       long ldv, long sstride, int K, int ntri, int klen)
+{
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int n0 = blockIdx.x * 64 + 16 * wave;
+	const int kb = blockIdx.y * klen;
+	int ke = kb + klen < K ? kb + klen : K;
+	if (n0 < ntri) {
+		const int kx = (n0 + 16 + 15) & ~15;        // columns <= n0+15 of the triangular rows
+		if (kx < ke) ke = kx;
+	}
+	double acc[16][MQ];
+#pragma unroll
+	for (int r = 0; r < 16; r++)
+#pragma unroll
+		for (int m = 0; m < MQ; m++) acc[r][m] = 0.0;
+	const double *lrow = L + (long)n0 * ldl;
+	for (int k = kb + 4 * lane; k < ke; k += 256) {
+		d4_t kv[MQ];
+#pragma unroll
+		for (int m = 0; m < MQ; m++) kv[m] = *reinterpret_cast<const d4_t *>(Kq + (long)m * ldk + k);
+#pragma unroll
+		for (int h = 0; h < 2; h++) {              // eight rows' loads in flight at a time
+			d4_t l[8];
+#pragma unroll
+			for (int r = 0; r < 8; r++) l[r] = *reinterpret_cast<const d4_t *>(lrow + (long)(8 * h + r) * ldl + k);
+#pragma unroll
+			for (int r = 0; r < 8; r++)
+#pragma unroll
+				for (int m = 0; m < MQ; m++) {
+					double a = acc[8 * h + r][m];
+					a = fma(l[r][0], kv[m][0], a);
+					a = fma(l[r][1], kv[m][1], a);
+					a = fma(l[r][2], kv[m][2], a);
+					a = fma(l[r][3], kv[m][3], a);
+					acc[8 * h + r][m] = a;
+				}
+		}
+	}
+#pragma unroll
+	for (int r = 0; r < 16; r++)
+#pragma unroll
+		for (int m = 0; m < MQ; m++) {
+			double a = acc[r][m];
+			a += __shfl_xor(a, 32);
+			a += __shfl_xor(a, 16);
+			a += __shfl_xor(a, 8);
+			a += __shfl_xor(a, 4);
+			a += __shfl_xor(a, 2);
+			a += __shfl_xor(a, 1);
+			acc[r][m] = a;
+		}
+	if (lane == 0) {
+		double *vp = Vp + (long)blockIdx.y * sstride + n0;
+#pragma unroll
+		for (int m = 0; m < MQ; m++)
+#pragma unroll
+			for (int r = 0; r < 16; r++) vp[(long)m * ldv + r] = acc[r][m];
+	}
+}
+
+// ONE query (row 0 of Kq); otherwise as launch_skinny_nt.  (Four queries per lane need 256 VGPRs -- one wave per SIMD --:
+// from two queries on the skinny kernel stays.)
+hipError_t launch_gemv_tri(hipStream_t s, const double *Kq, long ldk, const double *L, long ldl, double *Vp, long ldv,
+                           long sstride, int mq, int ntot, int K, int ntri, int nslice, int klen)
+{
+	const dim3 grid(ntot / 64, nslice);
+	if (mq != 1) return hipErrorInvalidValue;
+	hipLaunchKernelGGL(gemv_tri_kernel<1>, grid, dim3(256), 0, s, Kq, ldk, L, ldl, Vp, ldv, sstride, K, ntri, klen);
+	return hipGetLastError();
+}
+
 // Vp[s][q][n] for q < 16*tq (tq = 1..4), n < ntot (multiple of 64), slices of klen (multiple of 16) over [0, K)
 hipError_t launch_skinny_nt(hipStream_t s, const double *Kq, long ldk, const double *L, long ldl, double *Vp, long ldv,
                             long sstride, int tq, int ntot, int K, int ntri, int nslice, int klen)
