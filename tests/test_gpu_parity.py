@@ -887,6 +887,14 @@ def test_n8192_c3_oracle_fixture_and_a_50000_query_call(gpu_ctx):
     mid[:nq] = Xq
     mm, vm = gpu_ctx.predict(mid)
     assert np.array_equal(mm[:nq], mb[:nq]) and np.array_equal(vm[:nq], vb[:nq])
+    # emulate_point's own path (round 4): ONE query per call (small k-vector kernel, matrix-vector stream over L^-1, epilogue
+    # with the slice sums in front) and three per call (the skinny MFMA product) against the same oracle numbers
+    for i in range(6):
+        m1, v1 = gpu_ctx.predict(Xq[i:i + 1])
+        assert abs(m1[0] - f["mean"][i]) < RTOL * max(1.0, np.abs(f["mean"]).max()) and abs(v1[0] - f["var"][i]) < RTOL * kappa
+        assert abs(m1[0] - m64[i]) < 1e-11 * max(1.0, np.abs(m64).max()) and abs(v1[0] - v64[i]) < 1e-11 * kappa
+    m3, v3 = gpu_ctx.predict(Xq[6:9])
+    assert np.max(np.abs(m3 - f["mean"][6:9])) < RTOL * max(1.0, np.abs(f["mean"]).max()) and np.max(np.abs(v3 - f["var"][6:9])) < RTOL * kappa
 
 
 def test_exact_gradient_against_mpmath_golden_v3():
@@ -1262,9 +1270,11 @@ def _schedule_run(monkeypatch, env):
         out = [c.loglik(th), c.loglik(th), c.loglik_batch(ths), c.loglik_batch(ths), c.loglik_grad(th)]
         c.predict_setup(th)
         pm, pv = c.predict(synth.design(700, d, 99)[0])
+        p1 = c.predict(synth.design(700, d, 99)[0][:1])              # one query: emulate_point's path
         c.close()
         _schedule_cache[key] = {"v0": out[0]["value"], "v1": out[1]["value"], "s2": out[0]["sigma2"], "b2": out[2]["value"],
-                                "b3": out[3]["value"], "beta2": out[2]["beta"], "grad": out[4]["grad"], "pm": pm, "pv": pv}
+                                "b3": out[3]["value"], "beta2": out[2]["beta"], "grad": out[4]["grad"], "pm": pm, "pv": pv,
+                                "p1m": p1[0][0], "p1v": p1[1][0]}
     return _schedule_cache[key]
 
 
@@ -1273,7 +1283,8 @@ def _schedule_run(monkeypatch, env):
                                  {"GPEMU_GEMM_BIG_TILES": "1000000"}, {"GPEMU_GEMM_TABLE": "0"}, {"GPEMU_GEMM_TABLE": "5"},
                                  {"GPEMU_FACTOR_AHEAD": "0", "GPEMU_NO_GRAPH": "1", "GPEMU_GEMM_BIG_TILES": "1"},
                                  {"GPEMU_SPLIT_RHS_ROWS": "0", "GPEMU_GEMM_BIG_TILES": "1"}, {"GPEMU_SPLIT_RHS_ROWS": "0"},
-                                 {"GPEMU_KVEC_GRAM": "0"}, {"GPEMU_IDLE_WAVES": "0"}, {"GPEMU_IDLE_WAVES": "0", "GPEMU_GEMM_BIG_TILES": "1"}])
+                                 {"GPEMU_KVEC_GRAM": "0"}, {"GPEMU_IDLE_WAVES": "0"}, {"GPEMU_IDLE_WAVES": "0", "GPEMU_GEMM_BIG_TILES": "1"},
+                                 {"GPEMU_GEMV_POINT": "0"}])
 def test_schedule_switches_keep_parity(monkeypatch, env):
     """the measurement switches of INTEGRATION.md (factor-ahead, panel widths, tile shapes, tile order, no graph, the form
     of the prediction sweep's k-vector fill) change the
@@ -1293,6 +1304,10 @@ def test_schedule_switches_keep_parity(monkeypatch, env):
     # 700 predictions (triangular-operand products, k-ranges per tile) through the same switches
     assert np.max(np.abs(got["pm"] - base["pm"])) < 1e-9 * max(1.0, np.max(np.abs(base["pm"])))
     assert np.max(np.abs(got["pv"] - base["pv"])) < 1e-9 * max(1e-3, np.max(np.abs(base["pv"])))
+    # one query per call: the same numbers as inside the 700-query call to rounding, whichever product kernel ran
+    assert abs(got["p1m"] - base["pm"][0]) < 1e-9 * max(1.0, np.max(np.abs(base["pm"]))) and abs(got["p1v"] - base["pv"][0]) < 1e-9 * max(1e-3, np.max(np.abs(base["pv"])))
+    if "GPEMU_FILL_GRAM" not in env and "GPEMU_GEMV_POINT" not in env:
+        assert got["p1m"] == base["p1m"] and got["p1v"] == base["p1v"]
     if "GPEMU_FILL_GRAM" not in env:
         assert got["v0"] == base["v0"] and np.array_equal(got["b2"], base["b2"])
         assert np.array_equal(got["beta2"], base["beta2"]) and np.array_equal(got["grad"], base["grad"])
