@@ -29,7 +29,9 @@ for it in range(NIT):
         assert np.allclose(gb['grad'][0],g['grad'],rtol=1e-9,atol=1e-12)
     c.predict_setup(th); m,var=c.predict(synth.queries(int(rng.integers(1,300)),d,7))
     sig=(v,float(m[0]))
-    if key in ref: assert ref[key]==sig,(key,ref[key],sig)
+    # the likelihood value bit for bit; the first query's mean to rounding (the number of queries of the call picks the path:
+    # one query = matrix-vector kernel, 2-16 = skinny product, more = GEMM with Gram-form k-vectors; each is deterministic)
+    if key in ref: assert ref[key][0]==sig[0] and abs(ref[key][1]-sig[1])<=1e-12*max(1.0,abs(sig[1])),(key,ref[key],sig)
     ref[key]=sig
     if it%100==99: print("it",it,"elapsed %.1fs"%(time.time()-t0),"free MB",torch.cuda.mem_get_info()[0]>>20,flush=True)
 for c in ctxs: c.close()
