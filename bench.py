@@ -152,10 +152,13 @@ def cpu_baseline(kind, order, N, d, seed, sizes=(1024, 1536, 2048)):
     }
 
 
-def train_through_cli(N, d, seed, dev, runs, exact=True):
+def train_through_cli(N, d, seed, dev, runs, exact=True, rank=0, world=1, local_rank=0, rendezvous=None):
     """region D: `interactive_emulator estimate_thetas` (csrc/host, the reference's CLI contract) as a child process on a
     pow-exp N x d INPUT_MODEL_FILE (interactive_emulator.c:222-238 format), fixed seed, `runs` BFGS runs in lock-step
-    groups (two per GPU).  Returns the search's own figures (GPEMU_SEARCH_STATS line of estimate_thetas_threaded)."""
+    groups (two per GPU).  Returns the search's own figures (GPEMU_SEARCH_STATS line of estimate_thetas_threaded).
+    world > 1: the same search as ONE PROCESS PER GPU (csrc/host/ranks.c) -- every bench rank starts the CLI with its own
+    GPEMU_RANK; run r of the list belongs to rank r mod world; one gpemu_rccl_allgather ends it; the figures are this
+    rank's share (bench.py adds them up), best_loglik is the search's result on every rank."""
     import re
     import subprocess
     import tempfile
@@ -169,6 +172,10 @@ def train_through_cli(N, d, seed, dev, runs, exact=True):
             np.savetxt(f, y, fmt="%.17g")
         env = dict(os.environ, GPEMU_DEVICES=str(dev), GPEMU_SEED="20261003", GPEMU_JOBS="1", GPEMU_RESTARTS=str(runs),
                    GPEMU_SEARCH_STATS="1")
+        if world > 1:
+            os.makedirs(os.path.join(rendezvous, "region_d"), exist_ok=True)          # a fresh directory per search
+            env.update(GPEMU_RANK=str(rank), GPEMU_WORLD_SIZE=str(world), GPEMU_LOCAL_RANK=str(local_rank),
+                       GPEMU_RENDEZVOUS_DIR=os.path.join(rendezvous, "region_d"))
         cmd = [build.CLI_BIN, "estimate_thetas", inp, snap, "--covariance_fn=1", "--regression_order=0"]
         if exact:
             cmd.append("--exact_gradient")
@@ -194,6 +201,7 @@ def train_through_cli(N, d, seed, dev, runs, exact=True):
                 "ms_per_bfgs_iteration_per_run": secs * 1e3 * nthreads / max(niter, 1),
                 "search_seconds": secs, "cli_wall_seconds": wall, "best_loglik": best,
                 "gradient": "exact" if exact else "literal (reference formulas)",
+                "snapshot_sha256": __import__("hashlib").sha256(open(snap, "rb").read()).hexdigest() if rank == 0 else None,
                 "workload": f"pow-exp, N={N}, d={d}, regression_order=0; lib/interactive_emulator estimate_thetas, GPEMU_RESTARTS={runs}"}
 
 
@@ -323,6 +331,53 @@ def pca8_emulator_cli(dev, npts=100000):
                 "points_per_s": npts / st["loop_wall_s"], "component_predictions_per_s": nr * npts / st["loop_wall_s"],
                 "stage_busy_s": {"read_parse": st["parse_s"], "device": st["device_s"], "format_write": st["format_s"]},
                 "workload": f"N={N}, d={d}, {nt} outputs back-projected from {nr} PCA components; interactive_mode -q, text protocol"}
+
+
+def pca8_train_ranks_cli(dev, rank, world, local_rank, rendezvous, restarts=4):
+    """region F: BASELINE configs[3] TRAINED through the drop-in as ONE PROCESS PER GPU (csrc/host/ranks.c): every bench
+    rank starts `interactive_emulator estimate_thetas` on the same N=4096, d=16, t=9 INPUT_MODEL_FILE with GPEMU_RANK /
+    GPEMU_WORLD_SIZE of its own; the 8 PCA components are dealt to the ranks, the thetas meet in ONE gpemu_rccl_allgather
+    (RCCL over xGMI when the ranks sit on different GPUs) and rank 0 writes the snapshot, whose sha256 is reported: it is
+    the same string at every --gpus N, since a component's search depends on the seed alone."""
+    import hashlib
+    import re
+    import subprocess
+    from madaiemulator_amd import build, synth
+    N, d, nt = 4096, 16, 9
+    inp, snap = os.path.join(rendezvous, f"pca8_train_{rank}.dat"), os.path.join(rendezvous, f"pca8_snapshot_{rank}.txt")
+    X, y = synth.design(N, d, 20261003 + 3)
+    Y = synth.multi_outputs(X, y, nt) + 0.05 * synth.normal(12, N * nt).reshape(N, nt)
+    with open(inp, "w") as f:
+        f.write(f"{nt}\n{d}\n{N}\n")
+        np.savetxt(f, X, fmt="%.17g")
+        np.savetxt(f, Y, fmt="%.17g")
+    env = dict(os.environ, GPEMU_DEVICES=str(dev), GPEMU_SEED="20261004", GPEMU_JOBS="1", GPEMU_RESTARTS=str(restarts),
+               GPEMU_SEARCH_STATS="1", GPEMU_RANK=str(rank), GPEMU_WORLD_SIZE=str(world), GPEMU_LOCAL_RANK=str(local_rank),
+               GPEMU_RENDEZVOUS_DIR=os.path.join(rendezvous, "region_f"))
+    os.makedirs(os.path.join(rendezvous, "region_f"), exist_ok=True)                  # a fresh directory per search
+    cmd = [build.CLI_BIN, "estimate_thetas", inp, snap, "--covariance_fn=1", "--regression_order=0", "--pca_variance=1.0",
+           "--exact_gradient"]
+    t0 = time.perf_counter()
+    try:
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+    except (subprocess.TimeoutExpired, OSError) as ex:
+        return {"error": repr(ex)[:300]}
+    wall = time.perf_counter() - t0
+    if out.returncode != 0:
+        return {"error": out.stderr[-600:]}
+    if os.environ.get("BENCH_KEEP_STDERR"):
+        sys.stderr.write(out.stderr)
+    secs = [float(v) for v in re.findall(r"# search stats: .* seconds ([0-9.]+) best", out.stderr)]
+    nvg = [int(v) for v in re.findall(r"value_grad_evals (\d+)", out.stderr)]
+    res = {"cli_wall_seconds": wall, "components_trained_here": len(secs), "search_seconds_here": sum(secs),
+           "value_grad_evals_here": sum(nvg)}
+    if rank == 0:
+        res["snapshot_sha256"] = hashlib.sha256(open(snap, "rb").read()).hexdigest()
+        res["gather"] = ("none (one process)" if world == 1 else "files (GPEMU_GATHER=file: ranks sharing a device)"
+                         if os.environ.get("GPEMU_GATHER") == "file" else "gpemu_rccl_allgather (RCCL), one per search")
+        res["workload"] = (f"N={N}, d={d}, {nt} outputs -> 8 PCA components, pow-exp, regression_order=0, GPEMU_RESTARTS={restarts}; "
+                           f"lib/interactive_emulator estimate_thetas as {world} process(es), components c = rank mod {world}")
+    return res
 
 
 def pca8_region(abi, shard, synth, dev, rank, world_size, steps, barrier, reduce_max):
@@ -834,9 +889,39 @@ def main():
     #      product's own restart pool -- lock-step groups of BFGS threads over gpemu_loglik_grad_batch_* -- trains the
     #      pow-exp model of region C from an INPUT_MODEL_FILE with a fixed seed and a bounded run list; what is reported is
     #      what that search achieved (its own GPEMU_SEARCH_STATS line), beside the raw C-ABI figure of region C
+    #      With --gpus N > 1 the SAME search (same run list, same seed) runs as one CLI process per GPU (ranks.c): the runs are
+    #      dealt to the ranks and one gpemu_rccl_allgather picks the winner; value_grad_evals_per_s then counts all ranks'
+    #      evaluations over the slowest rank's search time, and best_loglik / snapshot_sha256 are those of the N=1 line.
+    import shutil
+    import tempfile
+    rdv = [tempfile.mkdtemp(prefix="gpemu_bench_ranks_") if (rank == 0 and distributed) else None]
+    if distributed:
+        dist.broadcast_object_list(rdv, src=0)
     train = None
-    if rank == 0 and ngpus == 1 and not args.no_train and not args.no_grad:
-        train = train_through_cli(N, d, seed + 1, dev, args.train_runs, exact=not args.train_literal)
+    if not args.no_train and not args.no_grad and (rank == 0 or distributed):
+        barrier()
+        mine = train_through_cli(N, d, seed + 1, dev, args.train_runs, exact=not args.train_literal,
+                                 rank=rank, world=world_size, local_rank=local_rank, rendezvous=rdv[0])
+        if distributed:
+            ok = "value_grad_evals" in mine
+            worst = allreduce_max(mine["search_seconds"] if ok else 0.0)
+            failed = allreduce_max(0.0 if ok else 1.0)
+            tot = torch.tensor([float(mine.get("value_grad_evals", 0)), float(mine.get("runs", 0))], dtype=torch.float64, device=tdev)
+            dist.all_reduce(tot)
+            if rank == 0:
+                train = mine
+                if ok and not failed:
+                    train.update(value_grad_evals=int(tot[0].item()), runs=int(tot[1].item()), search_seconds=worst,
+                                 value_grad_evals_per_s=float(tot[0].item()) / worst, processes=world_size,
+                                 gather="files (GPEMU_GATHER=file: ranks sharing a device)" if os.environ.get("GPEMU_GATHER") == "file"
+                                 else "gpemu_rccl_allgather (RCCL), one per search")
+                    for k in ("value_only_evals", "answered_from_cache", "device_rounds", "mean_requests_per_round", "bfgs_iterations",
+                              "ms_per_bfgs_iteration_per_run", "host_threads", "lockstep_groups"):
+                        train[k + "_rank0"] = train.pop(k)
+                elif failed:
+                    train = {"error": mine.get("error", "another rank's CLI failed")}
+        else:
+            train = mine
         if train and vg and "value_grad_evals_per_s" in train:
             train["fraction_of_raw_value_grad"] = train["value_grad_evals_per_s"] / vg["value"]
         note("region D (estimate_thetas through the C layer) done")
@@ -852,6 +937,25 @@ def main():
         if rank == 0 and ngpus == 1 and not args.no_interactive:
             pca8["emulator_through_cli"] = pca8_emulator_cli(dev)
         note("region E (8 PCA components) done")
+    # ---- region F: configs[3] TRAINED by the C product as one process per GPU (ranks.c): the bench ranks each start the CLI
+    #      with their rank; the CLI processes gather the thetas among themselves through RCCL (gpemu_rccl_allgather)
+    ranks_cli = None
+    if not args.no_pca8 and not args.no_train:
+        barrier()
+        t0 = time.perf_counter()
+        with tempfile.TemporaryDirectory(prefix="gpemu_bench_") as own:
+            mine = pca8_train_ranks_cli(dev, rank, world_size, local_rank, rdv[0] if distributed else own, restarts=16)
+        f_wall, f_fail, f_evals = time.perf_counter() - t0, 1.0 if "error" in mine else 0.0, float(mine.get("value_grad_evals_here", 0))
+        if distributed:
+            f_wall, f_fail = allreduce_max(f_wall), allreduce_max(f_fail)
+            tot = torch.tensor([f_evals], dtype=torch.float64, device=tdev)
+            dist.all_reduce(tot)
+            f_evals = float(tot.item())
+        if rank == 0:
+            ranks_cli = dict(mine, wall_seconds_max_over_ranks=f_wall, ranks_failed=bool(f_fail > 0), processes=world_size,
+                             value_grad_evals_all_ranks=int(f_evals),
+                             value_grad_evals_per_s_wall=f_evals / f_wall if f_wall > 0 else None)
+        note("region F (configs[3] trained as one CLI process per GPU) done")
     # ---- roofline of the prediction GEMM (the likelihood rooflines were taken right behind region A)
     if rank == 0:
         if pred is not None:
@@ -889,6 +993,7 @@ def main():
             "value_grad": vg,
             "estimate_thetas_c_layer": train,
             "pca8": pca8,
+            "pca8_trained_by_cli_ranks": ranks_cli,
             "single_evaluation": single,
             "rccl_ranks": (world_size if (distributed and backend == "nccl") else (1 if not distributed else 0)),
             "process_group": (backend if distributed else None),
@@ -902,6 +1007,8 @@ def main():
         c.close()
     if distributed:
         dist.barrier()
+        if rank == 0 and rdv[0]:
+            shutil.rmtree(rdv[0], ignore_errors=True)
         dist.destroy_process_group()
 
 

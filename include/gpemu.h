@@ -54,6 +54,16 @@ int  gpemu_device_count(void);
  * 10 GB of C^-1 corners, per context. */
 int  gpemu_device_memory(int device, size_t *free_bytes, size_t *total_bytes);
 
+/* ---- the single collective of a multi-process run (north_star: "one GPU per shard with a single RCCL gather
+ * over xGMI at the end"): all-gather of `count` doubles per rank over RCCL -- what the mutex-guarded arg-max of
+ * libEmu/estimate_threaded.c:308-313 and the serial component loop of multivar_support.c:20-28 become when the
+ * independent restarts / PCA components run one process per GPU (csrc/host/ranks.c).  Host buffers:
+ * recv[r * count + i] = rank r's send[i].  librccl is opened at run time; the ncclUniqueId goes from rank 0 to the
+ * others through the file `id_path` (a fresh name per call, in a directory every rank can reach).  errbuf (optional)
+ * receives the message of a failure. */
+int gpemu_rccl_allgather(int device, int rank, int world, const char *id_path, const double *send, int count,
+                         double *recv, char *errbuf, size_t errlen);
+
 /* ---- model data (modelstruct.h:28-98: xmodel, training_vector) ------
  * Uploads the N x d design and the N training values to HBM and builds the
  * regression basis H (regression.c:9-67,100-112: nreg = 1 + order*d) there.

@@ -29,6 +29,7 @@ SYMBOLS = {
     "gpemu_version": (C.c_char_p, []),
     "gpemu_device_count": (C.c_int, []),
     "gpemu_device_memory": (C.c_int, [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "gpemu_rccl_allgather": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_char_p, _dp, C.c_int, _dp, C.c_char_p, C.c_size_t]),
     "gpemu_set_model": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp]),
     "gpemu_set_training": (C.c_int, [C.c_void_p, _dp]),
     "gpemu_cov_matrix": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp]),

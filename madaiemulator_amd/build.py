@@ -54,7 +54,7 @@ def build_hip(force=False, verbose=False):
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
         objs.append(o)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -85,7 +85,10 @@ static int estimate_thetas(struct cmdLineOpts *o)
 	gsl_matrix *xmodel = NULL, *training = NULL;
 	double varfrac = 0.95;
 	if (!open_model_file(o->inputfile, &xmodel, &training)) return perr("Input File read failed.");
-	FILE *out = fopen(o->statefile, "w");
+	/* one process per GPU (GPEMU_RANK / GPEMU_WORLD_SIZE, ranks.c): every rank trains its share and ends with the whole
+	 * model; rank 0 alone writes MODEL_SNAPSHOT_FILE */
+	gpemu_host_rank_device();
+	FILE *out = fopen(gpemu_host_rank() == 0 ? o->statefile : "/dev/null", "w");
 	if (!out) return perr("Opening statefile failed.");
 	if (o->pca_variance <= 1.0 && o->pca_variance > 0) varfrac = o->pca_variance;
 	if (o->covFn < 0 || o->covFn > 3) { fprintf(stderr, "#ERROR cov_fn_index %d not supported\n", o->covFn); exit(EXIT_FAILURE); }

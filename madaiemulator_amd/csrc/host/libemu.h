@@ -268,6 +268,15 @@ void *gpemu_host_group_create(struct estimate_thetas_params **members, int n);
 void gpemu_host_group_leave(void *params);
 void gpemu_host_group_destroy(void *group);
 
+/* one process per GPU (ranks.c): GPEMU_RANK / GPEMU_WORLD_SIZE / GPEMU_LOCAL_RANK / GPEMU_RENDEZVOUS_DIR.  estimate_multi deals
+ * the PCA components, estimate_thetas_threaded (single-output models) the runs of the run list to the ranks; the one
+ * collective is an all-gather of a few doubles per rank (RCCL: gpemu_rccl_allgather; GPEMU_GATHER=file for ranks that share
+ * a device).  Rank 0 writes the snapshot; every rank ends with the full model. */
+int gpemu_host_world_size(void);
+int gpemu_host_rank(void);
+void gpemu_host_rank_device(void);
+void gpemu_host_allgather(const double *send, int count, double *recv);
+
 /* interactive_mode's request/response loop (src/interactive_emulator.c:398-440) as a reader -> device -> writer pipeline
  * (interactive_io.c): reads points of nparams numbers from fd_in -- text, the reference's fscanf("%lf%*c") framing, or raw
  * doubles (binary != 0: the reference's BINARY_INTERACTIVE_MODE framing, :418-432) --, hands the points that are already

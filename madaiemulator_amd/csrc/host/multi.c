@@ -279,8 +279,43 @@ static void *component_main(void *arg)
 	return NULL;
 }
 
+/* one process per GPU (ranks.c): rank r trains the components c = r, r + W, ...; the thetas of all components meet in ONE
+ * all-gather (nthetas doubles per component, the shares padded to the same length); every rank then holds the whole model,
+ * rank 0 writes it.  A single-output model has nothing to deal here: estimate_thetas_threaded deals its run list instead. */
+static int g_components_over_ranks = 0;
+int gpemu_host_components_over_ranks(void) { return g_components_over_ranks; }
+
+static void estimate_multi_ranks(multi_modelstruct *m, FILE *outfp)
+{
+	const int world = gpemu_host_world_size(), rank = gpemu_host_rank();
+	const int nthetas = (int)m->pca_model_array[0]->thetas->size;
+	const int share = (m->nr + world - 1) / world;                  /* components per rank, padded */
+	g_components_over_ranks = 1;
+	for (int i = rank; i < m->nr; i += world)
+		estimate_thetas_threaded(m->pca_model_array[i], m->pca_model_array[i]->options);
+	g_components_over_ranks = 0;
+	double *send = (double *)calloc((size_t)share * nthetas, sizeof(double));
+	double *recv = (double *)calloc((size_t)share * nthetas * world, sizeof(double));
+	for (int j = 0, i = rank; i < m->nr; i += world, j++)
+		for (int t = 0; t < nthetas; t++) send[(size_t)j * nthetas + t] = gsl_vector_get(m->pca_model_array[i]->thetas, t);
+	gpemu_host_allgather(send, share * nthetas, recv);
+	for (int i = 0; i < m->nr; i++) {
+		const double *src = recv + ((size_t)(i % world) * share + (size_t)(i / world)) * nthetas;
+		for (int t = 0; t < nthetas; t++) gsl_vector_set(m->pca_model_array[i]->thetas, t, src[t]);
+	}
+	free(send); free(recv);
+	if (rank == 0) dump_multi_modelstruct(outfp, m);
+}
+
 void estimate_multi(multi_modelstruct *m, FILE *outfp)
 {
+	if (gpemu_host_world_size() > 1) {
+		if (m->nr > 1) { estimate_multi_ranks(m, outfp); return; }
+		/* one component: its run list is dealt to the ranks inside estimate_thetas_threaded; every rank returns the same thetas */
+		estimate_thetas_threaded(m->pca_model_array[0], m->pca_model_array[0]->options);
+		if (gpemu_host_rank() == 0) dump_multi_modelstruct(outfp, m);
+		return;
+	}
 	int nslots = gpemu_host_thread_device_get() >= 0 ? 1 : gpemu_host_device_slots();
 	if (nslots > m->nr) nslots = m->nr;
 	if (nslots <= 1) {

@@ -316,6 +316,7 @@ static unsigned long seed_noblock(void)
 struct pool {
 	pthread_mutex_t result_lock;
 	int total_runs, nthreads, next_run;
+	int rank, world, local_runs;     /* ranks.c: runs rank, rank + world, ... are this process's (world = 1: all of them) */
 	unsigned long seed;
 	gsl_vector *best_thetas;
 	double best_likelyhood_val;
@@ -339,9 +340,11 @@ static void *worker_main(void *arg)
 	gpemu_host_thread_device(w->device);         /* contexts this thread creates live on its slot's device */
 	for (;;) {
 		pthread_mutex_lock(&P->result_lock);
-		const int run = P->next_run < P->total_runs ? P->next_run++ : -1;
+		/* (one process per GPU, ranks.c: this rank owns the runs rank, rank + W, ... of the list) */
+		const int mine = P->next_run < P->local_runs ? P->next_run++ : -1;
 		pthread_mutex_unlock(&P->result_lock);
-		if (run < 0) break;
+		if (mine < 0) break;
+		const int run = P->rank + P->world * mine;
 		gsl_rng_set(w->params.random_number, P->seed ? P->seed + 7919UL * (unsigned long)run : seed_noblock());
 		if (w->params.h_matrix) { gsl_matrix_free(w->params.h_matrix); w->params.h_matrix = NULL; }
 		maxWithMultiMin(&w->params);             /* max_tries = 1: one restart */
@@ -443,15 +446,21 @@ void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 	/* the batched gradient exists for pow-exp (literal or exact) and for Matern with the corrected forms (gpemu.h modes) */
 	if (options->cov_fn_index != POWEREXPCOVFN && gpemu_host_modes() != (GPEMU_MODE_EXACT_GRAD | GPEMU_MODE_MATERN_LOG)) lockstep = 1;
 	const int total = njobs * restarts;             /* the run list */
+	/* one process per GPU (ranks.c): a single-output model's run list is dealt to the ranks (a multi-output model deals its
+	 * components instead, estimate_multi, and every rank then runs whole lists) */
+	extern int gpemu_host_components_over_ranks(void);
+	const int world = gpemu_host_components_over_ranks() ? 1 : gpemu_host_world_size();
+	const int rank = world > 1 ? gpemu_host_rank() : 0;
+	const int local_total = total > rank ? (total - rank + world - 1) / world : 0;
 	/* device slots this search may use */
 	const int pinned = gpemu_host_thread_device_get();
 	const int nslots = pinned >= 0 ? 1 : gpemu_host_device_slots();
 	int ngroups = 0;
 	int glo[512], ghi[512], gslot[512];
 	if (lockstep > 1) {
-		ngroups = gpemu_host_plan_groups(total, lockstep, per_slot, nslots, &nthreads, glo, ghi, gslot, 512);
+		ngroups = gpemu_host_plan_groups(local_total > 0 ? local_total : 1, lockstep, per_slot, nslots, &nthreads, glo, ghi, gslot, 512);
 		if (ngroups < 1) { fprintf(stderr, "estimate_thetas_threaded: cannot lay out the lock-step groups\n"); exit(EXIT_FAILURE); }
-	} else if (nthreads > total) nthreads = total;
+	} else if (nthreads > local_total) nthreads = local_total > 0 ? local_total : 1;
 	unsigned long seed = g_seed;
 	env = getenv("GPEMU_SEED");
 	if (env && atol(env) > 0) seed = (unsigned long)atol(env);
@@ -464,6 +473,7 @@ void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 	struct pool P;
 	pthread_mutex_init(&P.result_lock, NULL);
 	P.total_runs = total; P.nthreads = nthreads; P.next_run = 0; P.seed = seed;
+	P.rank = rank; P.world = world; P.local_runs = local_total;
 	P.best_thetas = gsl_vector_calloc(options->nthetas);
 	P.best_likelyhood_val = SCREWUPVALUE_T;
 	P.best_run = total;
@@ -524,6 +534,27 @@ void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 		gsl_vector_free(W[i].best_thetas);
 		gsl_vector_free(W[i].params.the_model->thetas);
 		free(W[i].params.the_model);
+	}
+	if (world > 1) {
+		/* the arg-max of estimate_threaded.c:308-313 across processes: ONE all-gather of (best value, its run index, its
+		 * thetas) per rank; the larger value wins, ties go to the lower run index -- what one process decides run by run */
+		const int nt = options->nthetas, len = 2 + nt;
+		double *send = (double *)calloc((size_t)len, sizeof(double)), *recv = (double *)calloc((size_t)len * world, sizeof(double));
+		send[0] = P.best_likelyhood_val; send[1] = (double)P.best_run;
+		for (int t = 0; t < nt; t++) send[2 + t] = gsl_vector_get(P.best_thetas, t);
+		gpemu_host_allgather(send, len, recv);
+		int win = -1;
+		for (int r = 0; r < world; r++) {
+			const double *q = recv + (size_t)r * len;
+			if ((int)q[1] >= total) continue;                           /* that rank had no successful run */
+			if (win < 0 || q[0] > recv[(size_t)win * len] || (q[0] == recv[(size_t)win * len] && q[1] < recv[(size_t)win * len + 1])) win = r;
+		}
+		if (win >= 0) {
+			P.best_likelyhood_val = recv[(size_t)win * len];
+			P.best_run = (int)recv[(size_t)win * len + 1];
+			for (int t = 0; t < nt; t++) gsl_vector_set(P.best_thetas, t, recv[(size_t)win * len + 2 + t]);
+		}
+		free(send); free(recv);
 	}
 	gsl_vector_memcpy(the_model->thetas, P.best_thetas);
 	g_stat_best_gnorm = P.best_gnorm;

@@ -2,6 +2,7 @@
 interactive_emulator CLI, driven the way the reference's callers drive them; results checked against the oracle."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -553,6 +554,120 @@ def test_eight_pca_components_over_eight_device_slots_write_the_serial_snapshot(
     toks = snaps["serial"].split()
     assert int(toks[0]) == nt and int(toks[1]) == 8                     # nr = nt - 1 (multi_modelstruct.c:267-272)
     assert snaps["serial"] == snaps["eight_slots"] == snaps["two_slots"]
+
+
+def test_rank_gather_file_transport_three_processes(tmp_path):
+    """ranks.c: gpemu_host_allgather between three processes named by GPEMU_RANK / GPEMU_WORLD_SIZE, through the file
+    transport (GPEMU_GATHER=file; the RCCL transport needs one GPU per rank): two gathers in a row (sequence numbers keep
+    them apart), every rank ends with every share in rank order.  Host logic, no GPU."""
+    code = (
+        "import ctypes, os, sys\n"
+        "from madaiemulator_amd import build\n"
+        "L = ctypes.CDLL(build.HOST_LIB)\n"
+        "L.gpemu_host_allgather.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.POINTER(ctypes.c_double)]\n"
+        "r, w = L.gpemu_host_rank(), L.gpemu_host_world_size()\n"
+        "out = []\n"
+        "for n in (3, 5):\n"
+        "    send = (ctypes.c_double * n)(*[100.0 * r + i + 0.25 * n for i in range(n)])\n"
+        "    recv = (ctypes.c_double * (n * w))()\n"
+        "    L.gpemu_host_allgather(send, n, recv)\n"
+        "    out.append(list(recv))\n"
+        "print(r, w, out)\n")
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              cwd=ROOT,
+                              env=dict(os.environ, GPEMU_RANK=str(r), GPEMU_WORLD_SIZE="3", GPEMU_GATHER="file",
+                                       GPEMU_RENDEZVOUS_DIR=str(tmp_path)))
+             for r in range(3)]
+    want = [[100.0 * r + i + 0.25 * n for r in range(3) for i in range(n)] for n in (3, 5)]
+    for r, p in enumerate(procs):
+        so, se = p.communicate(timeout=120)
+        assert p.returncode == 0, se
+        assert so.strip() == f"{r} 3 {want}"
+    # a rank outside the world is refused, and so is a world without a rendezvous directory
+    bad = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                         cwd=ROOT,
+                         env=dict(os.environ, GPEMU_RANK="3", GPEMU_WORLD_SIZE="3", GPEMU_RENDEZVOUS_DIR=str(tmp_path)))
+    assert bad.returncode != 0 and "outside" in bad.stderr
+    env = dict(os.environ, GPEMU_RANK="0", GPEMU_WORLD_SIZE="2")
+    env.pop("GPEMU_RENDEZVOUS_DIR", None)
+    bad = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env,
+                         cwd=ROOT)
+    assert bad.returncode != 0 and "GPEMU_RENDEZVOUS_DIR" in bad.stderr
+
+
+def _run_ranks(cmd, world, rendezvous, env, snap_of_rank):
+    """start `world` processes of the CLI, rank r writing to snap_of_rank(r); returns their stdouts"""
+    procs = []
+    for r in range(world):
+        e = dict(env, GPEMU_RANK=str(r), GPEMU_WORLD_SIZE=str(world), GPEMU_GATHER="file", GPEMU_RENDEZVOUS_DIR=str(rendezvous))
+        procs.append(subprocess.Popen([c if c != "@SNAP@" else str(snap_of_rank(r)) for c in cmd], env=e,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for r, p in enumerate(procs):
+        so, se = p.communicate(timeout=900)
+        assert p.returncode == 0, (r, se[-2000:])
+        outs.append(so)
+    return outs
+
+
+@pytest.mark.gpu
+def test_one_process_per_gpu_ranks_write_the_serial_snapshot(tmp_path):
+    """SURVEY 8(e) as PROCESSES (ranks.c): `interactive_emulator estimate_thetas` started W times with GPEMU_RANK /
+    GPEMU_WORLD_SIZE.  A multi-output model deals its PCA components to the ranks (multivar_support.c:20-28), a
+    single-output model the runs of its run list (estimate_threaded.c:101-113); ONE all-gather of a few doubles per rank
+    ends the search and rank 0 writes the snapshot -- byte for byte the one a single process writes, for W = 2 and for a
+    W that does not divide the work.  The ranks here share the one GPU of the box, so the gather goes through files
+    (GPEMU_GATHER=file); on a node each rank has its own GPU and the gather is gpemu_rccl_allgather."""
+    cli = build.CLI_BIN
+    base = dict(os.environ, GPEMU_SEED="2024", GPEMU_RESTARTS="2", GPEMU_DEVICES="0")
+    serial = tmp_path / "serial"
+    run([cli, "estimate_thetas", MULTI, str(serial), "--regression_order=1"], env=base)
+    for world in (2, 3):
+        rdv = tmp_path / f"rdv_multi_{world}"
+        rdv.mkdir()
+        _run_ranks([cli, "estimate_thetas", MULTI, "@SNAP@", "--regression_order=1"], world, rdv, base,
+                   lambda r: tmp_path / f"multi_w{world}_r{r}")
+        assert (tmp_path / f"multi_w{world}_r0").read_bytes() == serial.read_bytes()
+        for r in range(1, world):
+            assert not (tmp_path / f"multi_w{world}_r{r}").exists()          # rank 0 alone writes
+    # single-output model: the run list (GPEMU_JOBS x GPEMU_RESTARTS = 10 runs) over 2 and over 4 ranks
+    N, d = 220, 3
+    X, y = synth.design(N, d, 1357)
+    y = y + 0.2 * synth.normal(9, N)
+    f = tmp_path / "one.dat"
+    _write_model_file(f, X, y)
+    base = dict(os.environ, GPEMU_SEED="31", GPEMU_JOBS="2", GPEMU_RESTARTS="5", GPEMU_EXACT_GRAD="1", GPEMU_DEVICES="0")
+    serial = tmp_path / "serial_one"
+    run([cli, "estimate_thetas", str(f), str(serial), "--regression_order=0"], env=base)
+    for world in (2, 4):
+        rdv = tmp_path / f"rdv_one_{world}"
+        rdv.mkdir()
+        _run_ranks([cli, "estimate_thetas", str(f), "@SNAP@", "--regression_order=0"], world, rdv, base,
+                   lambda r: tmp_path / f"one_w{world}_r{r}")
+        assert (tmp_path / f"one_w{world}_r0").read_bytes() == serial.read_bytes()
+
+
+@pytest.mark.gpu
+def test_rccl_allgather_entry(tmp_path):
+    """gpemu_rccl_allgather (include/gpemu.h; csrc/hip/rccl_gather.hip): librccl opened at run time, communicator from
+    an id file, ncclAllGather of doubles on a stream of its own.  One GPU on the box = a world of one rank (two RCCL ranks
+    cannot share a device); the id file is gone afterwards; bad arguments come back as GPEMU_ERR_ARG with a message."""
+    import ctypes
+    from madaiemulator_amd import abi
+    L = abi.load()
+    L.gpemu_rccl_allgather.restype = ctypes.c_int
+    L.gpemu_rccl_allgather.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double),
+                                       ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_size_t]
+    n = 11
+    send = (ctypes.c_double * n)(*[1.5 * i - 3.0 for i in range(n)])
+    recv = (ctypes.c_double * n)()
+    err = ctypes.create_string_buffer(256)
+    idf = tmp_path / "id0"
+    rc = L.gpemu_rccl_allgather(0, 0, 1, str(idf).encode(), send, n, recv, err, 256)
+    assert rc == 0, err.value
+    assert list(recv) == list(send) and not idf.exists()
+    rc = L.gpemu_rccl_allgather(0, 2, 2, str(idf).encode(), send, n, recv, err, 256)
+    assert rc != 0 and err.value
 
 
 def _write_model_file(path, X, y):
