@@ -4,7 +4,8 @@
 // It replaces the mutex-guarded arg-max / the serial component loop of the reference's single process
 // (libEmu/estimate_threaded.c:308-313, multivar_support.c:20-28) at the point where independent shards meet.
 //
-// librccl is opened at run time (dlopen): a single-GPU user of libgpemu_hip.so needs no RCCL.  The ncclUniqueId travels from
+// librccl is opened at run time (dlopen, the copy beside this library's libamdhip64): a single-GPU user of libgpemu_hip.so
+// needs no RCCL.  The ncclUniqueId travels from
 // rank 0 to the others through a file in a directory all ranks can see (written under a temporary name and renamed, so a
 // reader never sees half of it); one communicator per call -- the gather happens once, at the end of a search.
 #include "gpemu_internal.hpp"
@@ -30,10 +31,23 @@ struct Rccl {
 
 static bool load_rccl(Rccl &r, std::string &err)
 {
-	const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+	// The RCCL that belongs to THIS library's HIP runtime: the librccl next to the libamdhip64 we are linked with, by full path.
+	// A bare "librccl.so.1" would be answered with whatever copy the process already holds -- in a Python process that has
+	// imported torch, torch's own librccl, which drives torch's own HIP runtime and sees none of our devices or streams.
+	Dl_info self;
+	if (dladdr((void *)&hipGetDeviceCount, &self) && self.dli_fname) {
+		std::string dir(self.dli_fname);
+		const size_t slash = dir.rfind('/');
+		if (slash != std::string::npos) {
+			dir.resize(slash + 1);
+			r.h = dlopen((dir + "librccl.so.1").c_str(), RTLD_NOW | RTLD_LOCAL);
+			if (!r.h) r.h = dlopen((dir + "librccl.so").c_str(), RTLD_NOW | RTLD_LOCAL);
+		}
+	}
+	const char *names[] = {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
 	for (const char *n : names) {
-		r.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
 		if (r.h) break;
+		r.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
 	}
 	if (!r.h) { err = std::string("cannot open librccl: ") + dlerror(); return false; }
 	r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
@@ -93,6 +107,7 @@ extern "C" int gpemu_rccl_allgather(int device, int rank, int world, const char 
 	std::string err;
 	if (!load_rccl(R, err)) return fail(GPEMU_ERR_HIP, err);
 	if (hipSetDevice(device) != hipSuccess) return fail(GPEMU_ERR_HIP, "hipSetDevice failed");
+	(void)hipGetLastError();        // RCCL reads the thread's last HIP error after its launches: do not hand it a stale one
 	ncclUniqueId id;
 	memset(&id, 0, sizeof id);
 	if (rank == 0) {

@@ -653,6 +653,9 @@ def test_rccl_allgather_entry(tmp_path):
     an id file, ncclAllGather of doubles on a stream of its own.  One GPU on the box = a world of one rank (two RCCL ranks
     cannot share a device); the id file is gone afterwards; bad arguments come back as GPEMU_ERR_ARG with a message."""
     import ctypes
+    import torch                           # the hard case on purpose: torch brings ITS OWN librccl and HIP runtime into the
+    import torch.distributed               # process; the entry must still open the librccl beside the libamdhip64 it links
+    assert torch.zeros(1).item() == 0.0
     from madaiemulator_amd import abi
     L = abi.load()
     L.gpemu_rccl_allgather.restype = ctypes.c_int
