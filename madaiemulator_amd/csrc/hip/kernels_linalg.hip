@@ -137,6 +137,22 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 	}
 	if (g.tri && tn * BN > tm * BM + BM - 1 + g.diag_off) return;
 	const TraceT0 tr0 = trace_begin(g.trace);
+	if (BM == 128 && g.stagger_ticks > 0 && (long)blockIdx.y * gridDim.x + blockIdx.x < 512) {
+		// The two workgroups that share a CU start together and their tiles take the same time: left alone they stay in
+		// phase for the whole launch -- both store their tile, both load the next one and its first chunks in the same tens
+		// of microseconds, during which the CU's matrix pipes have nothing to do (profiles/r04_pmc_sq.txt: busy 90 %).  Of the
+		// launch's first round the workgroup in the odd slot of its CU (HW_ID.TG_ID, scratch/mb/hwid_pairs.hip) therefore
+		// starts late by about the length of that phase; its successors inherit the offset, and from then on one
+		// workgroup's memory phase runs under the other's matrix instructions.
+		unsigned hw;
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+		if ((hw >> 16) & 1) {
+			const unsigned long long t0 = wall_clock64();
+			while (wall_clock64() - t0 < (unsigned long long)g.stagger_ticks) __builtin_amdgcn_s_sleep(16);
+		}
+		// (spreading the whole first round over 0 .. 375 us, so that the 512 C-tile reads of a round do not meet either, made
+		// the K=2048 launches 4-10 % slower: it is the pair on a CU that matters, not the chip-wide burst)
+	}
 	int kb = g.k0, ke = g.k1;
 	if (g.kstart_mode) {
 		int ks = (tm * BM - g.kstart_off) & ~(GEMM_BK - 1);
@@ -290,6 +306,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 		d2_t xa[TM], xb[TN], ya[TM], yb[TN];
 		// (every wave's buffer_load ... lds must have landed before the barrier that hands the chunk to the other waves: the
 		// compiler places this wait itself today; it is spelled out so that correctness does not hang on that)
+		// (chunk 1 requested together with chunk 0, waiting for chunk 0 alone -- vmcnt(NPA + NPB) -- was measured: the 13-14 us
+		// of a tile's prologue did not move, round 4)
 		GEMM_DMA(0, kb);
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		__syncthreads();
@@ -698,6 +716,9 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs &a_in)
 			if (tt.dptr) { a.order_mode = 3; a.tile_table = tt.dptr; T = tt.len; }
 		}
 	}
+	// (the first-round offset pays from the second round on: a launch that fits two rounds of 512 resident workgroups or fewer
+	// would only start its odd slots late)
+	if ((long)T * nbatch < 1024 || a.ksplit > 1) a.stagger_ticks = 0;
 	if (cfg == 8) hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 4, 4, 2>), dim3(T, nbatch), dim3(512), 0, s, a);
 	else if (a.fa) hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2, 1>), dim3(T, nbatch), dim3(256), 0, s, a);
 	else hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2>), dim3(T, nbatch), dim3(256), 0, s, a);
