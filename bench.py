@@ -652,7 +652,7 @@ def main():
     #      card region A was timed in (at the end of the whole line, a minute of load later, they read 3 % lower)
     roof, roof_other = None, {}
     if rank == 0:
-        # the dominant kernel = gemm_nt_kernel<128,128,4,4,2,0> (128x128 tiles, 8 waves, operands by LDS-DMA): every
+        # the dominant kernel = gemm_nt_kernel<128,128,4,4,2,0,1> (128x128 tiles, 8 waves, operands by LDS-DMA, A negated by the NEG bit): every
         # update of a lock-step batch with >= 1024 such tiles and n >= 256 (contraction lengths 256 .. 2048), 95 % of its flops and
         # 79 % of the GPU time of the likelihood region (profiles/r03_kernel_stats_*)
         ctx.prof_begin(abi.PROF_GEMM_BIG)
@@ -684,7 +684,7 @@ def main():
             else:
                 traffic = (2.0 * tj["fetch_bytes_raw"] + tj["write_bytes"]) / tj["launches"]
                 traffic_src, traffic_why = os.path.basename(tpath), None
-        roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<128,128,4,4,2,0> (potrf trailing updates on 128x128 tiles, LDS-DMA staging, v_mfma_f64_16x16x4_f64)",
+        roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<128,128,4,4,2,0,1> (potrf trailing updates on 128x128 tiles, LDS-DMA staging, v_mfma_f64_16x16x4_f64)",
                 "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS,
                 "traffic": traffic, "traffic_source": traffic_src, "traffic_null_because": traffic_why,
                 "launches": p["n"], "avg_launch_us": p["ms"] * 1e3 / max(p["n"], 1),

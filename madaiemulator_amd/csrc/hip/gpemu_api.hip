@@ -99,6 +99,7 @@ static hipError_t gemm(gpemu_ctx *ctx, const GemmArgs &a_in)
 	a.table_sb = ctx->sched.gemm_table;
 	a.keep_idle_waves = ctx->sched.idle_waves ? 0 : 1;
 	a.stagger_ticks = ctx->sched.stagger_us * 100;
+	a.no_neg_modifier = ctx->sched.neg_modifier ? 0 : 1;
 	a.trace = trace_slot(ctx, "gemm m=%d n=%d k=%d", a.m, a.n, a.k1 - a.k0);
 	// GPEMU_PROF_GEMM: every GEMM launch; GPEMU_PROF_GEMM_BIG: only the launches that run the 128x128 8-wave kernel
 	// (gemm_nt_kernel<128,128,4,4,2,0>, the dominant kernel of a batched factorisation); GPEMU_PROF_GEMM_K512: only
@@ -154,6 +155,7 @@ static Sched read_environment()
 	sc.kvec_gram = geti("GPEMU_KVEC_GRAM", 1) != 0;
 	sc.gemv_point = geti("GPEMU_GEMV_POINT", 1) != 0;
 	sc.idle_waves = geti("GPEMU_IDLE_WAVES", 1) != 0;
+	sc.neg_modifier = geti("GPEMU_NEG_MODIFIER", 1) != 0;
 	sc.stagger_us = std::max(0, std::min(1000, geti("GPEMU_STAGGER_US", 20)));
 	sc.factor_ahead = geti("GPEMU_FACTOR_AHEAD", 1) != 0;
 	v = geti("GPEMU_NB_TOP", 0);
@@ -1811,6 +1813,7 @@ extern "C" int gpemu_test_gemm_bench(gpemu_ctx *ctx, int m, int n, int k, int ld
 	g.big_tiles = ctx->sched.gemm_big_tiles; g.table_sb = ctx->sched.gemm_table;
 	g.keep_idle_waves = ctx->sched.idle_waves ? 0 : 1;
 	g.stagger_ticks = ctx->sched.stagger_us * 100;
+	g.no_neg_modifier = ctx->sched.neg_modifier ? 0 : 1;
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0); hipEventCreate(&e1);
 	hipError_t e = launch_gemm(ctx->stream, g);

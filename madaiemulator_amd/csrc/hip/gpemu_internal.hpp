@@ -69,6 +69,7 @@ struct GemmArgs {
 	int table_sb;        // XCD-blocked tile table for launches of >= 512 tiles: side of the super-blocks (0: off)
 	int force_cfg;       // test/bench hook: 2 = 64x64 tiles, 8 = 128x128 tiles, 0 = automatic
 	int keep_idle_waves; // 1: waves above the diagonal of a triangular update's diagonal tiles compute their (unread) output anyway (A/B switch)
+	int no_neg_modifier; // 1: alpha = -1 by negating the accumulators on the way in and out, as rounds 1-3 did (A/B switch)
 	int stagger_ticks;   // > 0: of the launch's first round, the workgroup in the odd slot of its CU starts this many 10 ns ticks late (kernel comment)
 };
 
@@ -86,6 +87,7 @@ struct Sched {
 	int idle_waves = 1;          // GPEMU_IDLE_WAVES: waves wholly above the diagonal of a diagonal tile issue no matrix instructions
 	int nb_top = 0;              // GPEMU_NB_TOP: outer panel width; 0 = automatic (512 for one matrix, 2048 / 1024 for a batch)
 	int split_rhs_rows = 1;      // GPEMU_SPLIT_RHS_ROWS: big-tile updates take the 64 right-hand-side rows in a launch of their own
+	int neg_modifier = 1;        // GPEMU_NEG_MODIFIER: C - A B^T through the NEG bit of the fp64 matrix instruction
 	int stagger_us = 20;         // GPEMU_STAGGER_US: first-round offset between the two workgroups of a CU in the 128x128 GEMM (0 = none)
 };
 

@@ -79,7 +79,7 @@ __device__ __forceinline__ void tri_inverse16(double *M, int o, double *tile, in
 // k-ordered chain whatever the tile shape: 128x128 and 64x64 tiles give the same bits.
 // (The register-staged loops of rounds 1-2, their L2-prefetch variant and the 128x64 / 256x128 / 128x256 shapes measured
 // slower -- profiles/r02_gemm_*.txt -- and left the tree in round 3; `git log` has them.)
-template <int BM, int BN, int MINW, int WGM, int WGN, int FA = 0>
+template <int BM, int BN, int MINW, int WGM, int WGN, int FA = 0, int NEG = 0>
 __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs g)
 {
 	constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -134,9 +134,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 		// triangular B operand: the k-range grows with the tile column; start with the long tiles so that the tail
 		// of the launch is made of short ones
 		if (g.kend_mode) tn = (g.n + BN - 1) / BN - 1 - tn;
+		// (the other way round -- neighbours share the query rows and walk down the rows of L^-1 -- was measured on the
+		// prediction sweep: 0.70 against 1.01 M predictions/s, round 4)
 	}
 	if (g.tri && tn * BN > tm * BM + BM - 1 + g.diag_off) return;
 	const TraceT0 tr0 = trace_begin(g.trace);
+	// (prologue and epilogue at wave priority 3, the k-loop at 0: the prologue shrinks from 13.3 to 7.8 us -- its instructions
+	// wait for issue slots behind the neighbours' 64-cycle matrix instructions -- and the launch gets 1-4 % SLOWER: those
+	// slots were the neighbours' matrix instructions; the prologue's time is not idle matrix-pipe time.  Round 4.)
 	if (BM == 128 && g.stagger_ticks > 0 && (long)blockIdx.y * gridDim.x + blockIdx.x < 512) {
 		// The two workgroups that share a CU start together and their tiles take the same time: left alone they stay in
 		// phase for the whole launch -- both store their tile, both load the next one and its first chunks in the same tens
@@ -190,6 +195,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 	// would still be issued)
 	const bool idle = __builtin_amdgcn_readfirstlane((int)(g.tri && !g.keep_idle_waves && !(FA && g.fa && tm == 0 && tn == 0) &&
 	                                                     (tn * BN + wn * WN > tm * BM + wm * WM + WM - 1 + g.diag_off))) != 0;
+	// C - A B^T (alpha = -1 on top of C: every update of the factorisation): the matrix instruction negates its A operand
+	// (NEG bit of the fp64 MFMA, the builtin's last argument) instead of the accumulators being negated on the way in and on
+	// the way out -- 64 vector instructions per lane and tile less, and the C tile's load no longer has to land before the
+	// first operand chunk is requested.  fma(-a, b, c) = -fma(a, b, -c) exactly: same bits.
+	// (NEG = 1 instantiations; launch_gemm picks them for beta != 0, alpha = -1.  Both loops in one kernel spilled 100 registers.)
+	constexpr bool nega = NEG != 0;
 	d4_t acc[TM][TN];
 	if (idle) {
 #pragma unroll
@@ -206,6 +217,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 #pragma unroll
 					for (int j = 0; j < TN; j++) acc[i][j][r] = crow[j * 16];
 				}
+			// (the tile through buffer loads -- one lane offset, the row steps in scalar registers, the column steps in the
+			// immediate field: ~40 vector instructions of address arithmetic less per lane -- measured equal to slightly slower,
+			// round 4: the prologue's 13-15 us are not its vector instructions)
 		} else {
 #pragma unroll
 			for (int i = 0; i < TM; i++)
@@ -222,7 +236,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 		}
 		// C / alpha with alpha = +-1 (launch_gemm refuses anything else when beta is set): a sign flip, not 64 fp64
 		// multiplications per lane (same bits; measured neutral)
-		if (g.alpha < 0.0) {
+		if (g.alpha < 0.0 && !nega) {
 #pragma unroll
 			for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -296,12 +310,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 			_Pragma("unroll") for (int i = 0; i < TM; i++) FA_[i] = *reinterpret_cast<const d2_t *>(pa + i * 2048); \
 			_Pragma("unroll") for (int j = 0; j < TN; j++) FB_[j] = *reinterpret_cast<const d2_t *>(pb + j * 2048); \
 		} while (0)
-#define GEMM_BLOCK(FA_, FB_)                                                                                      \
+#define GEMM_BLOCK(FA_, FB_, NEG_)                                                                                \
 		do {                                                                                                      \
 			_Pragma("unroll") for (int h = 0; h < 2; h++)                                                          \
 				_Pragma("unroll") for (int i = 0; i < TM; i++)                                                     \
 					_Pragma("unroll") for (int j = 0; j < TN; j++)                                                 \
-						acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA_[i][h], FB_[j][h], acc[i][j], 0, 0, 0); \
+						acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA_[i][h], FB_[j][h], acc[i][j], 0, 0, NEG_); \
 		} while (0)
 		d2_t xa[TM], xb[TN], ya[TM], yb[TN];
 		// (every wave's buffer_load ... lds must have landed before the barrier that hands the chunk to the other waves: the
@@ -309,8 +323,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 		// (chunk 1 requested together with chunk 0, waiting for chunk 0 alone -- vmcnt(NPA + NPB) -- was measured: the 13-14 us
 		// of a tile's prologue did not move, round 4)
 		GEMM_DMA(0, kb);
+		unsigned long long clk_issue = 0;
+		if (g.trace && tr0.wall) clk_issue = clock64();
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		__syncthreads();
+		if (g.trace && tr0.wall) atomicAdd(g.trace + 7, (unsigned long long)clock64() - clk_issue);     // C tile and chunk 0 landing
 		if (kb + GEMM_BK < ke) GEMM_DMA(1, kb + GEMM_BK);
 		if (!idle) GEMM_FRAGS(xa, xb, 0, 0);
 		if (g.trace && tr0.wall) atomicAdd(g.trace + 5, (unsigned long long)clock64() - tr0.clk);   // prologue
@@ -319,7 +336,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 			if (!idle) {
 				GEMM_FRAGS(ya, yb, cur, 1);
 				__builtin_amdgcn_sched_barrier(0);
-				GEMM_BLOCK(xa, xb);
+				GEMM_BLOCK(xa, xb, NEG);
 			}
 			__builtin_amdgcn_sched_barrier(0);
 			// chunk k+1 (requested a k-step ago) has landed for every wave; every wave has read the last of chunk k
@@ -329,7 +346,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 			if (!idle) {
 				if (k + GEMM_BK < ke) GEMM_FRAGS(xa, xb, cur ^ 1, 0);
 				__builtin_amdgcn_sched_barrier(0);
-				GEMM_BLOCK(ya, yb);
+				GEMM_BLOCK(ya, yb, NEG);
 			}
 			__builtin_amdgcn_sched_barrier(0);
 			cur ^= 1;
@@ -344,7 +361,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 	// epilogue: alpha * accumulators (a sign flip or nothing for alpha = -+1, see above)
 	unsigned long long clk_loop_end = 0;
 	if (g.trace && tr0.wall) clk_loop_end = clock64();
-	if (g.alpha == -1.0) {
+	if (nega) {
+		// nothing: the accumulators hold C - A B^T
+	} else if (g.alpha == -1.0) {
 #pragma unroll
 		for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -719,9 +738,17 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs &a_in)
 	// (the first-round offset pays from the second round on: a launch that fits two rounds of 512 resident workgroups or fewer
 	// would only start its odd slots late)
 	if ((long)T * nbatch < 1024 || a.ksplit > 1) a.stagger_ticks = 0;
-	if (cfg == 8) hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 4, 4, 2>), dim3(T, nbatch), dim3(512), 0, s, a);
-	else if (a.fa) hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2, 1>), dim3(T, nbatch), dim3(256), 0, s, a);
-	else hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2>), dim3(T, nbatch), dim3(256), 0, s, a);
+	// C - A B^T on top of C (every update of the factorisation): the instantiations whose matrix instruction negates A
+	const bool neg = a.beta && a.alpha == -1.0 && !a.no_neg_modifier;
+	if (neg) {
+		if (cfg == 8) hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 4, 4, 2, 0, 1>), dim3(T, nbatch), dim3(512), 0, s, a);
+		else if (a.fa) hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2, 1, 1>), dim3(T, nbatch), dim3(256), 0, s, a);
+		else hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2, 0, 1>), dim3(T, nbatch), dim3(256), 0, s, a);
+	} else {
+		if (cfg == 8) hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 4, 4, 2>), dim3(T, nbatch), dim3(512), 0, s, a);
+		else if (a.fa) hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2, 1>), dim3(T, nbatch), dim3(256), 0, s, a);
+		else hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 2, 2>), dim3(T, nbatch), dim3(256), 0, s, a);
+	}
 	return hipGetLastError();
 }
 

@@ -1,11 +1,11 @@
-"""one lock-step likelihood batch of 16 at N=8192 under GPEMU_TRACE=1: device wall time by launch class (tag and, for the GEMM,
+"""one lock-step likelihood batch of B (argv[1], default 16) at N=8192 under GPEMU_TRACE=1: device wall time by launch class (tag and, for the GEMM,
 n x k), against the time the class's matrix instructions need at 78.6 TFLOP/s.  usage: python scratch/r04_batch_time_by_launch_class.py"""
 import os, re, sys, tempfile, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["GPEMU_TRACE"] = "1"
 import numpy as np
 from madaiemulator_amd import abi, synth
-N, d, B = 8192, 8, 16
+N, d, B = 8192, 8, (int(sys.argv[1]) if len(sys.argv) > 1 else 16)
 X, y = synth.design(N, d, 6)
 c = abi.Context(0)
 c.set_model(3, 1, X, y)

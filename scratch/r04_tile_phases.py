@@ -17,7 +17,7 @@ with tempfile.TemporaryDirectory() as t:
     p = os.path.join(t, "trace.txt")
     c.trace_dump(p)
     lines = open(p).read().splitlines()
-print("launch                          wall_us  wg_life_us  prologue_us  epilogue_us  GHz   mfma_us(half CU)  rounds")
+print("launch                          wall_us  wg_life_us  prologue_us  (landing_us)  epilogue_us  GHz   mfma_us(half CU)  rounds")
 for ln in lines:
     tag, _, times = ln.rpartition("|")
     m = re.search(r"gemm m=(\d+) n=(\d+) k=(\d+)", tag)
@@ -25,8 +25,9 @@ for ln in lines:
     mm, nn, kk = (int(v) for v in m.groups())
     q = [int(v) for v in times.split()]
     s, e, wsum, wn, wclk, pro, epi = q[:7]
+    land = q[7] if len(q) > 7 else 0
     if kk < 512 or wn == 0 or nn < 1024: continue
     ghz = wclk / max(wsum, 1)
     ideal = 2.0 * 128 * 128 * kk / (78.6e12 / 512) * 1e6
     tiles = sum(1 for i in range((mm + 127) // 128) for j in range((nn + 127) // 128) if j * 128 <= i * 128 + 127 + (mm - nn if mm > nn else 0)) * B
-    print("%-30s %8.1f %10.1f %11.1f %11.1f  %.2f %12.1f %10.2f" % (tag.strip()[:30], (e - s) / 1e3, wsum / wn / 1e3, pro / wn / ghz / 1e3, epi / wn / ghz / 1e3, ghz, ideal, tiles / 512.0))
+    print("%-30s %8.1f %10.1f %11.1f %13.1f %11.1f  %.2f %12.1f %10.2f" % (tag.strip()[:30], (e - s) / 1e3, wsum / wn / 1e3, pro / wn / ghz / 1e3, land / wn / ghz / 1e3, epi / wn / ghz / 1e3, ghz, ideal, tiles / 512.0))

@@ -28,14 +28,20 @@ for line in open(sys.argv[1]):
     name, calls, total = m.group(1), int(m.group(2)), float(m.group(3)) * 1024.0
     for pat, key in KEYS:
         if pat in name:
+            # (several instantiations share a key -- e.g. the NEG = 0 / 1 forms of one tile shape: their counts add up)
             e = out.setdefault(key, {})
-            e["launches"] = calls
+            seen = e.setdefault("_launches_by_counter", {})
+            seen[cur] = seen.get(cur, 0) + calls
+            e["launches"] = seen[cur]
             if cur == "FETCH_SIZE":
-                e["fetch_bytes_raw"] = total
-                e["fetch_bytes_corrected"] = 2.0 * total
+                e["fetch_bytes_raw"] = e.get("fetch_bytes_raw", 0.0) + total
+                e["fetch_bytes_corrected"] = 2.0 * e["fetch_bytes_raw"]
             elif cur == "WRITE_SIZE":
-                e["write_bytes"] = total
+                e["write_bytes"] = e.get("write_bytes", 0.0) + total
             break
+for v in out.values():
+    if isinstance(v, dict):
+        v.pop("_launches_by_counter", None)
 g = [v for k, v in out.items() if k.startswith("gemm_nt_kernel_")]
 if g:
     out["gemm_nt_kernel"] = {"launches": sum(e["launches"] for e in g), "fetch_bytes_raw": sum(e.get("fetch_bytes_raw", 0) for e in g),
