@@ -181,7 +181,8 @@ def train_through_cli(N, d, seed, dev, runs, exact=True, rank=0, world=1, local_
             cmd.append("--exact_gradient")
         t0 = time.perf_counter()
         try:
-            out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+            # (as ranks: a rank whose peer failed would wait for it; bounded so that the scaling run still ends in minutes)
+            out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600 if world == 1 else 180)
         except (subprocess.TimeoutExpired, OSError) as ex:
             return {"error": repr(ex)[:300]}
         wall = time.perf_counter() - t0
@@ -359,7 +360,7 @@ def pca8_train_ranks_cli(dev, rank, world, local_rank, rendezvous, restarts=4):
            "--exact_gradient"]
     t0 = time.perf_counter()
     try:
-        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420 if world == 1 else 120)
     except (subprocess.TimeoutExpired, OSError) as ex:
         return {"error": repr(ex)[:300]}
     wall = time.perf_counter() - t0
@@ -940,7 +941,10 @@ def main():
     # ---- region F: configs[3] TRAINED by the C product as one process per GPU (ranks.c): the bench ranks each start the CLI
     #      with their rank; the CLI processes gather the thetas among themselves through RCCL (gpemu_rccl_allgather)
     ranks_cli = None
-    if not args.no_pca8 and not args.no_train:
+    if distributed and train is not None and "error" in train:
+        ranks_cli = {"skipped": "the CLI ranks of region D failed; not tried again"}
+    d_failed = allreduce_max(1.0 if ranks_cli is not None else 0.0) > 0 if distributed else False
+    if not args.no_pca8 and not args.no_train and not d_failed:
         barrier()
         t0 = time.perf_counter()
         with tempfile.TemporaryDirectory(prefix="gpemu_bench_") as own:

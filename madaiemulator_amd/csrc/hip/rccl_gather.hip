@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <time.h>
 #include <unistd.h>
@@ -114,7 +115,7 @@ extern "C" int gpemu_rccl_allgather(int device, int rank, int world, const char 
 		const ncclResult_t e = R.GetUniqueId(&id);
 		if (e != ncclSuccess) return fail(GPEMU_ERR_HIP, std::string("ncclGetUniqueId: ") + (R.GetErrorString ? R.GetErrorString(e) : "error"));
 		if (!write_id(id_path, id)) return fail(GPEMU_ERR_ARG, std::string("cannot write ") + id_path);
-	} else if (!read_id(id_path, id, 600.0)) {
+	} else if (!read_id(id_path, id, getenv("GPEMU_RCCL_WAIT_S") ? atof(getenv("GPEMU_RCCL_WAIT_S")) : 600.0)) {
 		return fail(GPEMU_ERR_ARG, std::string("rank 0 never wrote ") + id_path);
 	}
 	ncclComm_t comm = nullptr;
