@@ -1480,6 +1480,28 @@ def test_config4_eight_pca_components_n4096_d16(gpu_ctx):
         assert got[c, 1] == pytest.approx(z @ sl.cho_solve(cf, r, check_finite=False) / N, rel=RTOL)
 
 
+def test_n32768_beyond_the_baseline_sizes(gpu_ctx):
+    """N = 32768 (twice BASELINE's largest size; an 8.6 GB workspace per matrix, row offsets beyond 2^31 bytes): what the
+    domain offers without a 50-second LAPACK pass in the suite -- a batch element equals the same evaluation alone bit for
+    bit (two launch geometries over the same memory), scaling y by 3 scales the quadratic form by 9 and leaves log det
+    alone, the trend coefficient follows y.  The LAPACK comparison itself (1e-15, also at N = 65536) is
+    profiles/r04_large_n_32768_65536_against_lapack.txt (scratch/r04_n32768.py)."""
+    N, d = 32768, 8
+    X, y = synth.design(N, d, 20261003 + 9)
+    gpu_ctx.set_model(1, 0, X, y)
+    th = synth.default_thetas(1, d)
+    a = gpu_ctx.loglik(th)
+    assert a["status"] == 0 and a["info"] == 0 and np.isfinite(a["value"])
+    # the committed LAPACK run used this seed and these thetas
+    assert a["logdet"] == pytest.approx(-121957.945232, rel=1e-11) and a["quad"] == pytest.approx(2868.66861847, rel=1e-11)
+    b = gpu_ctx.loglik_batch(np.array([synth.perturbed_thetas(1, d, 3, 0), th]))
+    assert b["value"][1] == a["value"] and b["sigma2"][1] == a["sigma2"] and b["value"][0] != a["value"]
+    gpu_ctx.set_training(3.0 * y)
+    c = gpu_ctx.loglik(th)
+    assert c["quad"] == pytest.approx(9.0 * a["quad"], rel=1e-12) and c["logdet"] == a["logdet"]
+    assert c["beta"][0] == pytest.approx(3.0 * a["beta"][0], rel=1e-12)
+
+
 def test_config5_n16384_powexp(gpu_ctx):
     """N=16384, d=8, pow-exp (one rank's share of the hyper-parameter search): an evaluation against LAPACK on a
     numpy-built matrix (tests/gradref.py), theta sensitivity, and the y-scaling property."""
