@@ -930,6 +930,42 @@ def test_emuplusplus_class(tmp_path):
     assert int(pca["info"][0][1]) == int(open(snap).read().split()[1])          # number_outputs == nr in PCA mode
 
 
+@pytest.mark.gpu
+def test_emuplusplus_reference_example_flow(tmp_path):
+    """the reference's own test/emuplusplus-test, step for step: train-emu.sh (`interactive_emulator estimate_thetas
+    input_model_file.dat univariate_snapshot_file --regression_order=1` on the uni-simple data, emu-dir/train-emulator.sh)
+    then sample-emu.sh (src/example.cpp: `emulator my_emu(filename)`, QueryEmulator for every location of
+    sample_locations.dat).  Means and errors = sqrt(variance) against the oracle's emulate_point at the thetas the search
+    wrote into the snapshot; the class's answers equal interactive_mode's on the same snapshot."""
+    build.build_all()
+    exe = str(tmp_path / "emupp_driver")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-I", os.path.join(ROOT, "include"), "-I", build.HOST_SRC, "-o", exe,
+                           os.path.join(ROOT, "tests", "c", "emupp_driver.cpp"), "-L", build.LIBDIR, "-lEmuPlusPlusMI",
+                           "-lEmuMI", "-lgpemu_hip", f"-Wl,-rpath,{build.LIBDIR}", "-lm"])
+    snap = tmp_path / "univariate_snapshot_file"
+    run([build.CLI_BIN, "estimate_thetas", UNI, str(snap), "--regression_order=1"], env=dict(os.environ, GPEMU_SEED="4", GPEMU_RESTARTS="3"))
+    qpath = os.path.join(INP, "emuplusplus-test.sample_locations.dat")
+    Xq = np.loadtxt(qpath).reshape(-1, 1)
+    assert len(Xq) == 16
+    res = parse(run([exe, str(snap), qpath]))
+    assert res["info"][0] == [1.0, 1.0, 1.0, 1.0]                 # one parameter, one output, regression order 1, pow-exp
+    got = np.array(res["single"]).reshape(16, 2)
+    assert np.array_equal(got, np.array(res["batch"]).reshape(16, 2), equal_nan=True)
+    snapshot = parse_snapshot(open(snap).read().split())
+    mdl = snapshot["models"][0]
+    X, Y = synth.read_input_model_file(UNI)
+    # oracle prediction in PCA space, then the reference's back-projection (nt = nr = 1, multivar_support.c:103-157)
+    m, v, _ = O.Emulator(1, 1, X, mdl["z"], mdl["thetas"]).emulate(Xq)
+    lam, u = float(snapshot["evals"][0]), float(snapshot["evecs"][0, 0])
+    mean = Y[:, 0].mean() + u * np.sqrt(lam) * m
+    var = u * u * lam * v
+    assert np.max(np.abs(got[:, 0] - mean)) < 1e-7 * max(1.0, np.abs(mean).max())
+    ok = var > 1e-9
+    assert ok.sum() >= 10 and np.allclose(got[ok, 1] ** 2, var[ok], rtol=1e-6)
+    cli = np.array(run([build.CLI_BIN, "interactive_mode", str(snap), "-q"], stdin=open(qpath)).split(), float).reshape(16, 2)
+    assert np.allclose(cli[:, 0], got[:, 0], rtol=1e-12, atol=1e-12)
+
+
 def parse_snapshot(toks):
     """MODEL_SNAPSHOT_FILE grammar"""
     it = iter(toks)
