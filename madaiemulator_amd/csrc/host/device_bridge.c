@@ -702,6 +702,24 @@ double estimateSigmaFull(gsl_vector *thetas_less_amp, void *params_in)
 
 /* emulator_struct.c:13-37: factor once, keep everything the sweep needs resident in HBM.  cinverse / beta /
  * h_matrix are filled on the host as well because they are public fields of the struct. */
+/* Would alloc_emulator_struct refuse this model?  1: the covariance matrix at model->thetas (amplitude included) is not
+ * numerically positive definite; 0: it factors.  The search factors the matrix at amplitude 1 (maxmultimin.c:311) and the
+ * emulator the one at the estimated amplitude with the same nugget: noise-free training data drive the unbounded BFGS of the
+ * reference towards nugget -> 0, where the first can still factor and the second no longer does.  The CLI warns at
+ * training time instead of leaving the discovery to interactive_mode. */
+int gpemu_host_emulator_setup_fails(modelstruct *model)
+{
+	int key = 0;                                                 /* (its address is the key) a context of its own, released below */
+	gpemu_ctx *ctx = bind_model(&key, model, "gpemu_host_emulator_setup_fails");
+	double *th = pack_vector(model->thetas);
+	double *beta = (double *)malloc(sizeof(double) * (size_t)model->options->nregression_fns);
+	int info = 0;
+	const int rc = gpemu_predict_setup(ctx, th, model->options->nthetas, beta, &info);
+	free(th); free(beta);
+	gpemu_host_release(&key);
+	return rc == GPEMU_ERR_NOT_PD;
+}
+
 emulator_struct *alloc_emulator_struct(modelstruct *model)
 {
 	emulator_struct *e = (emulator_struct *)malloc(sizeof(emulator_struct));

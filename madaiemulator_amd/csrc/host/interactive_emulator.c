@@ -97,6 +97,15 @@ static int estimate_thetas(struct cmdLineOpts *o)
 	if (!model) return perr("Failed to allocated multi_modelstruct.\n");
 	estimate_multi(model, out);
 	fclose(out);
+	if (gpemu_host_rank() == 0 && !getenv("GPEMU_NO_SNAPSHOT_CHECK")) {
+		/* (not in the reference, which lets interactive_mode find out) */
+		for (int i = 0; i < model->nr; i++)
+			if (gpemu_host_emulator_setup_fails(model->pca_model_array[i]))
+				fprintf(stderr, "# warning: component %d: the covariance matrix at the trained thetas (amplitude e^%.3f, nugget e^%.3f) is numerically "
+				        "singular -- interactive_mode will refuse this snapshot (\"trying to cholesky a non postive def matrix\").  Training data without "
+				        "noise drive the search, which is unbounded as in the reference, towards nugget -> 0.\n", i,
+				        gsl_vector_get(model->pca_model_array[i]->thetas, 0), gsl_vector_get(model->pca_model_array[i]->thetas, 1));
+	}
 	free_multimodelstruct(model);
 	return EXIT_SUCCESS;
 }

@@ -272,6 +272,9 @@ void gpemu_host_group_destroy(void *group);
  * the PCA components, estimate_thetas_threaded (single-output models) the runs of the run list to the ranks; the one
  * collective is an all-gather of a few doubles per rank (RCCL: gpemu_rccl_allgather; GPEMU_GATHER=file for ranks that share
  * a device).  Rank 0 writes the snapshot; every rank ends with the full model. */
+/* 1 when alloc_emulator_struct would refuse the model at its present thetas ("trying to cholesky a non postive def matrix"),
+ * without exiting: estimate_thetas warns with it when a search has ended on a numerically singular model */
+int gpemu_host_emulator_setup_fails(modelstruct *model);
 int gpemu_host_world_size(void);
 int gpemu_host_rank(void);
 void gpemu_host_rank_device(void);

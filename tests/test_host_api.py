@@ -6,6 +6,7 @@ import sys
 
 import numpy as np
 import pytest
+import scipy.linalg as sl
 
 from madaiemulator_amd import build, synth
 from oracle import oracle as O
@@ -928,6 +929,88 @@ def test_emuplusplus_class(tmp_path):
     assert np.all(np.isnan(rest) | (np.nan_to_num(rest) < 1e-6))
     pca = parse(run([exe, str(snap), str(qf), "pca"]))
     assert int(pca["info"][0][1]) == int(open(snap).read().split()[1])          # number_outputs == nr in PCA mode
+
+
+def _oracle_through_snapshot(snap_text, Xq):
+    """oracle emulate_point per PCA component at the thetas of a MODEL_SNAPSHOT_FILE, back-projected as the reference does"""
+    sd = parse_snapshot(snap_text.split())
+    nr = sd["nr"]
+    m_pca, v_pca = np.empty((len(Xq), nr)), np.empty((len(Xq), nr))
+    for c, comp in enumerate(sd["models"]):
+        m_pca[:, c], v_pca[:, c], _ = O.Emulator(comp["cov"], comp["order"], comp["X"], comp["z"], comp["thetas"]).emulate(Xq)
+    ybar = sd["Y"].mean(axis=0)
+    out = [O.pca_backproject(ybar, sd["evals"], sd["evecs"], m_pca[q], v_pca[q]) for q in range(len(Xq))]
+    return sd, np.array([o[0] for o in out]), np.array([o[1] for o in out])
+
+
+@pytest.mark.gpu
+def test_reference_example_scripts_uni_2d_param_and_multi_simple(tmp_path):
+    """the two other example directories of the reference, with the command lines of their scripts:
+    test/uni-2d-param (train-emulator.sh: `estimate_thetas Latin_square_sampling_2d_samp_fn_200.dat M.dat
+    --regression_order=1`; sample-emulator.sh: `interactive_mode M.dat < sample_locations.dat`, nskip = 4 + nparams header
+    lines, then mean / variance alternating) and test/multi-simple (train-emulator.sh: `--regression_order=0`;
+    sample-emu.sh: the two points "0.03 0.04 0.01" and "0.05 0.02 0.01").  Every printed value against the oracle at the
+    thetas the snapshot holds."""
+    cli = build.CLI_BIN
+    env = dict(os.environ, GPEMU_SEED="2718", GPEMU_RESTARTS="3")
+    # uni-2d-param.  Its training values are a smooth function WITHOUT noise: the likelihood grows as the nugget -> 0 and the
+    # search (unbounded, as the reference's gsl bfgs2) ends at a nugget of e^-33 whatever the seed -- a covariance matrix of
+    # condition 1e16 that LAPACK refuses too.  The product says so when it writes the snapshot, and interactive_mode then ends
+    # with the reference's own message (emulate-fns.c:282-285); what is checked is that the two agree with an independent
+    # judgement of the matrix.
+    snap = tmp_path / "M.dat"
+    tr = subprocess.run([cli, "estimate_thetas", TWOD, str(snap), "--regression_order=1"], env=env, capture_output=True, text=True, timeout=600)
+    assert tr.returncode == 0
+    qpath = os.path.join(INP, "uni-2d-param.sample_locations.dat")
+    Q = np.array(open(qpath).read().split(), float).reshape(-1, 2)
+    sd = parse_snapshot(snap.read_text().split())
+    assert (sd["nt"], sd["nr"], sd["d"], sd["N"]) == (1, 1, 2, 200) and sd["models"][0]["order"] == 1
+    import gradref
+    Cm, _ = gradref.powexp_matrix(sd["models"][0]["X"], sd["models"][0]["thetas"])
+    try:
+        sl.cho_factor(Cm, lower=True)
+        lapack_ok = True
+    except np.linalg.LinAlgError:
+        lapack_ok = False
+    im = subprocess.run([cli, "interactive_mode", str(snap)], stdin=open(qpath), capture_output=True, text=True, timeout=600)
+    warned = "numerically singular" in tr.stderr
+    if im.returncode != 0:
+        assert "trying to cholesky a non postive def matrix, in emulate-fns.c sorry..." in im.stderr
+        assert warned and not lapack_ok and sd["models"][0]["thetas"][1] < -25.0
+    else:
+        assert not warned
+        lines = im.stdout.split()
+        assert lines[:6] == ["2", "param_0", "param_1", "2", "mean_0", "variance_0"]          # nskip = 6 = 4 + nparams
+        vals = np.array(lines[6:], float).reshape(-1, 2)
+        assert len(vals) == len(Q) > 100
+        _, mean, var = _oracle_through_snapshot(snap.read_text(), Q)
+        assert np.max(np.abs(vals[:, 0] - mean[:, 0])) < 1e-7 * max(1.0, np.abs(mean).max())
+        assert np.max(np.abs(vals[:, 1] - var[:, 0])) < 1e-7 * max(1e-3, np.abs(var).max())
+    # the same example with the thetas an analyst would settle on once warned (a nugget of e^-9 under the trained length
+    # scales): sample-emulator.sh's output against the oracle
+    th = np.array(sd["models"][0]["thetas"], float)
+    th[1] = -9.0
+    X2, Y2 = synth.read_input_model_file(TWOD)
+    snap2 = tmp_path / "M_nugget.dat"
+    snap2.write_text(synth.single_output_snapshot(X2, Y2[:, 0], 1, 1, th))
+    lines = run([cli, "interactive_mode", str(snap2)], stdin=open(qpath)).split()
+    assert lines[:6] == ["2", "param_0", "param_1", "2", "mean_0", "variance_0"]              # nskip = 6 = 4 + nparams
+    vals = np.array(lines[6:], float).reshape(-1, 2)
+    assert len(vals) == len(Q) == 1024
+    _, mean, var = _oracle_through_snapshot(snap2.read_text(), Q)
+    assert np.max(np.abs(vals[:, 0] - mean[:, 0])) < 1e-7 * max(1.0, np.abs(mean).max())
+    assert np.max(np.abs(vals[:, 1] - var[:, 0])) < 1e-7 * max(1e-3, np.abs(var).max())
+    # multi-simple
+    snap = tmp_path / "multi_snapshot_file"
+    run([cli, "estimate_thetas", MULTI, str(snap), "--regression_order=0"], env=env)
+    lines = run([cli, "interactive_mode", str(snap)], input="0.03 0.04 0.01\n0.05 0.02 0.01\n").split()
+    sd, mean, var = _oracle_through_snapshot(snap.read_text(), np.array([[0.03, 0.04, 0.01], [0.05, 0.02, 0.01]]))
+    nt = sd["nt"]
+    header = 1 + 3 + 1 + 2 * nt
+    assert lines[0] == "3" and lines[4] == str(2 * nt) and lines[5] == "mean_0" and lines[header - 1] == f"variance_{nt - 1}"
+    vals = np.array(lines[header:], float).reshape(2, nt, 2)
+    assert np.max(np.abs(vals[:, :, 0] - mean)) < 1e-7 * max(1.0, np.abs(mean).max())
+    assert np.max(np.abs(vals[:, :, 1] - var)) < 1e-7 * max(1e-3, np.abs(var).max())
 
 
 @pytest.mark.gpu
