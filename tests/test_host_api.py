@@ -183,6 +183,26 @@ def test_snapshot_golden_g7_roundtrips_byte_for_byte(driver, tmp_path):
     assert out.read_bytes() == open(G6SNAP, "rb").read()
 
 
+def test_print_thetas_mode(tmp_path):
+    """`interactive_emulator print_thetas MODEL_SNAPSHOT_FILE` (interactive_emulator.c:455-510 of the reference): the table of
+    exp(theta) per PCA component with the component's share of the kept variance ("%lf" fields, tab separated), and one
+    pca_emu_summary_<i>.dat per component (design columns and the component's training values) in the working directory.
+    Host logic only: no device is touched."""
+    out = subprocess.run([build.CLI_BIN, "print_thetas", G6SNAP], capture_output=True, text=True, timeout=60, cwd=tmp_path)
+    assert out.returncode == 0, out.stderr
+    sd = parse_snapshot(open(G6SNAP).read().split())
+    lines = out.stdout.splitlines()
+    assert lines[0] == "#-- EMULATOR LENGTH SCALES (thetas) IN PCA SPACE -- #"
+    assert lines[1] == "#-- id\tpca-var\tScale\tNugget" + "".join(f"\tlength_{k}" for k in range(sd["d"])) + " -- #"
+    assert len(lines) == 2 + sd["nr"]
+    for i, comp in enumerate(sd["models"]):
+        want = "%d\t" % i + "%f\t" % (sd["evals"][i] / sd["evals"].sum()) + "".join("%f\t" % np.exp(t) for t in comp["thetas"])
+        assert lines[2 + i] == want
+        rows = np.loadtxt(tmp_path / f"pca_emu_summary_{i}.dat")
+        assert rows.shape == (sd["N"], sd["d"] + 1)
+        assert np.allclose(rows[:, :-1], comp["X"], atol=5e-7) and np.allclose(rows[:, -1], comp["z"], atol=5e-7)
+
+
 def test_harness_snapshot_writer_is_the_products_dump_byte_for_byte(driver, tmp_path):
     """synth.snapshot_text / single_output_snapshot (what bench.py's interactive_mode regions feed the CLI: a
     MODEL_SNAPSHOT_FILE at SUPPLIED thetas) written in the reference's grammar and printf formats
