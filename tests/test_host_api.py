@@ -203,6 +203,26 @@ def test_print_thetas_mode(tmp_path):
         assert np.allclose(rows[:, :-1], comp["X"], atol=5e-7) and np.allclose(rows[:, -1], comp["z"], atol=5e-7)
 
 
+def test_cli_usage_and_argument_errors(tmp_path):
+    """the argument handling of interactive_emulator.c:255-345,520-545 of the reference: the usage text for too few
+    arguments, -h, an unknown mode or a missing file name; the reference's messages for files that cannot be opened; a
+    --pca_variance outside [0, 1] reported and replaced by 0.95 (and, the kept quirk, -v switching on --pca_output and
+    --quiet).  Host logic only."""
+    cli = build.CLI_BIN
+    def go(*args):
+        return subprocess.run([cli, *args], capture_output=True, text=True, timeout=60, cwd=tmp_path)
+    for args in ((), ("interactive_mode",), ("-h", "x", "y"), ("no_such_mode", "a", "b"), ("estimate_thetas", "only_one_file")):
+        r = go(*args)
+        assert r.returncode != 0 and r.stderr.startswith("useage:") and "print_thetas MODEL_SNAPSHOT_FILE" in r.stderr, args
+    r = go("print_thetas", "no_such_snapshot")
+    assert r.returncode != 0 and "Error opening file" in r.stderr
+    r = go("estimate_thetas", "no_such_input", "snap")
+    assert r.returncode != 0 and "Input File read failed." in r.stderr
+    r = go("print_thetas", G6SNAP, "--pca_variance=2.5")
+    assert r.returncode == 0 and "# err pca_variance argument given incorrect value: 2.500000" in r.stderr
+    assert "# using default value: 0.950000" in r.stderr and "# var-frac: 0.950000" in r.stderr
+
+
 def test_harness_snapshot_writer_is_the_products_dump_byte_for_byte(driver, tmp_path):
     """synth.snapshot_text / single_output_snapshot (what bench.py's interactive_mode regions feed the CLI: a
     MODEL_SNAPSHOT_FILE at SUPPLIED thetas) written in the reference's grammar and printf formats
@@ -1031,6 +1051,18 @@ def test_reference_example_scripts_uni_2d_param_and_multi_simple(tmp_path):
     vals = np.array(lines[header:], float).reshape(2, nt, 2)
     assert np.max(np.abs(vals[:, :, 0] - mean)) < 1e-7 * max(1.0, np.abs(mean).max())
     assert np.max(np.abs(vals[:, :, 1] - var)) < 1e-7 * max(1e-3, np.abs(var).max())
+
+
+@pytest.mark.gpu
+def test_cli_reads_the_input_model_file_from_stdin(tmp_path):
+    """INPUT_MODEL_FILE "-" (interactive_emulator.c:212-251 of the reference, "can be - to read from standard input"): the
+    same snapshot, byte for byte, as with the file name"""
+    cli = build.CLI_BIN
+    env = dict(os.environ, GPEMU_SEED="8", GPEMU_RESTARTS="2")
+    a, b = tmp_path / "from_file", tmp_path / "from_stdin"
+    run([cli, "estimate_thetas", UNI, str(a), "--regression_order=1"], env=env)
+    run([cli, "estimate_thetas", "-", str(b), "--regression_order=1"], env=env, stdin=open(UNI))
+    assert a.read_bytes() == b.read_bytes() and len(a.read_bytes()) > 500
 
 
 @pytest.mark.gpu
