@@ -103,7 +103,8 @@ static int estimate_thetas(struct cmdLineOpts *o)
 			if (gpemu_host_emulator_setup_fails(model->pca_model_array[i]))
 				fprintf(stderr, "# warning: component %d: the covariance matrix at the trained thetas (amplitude e^%.3f, nugget e^%.3f) is numerically "
 				        "singular -- interactive_mode will refuse this snapshot (\"trying to cholesky a non postive def matrix\").  Training data without "
-				        "noise drive the search, which is unbounded as in the reference, towards nugget -> 0.\n", i,
+				        "noise drive the search, which is unbounded as in the reference, towards nugget -> 0; GPEMU_NUGGET_FLOOR=<log nugget>, e.g. -12, "
+				        "gives the search a lower wall.\n", i,
 				        gsl_vector_get(model->pca_model_array[i]->thetas, 0), gsl_vector_get(model->pca_model_array[i]->thetas, 1));
 	}
 	free_multimodelstruct(model);

@@ -71,10 +71,21 @@ struct fdf {
 static double dot(const double *a, const double *b, int n) { double s = 0; for (int i = 0; i < n; i++) s += a[i] * b[i]; return s; }
 
 /* phi(alpha) = f(x + alpha p), dphi = g(x + alpha p).p ; NaN/inf values are reported as +inf so the search backs off */
+/* GPEMU_NUGGET_FLOOR (not in the reference; unset = no floor): a lower wall for the log nugget, the first of the optimised
+ * thetas (maxmultimin.c:281).  Training data without noise drive the unbounded search to nugget -> 0 and a numerically
+ * singular model (the reference's own test/uni-2d-param: e^-33); with the wall a trial point below it counts as unusable --
+ * exactly as one whose matrix does not factor -- and the line search backs off. */
+static double g_nugget_floor = -HUGE_VAL;
+
 static double phi(struct fdf *F, const double *x, const double *p, double alpha, double *gout, double *dphi, gsl_vector *xt, gsl_vector *gt)
 {
 	double f;
 	for (int i = 0; i < F->n; i++) gsl_vector_set(xt, i, x[i] + alpha * p[i]);
+	if (gsl_vector_get(xt, 0) < g_nugget_floor) {
+		for (int i = 0; i < F->n; i++) gout[i] = 0.0;
+		*dphi = INFINITY;
+		return INFINITY;
+	}
 	F->fdf(xt, F->args, &f, gt);
 	F->nevals++;
 	for (int i = 0; i < F->n; i++) gout[i] = gsl_vector_get(gt, i);
@@ -461,6 +472,8 @@ void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 		ngroups = gpemu_host_plan_groups(local_total > 0 ? local_total : 1, lockstep, per_slot, nslots, &nthreads, glo, ghi, gslot, 512);
 		if (ngroups < 1) { fprintf(stderr, "estimate_thetas_threaded: cannot lay out the lock-step groups\n"); exit(EXIT_FAILURE); }
 	} else if (nthreads > local_total) nthreads = local_total > 0 ? local_total : 1;
+	env = getenv("GPEMU_NUGGET_FLOOR");
+	g_nugget_floor = (env && *env) ? atof(env) : -HUGE_VAL;       /* (set before the worker threads exist) */
 	unsigned long seed = g_seed;
 	env = getenv("GPEMU_SEED");
 	if (env && atol(env) > 0) seed = (unsigned long)atol(env);

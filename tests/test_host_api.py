@@ -1026,13 +1026,15 @@ def test_reference_example_scripts_uni_2d_param_and_multi_simple(tmp_path):
         _, mean, var = _oracle_through_snapshot(snap.read_text(), Q)
         assert np.max(np.abs(vals[:, 0] - mean[:, 0])) < 1e-7 * max(1.0, np.abs(mean).max())
         assert np.max(np.abs(vals[:, 1] - var[:, 0])) < 1e-7 * max(1e-3, np.abs(var).max())
-    # the same example with the thetas an analyst would settle on once warned (a nugget of e^-9 under the trained length
-    # scales): sample-emulator.sh's output against the oracle
-    th = np.array(sd["models"][0]["thetas"], float)
-    th[1] = -9.0
-    X2, Y2 = synth.read_input_model_file(TWOD)
-    snap2 = tmp_path / "M_nugget.dat"
-    snap2.write_text(synth.single_output_snapshot(X2, Y2[:, 0], 1, 1, th))
+    # the same example with the lower wall the warning names (GPEMU_NUGGET_FLOOR, not in the reference): the search stops at
+    # the wall, the snapshot is usable, and sample-emulator.sh's output agrees with the oracle at the snapshot's thetas
+    assert "GPEMU_NUGGET_FLOOR" in tr.stderr or im.returncode == 0
+    snap2 = tmp_path / "M_floor.dat"
+    tr2 = subprocess.run([cli, "estimate_thetas", TWOD, str(snap2), "--regression_order=1"], env=dict(env, GPEMU_NUGGET_FLOOR="-12"),
+                         capture_output=True, text=True, timeout=600)
+    assert tr2.returncode == 0 and "numerically singular" not in tr2.stderr
+    th2 = parse_snapshot(snap2.read_text().split())["models"][0]["thetas"]
+    assert -12.0 <= th2[1] < -5.0                                   # walked down from the start range [-5, -2] to the wall
     lines = run([cli, "interactive_mode", str(snap2)], stdin=open(qpath)).split()
     assert lines[:6] == ["2", "param_0", "param_1", "2", "mean_0", "variance_0"]              # nskip = 6 = 4 + nparams
     vals = np.array(lines[6:], float).reshape(-1, 2)
