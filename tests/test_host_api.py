@@ -657,13 +657,13 @@ def test_one_process_per_gpu_ranks_write_the_serial_snapshot(tmp_path):
     GPEMU_WORLD_SIZE.  A multi-output model deals its PCA components to the ranks (multivar_support.c:20-28), a
     single-output model the runs of its run list (estimate_threaded.c:101-113); ONE all-gather of a few doubles per rank
     ends the search and rank 0 writes the snapshot -- byte for byte the one a single process writes, for W = 2 and for a
-    W that does not divide the work.  The ranks here share the one GPU of the box, so the gather goes through files
+    W larger than the number of components / not dividing the run list.  The ranks here share the one GPU of the box, so the gather goes through files
     (GPEMU_GATHER=file); on a node each rank has its own GPU and the gather is gpemu_rccl_allgather."""
     cli = build.CLI_BIN
     base = dict(os.environ, GPEMU_SEED="2024", GPEMU_RESTARTS="2", GPEMU_DEVICES="0")
     serial = tmp_path / "serial"
     run([cli, "estimate_thetas", MULTI, str(serial), "--regression_order=1"], env=base)
-    for world in (2, 3):
+    for world in (2, 4):                                            # (4 ranks for 3 components: one rank trains nothing)
         rdv = tmp_path / f"rdv_multi_{world}"
         rdv.mkdir()
         _run_ranks([cli, "estimate_thetas", MULTI, "@SNAP@", "--regression_order=1"], world, rdv, base,
