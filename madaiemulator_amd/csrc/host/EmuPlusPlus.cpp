@@ -12,7 +12,7 @@ void emulator::init(const std::string &path, bool pca)
 	FILE *fptr = fopen(path.c_str(), "r");
 	if (!fptr) {
 		std::cerr << "error opening statefile: " << path << std::endl;
-		exit(EXIT_FAILURE);
+		gpemu_host_exit(EXIT_FAILURE);
 	}
 	the_model = load_multi_modelstruct(fptr);
 	fclose(fptr);
@@ -33,7 +33,7 @@ void emulator::QueryEmulator(const std::vector<std::vector<double> > &xpoints, s
 	for (size_t q = 0; q < np; q++) {
 		if ((int)xpoints[q].size() != number_params) {
 			std::cerr << "Error::QueryEmulator called with incorrect number of dimensions in xpoint" << std::endl;
-			exit(EXIT_FAILURE);
+			gpemu_host_exit(EXIT_FAILURE);
 		}
 		for (int k = 0; k < number_params; k++) flat[q * number_params + k] = xpoints[q][k];
 	}
@@ -54,10 +54,10 @@ void emulator::QueryEmulator(const std::vector<double> &xpoint, std::vector<doub
 	if ((int)xpoint.size() != number_params) {
 		std::cerr << "Error::QueryEmulator called with incorrect number of dimensions in xpoint" << std::endl;
 		std::cerr << "xpoint.length: " << xpoint.size() << " emulator->number_params: " << number_params << std::endl;
-		exit(EXIT_FAILURE);
+		gpemu_host_exit(EXIT_FAILURE);
 	}
-	if (!Means.empty()) { std::cerr << "Error::QueryEmulator called with nonempty Means vector" << std::endl; exit(EXIT_FAILURE); }
-	if (!Errors.empty()) { std::cerr << "Error::QueryEmulator called with nonempty Errors vector" << std::endl; exit(EXIT_FAILURE); }
+	if (!Means.empty()) { std::cerr << "Error::QueryEmulator called with nonempty Means vector" << std::endl; gpemu_host_exit(EXIT_FAILURE); }
+	if (!Errors.empty()) { std::cerr << "Error::QueryEmulator called with nonempty Errors vector" << std::endl; gpemu_host_exit(EXIT_FAILURE); }
 	std::vector<std::vector<double> > xs(1, xpoint), mm, ee;
 	QueryEmulator(xs, mm, ee);
 	Means = mm[0];

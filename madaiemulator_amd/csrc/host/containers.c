@@ -6,13 +6,15 @@
 #include <string.h>
 #include <stdio.h>
 
+extern void gpemu_host_exit(int status) __attribute__((noreturn));   /* fatal.c */
+
 static gsl_block *block_alloc(size_t n, int zero)
 {
 	gsl_block *b = (gsl_block *)malloc(sizeof(gsl_block));
-	if (!b) { fprintf(stderr, "gsl_compat: out of memory\n"); exit(EXIT_FAILURE); }
+	if (!b) { fprintf(stderr, "gsl_compat: out of memory\n"); gpemu_host_exit(EXIT_FAILURE); }
 	b->size = n;
 	b->data = (double *)(zero ? calloc(n ? n : 1, sizeof(double)) : malloc((n ? n : 1) * sizeof(double)));
-	if (!b->data) { fprintf(stderr, "gsl_compat: out of memory\n"); exit(EXIT_FAILURE); }
+	if (!b->data) { fprintf(stderr, "gsl_compat: out of memory\n"); gpemu_host_exit(EXIT_FAILURE); }
 	return b;
 }
 

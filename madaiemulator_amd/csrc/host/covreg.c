@@ -91,7 +91,7 @@ void derivative_l_gauss(gsl_matrix *dCdTheta, gsl_matrix *xmodel, double thetaLe
 	gpemu_ctx *ctx = gpemu_host_scratch_ctx("derivative_l_gauss");
 	int rc = gpemu_derivative_gauss(ctx, N, xc, thetaLength, dCdTheta->data, (int)dCdTheta->tda);
 	free(xc);
-	if (rc) { fprintf(stderr, "derivative_l_gauss: gpemu error %d: %s\n", rc, gpemu_last_error(ctx)); exit(EXIT_FAILURE); }
+	if (rc) { fprintf(stderr, "derivative_l_gauss: gpemu error %d: %s\n", rc, gpemu_last_error(ctx)); gpemu_host_exit(EXIT_FAILURE); }
 }
 /* libEmu/emulator.c:401-433.  Literal: `rtemp` is never reset between (i,j) pairs (:410 vs :423-425), so element
  * (i,j) depends on every element before it in row-major order, and thetaLength is the raw (log-scale) value.  The
@@ -150,7 +150,7 @@ extern int gpemu_host_device(void);
 static void die_gpemu(gpemu_ctx *ctx, int rc, const char *where)
 {
 	fprintf(stderr, "%s: gpemu error %d: %s\n", where, rc, ctx ? gpemu_last_error(ctx) : "no context");
-	exit(EXIT_FAILURE);
+	gpemu_host_exit(EXIT_FAILURE);
 }
 
 static double *pack_matrix(const gsl_matrix *m)
@@ -173,7 +173,7 @@ void makeCovMatrix_fnptr(gsl_matrix *cov_matrix, gsl_matrix *xmodel, gsl_vector 
                          int nparams, double (*covariance_fn_ptr)(gsl_vector *, gsl_vector *, gsl_vector *, int, int))
 {
 	const int kind = gpemu_host_kind_of(covariance_fn_ptr);
-	if (!kind) { fprintf(stderr, "makeCovMatrix_fnptr: unknown covariance function (no device kernel)\n"); exit(EXIT_FAILURE); }
+	if (!kind) { fprintf(stderr, "makeCovMatrix_fnptr: unknown covariance function (no device kernel)\n"); gpemu_host_exit(EXIT_FAILURE); }
 	gpemu_ctx *ctx = NULL;
 	int rc = gpemu_ctx_create(&ctx, gpemu_host_device());
 	if (rc) die_gpemu(NULL, rc, "makeCovMatrix_fnptr");
@@ -195,7 +195,7 @@ void makeKVector_fnptr(gsl_vector *kvector, gsl_matrix *xmodel, gsl_vector *xnew
                        double (*covariance_fn_ptr)(gsl_vector *, gsl_vector *, gsl_vector *, int, int))
 {
 	const int kind = gpemu_host_kind_of(covariance_fn_ptr);
-	if (!kind) { fprintf(stderr, "makeKVector_fnptr: unknown covariance function (no device kernel)\n"); exit(EXIT_FAILURE); }
+	if (!kind) { fprintf(stderr, "makeKVector_fnptr: unknown covariance function (no device kernel)\n"); gpemu_host_exit(EXIT_FAILURE); }
 	gpemu_ctx *ctx = NULL;
 	int rc = gpemu_ctx_create(&ctx, gpemu_host_device());
 	if (rc) die_gpemu(NULL, rc, "makeKVector_fnptr");
@@ -255,7 +255,7 @@ void (*makeGradMatLength)(gsl_matrix *dCdTheta, gsl_matrix *xmodel, double theta
 
 static void need_global(const void *p, const char *who)
 {
-	if (!p) { fprintf(stderr, "%s: set_global_ptrs has not been called\n", who); exit(EXIT_FAILURE); }
+	if (!p) { fprintf(stderr, "%s: set_global_ptrs has not been called\n", who); gpemu_host_exit(EXIT_FAILURE); }
 }
 
 void makeCovMatrix(gsl_matrix *cov_matrix, gsl_matrix *xmodel, gsl_vector *thetas, int nmodel_points, int nthetas, int nparams)

@@ -11,8 +11,11 @@
 #include <string.h>
 #include <math.h>
 #include <pthread.h>
+#include <time.h>
 #include "libemu.h"
 #include "gpemu.h"
+
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 
 extern int gpemu_host_kind_of(double (*fn)(gsl_vector *, gsl_vector *, gsl_vector *, int, int));
 
@@ -143,11 +146,12 @@ void gpemu_host_eval_stats(long *value_evals, long *valgrad_evals, long *cached,
 static struct entry *g_entries = NULL;
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 
+static void die(gpemu_ctx *ctx, int rc, const char *where) __attribute__((noreturn));
 static void die(gpemu_ctx *ctx, int rc, const char *where)
 {
-	fprintf(stderr, "%s: gpemu error %d: %s\n", where, rc,
-	        ctx ? gpemu_last_error(ctx) : rc == GPEMU_ERR_NO_DEVICE ? "no usable HIP device" : "(reported by the lock-step group's device context)");
-	exit(EXIT_FAILURE);
+	/* (message and exit behind ONE gate, fatal.c: a device error usually hits several host threads at once) */
+	gpemu_host_fatal("%s: gpemu error %d: %s\n", where, rc,
+	                 ctx ? gpemu_last_error(ctx) : rc == GPEMU_ERR_NO_DEVICE ? "no usable HIP device" : "(reported by the lock-step group's device context)");
 }
 
 static struct entry *lookup(const void *key, int create)
@@ -186,7 +190,7 @@ gpemu_ctx *gpemu_host_scratch_ctx(const char *where)
 {
 	static __thread char tls_key;
 	struct entry *e = lookup(&tls_key, 1);
-	if (!e || !e->ctx) { fprintf(stderr, "%s: no device context\n", where); exit(EXIT_FAILURE); }
+	if (!e || !e->ctx) { fprintf(stderr, "%s: no device context\n", where); gpemu_host_exit(EXIT_FAILURE); }
 	return e->ctx;
 }
 
@@ -252,7 +256,7 @@ static struct entry *bind_model_entry(const void *key, modelstruct *m, const cha
 	struct entry *e = lookup(key, 1);
 	const optstruct *o = m->options;
 	const int kind = gpemu_host_kind_of(m->covariance_fn);
-	if (!kind) { fprintf(stderr, "%s: unknown covariance function (no device kernel)\n", where); exit(EXIT_FAILURE); }
+	if (!kind) { fprintf(stderr, "%s: unknown covariance function (no device kernel)\n", where); gpemu_host_exit(EXIT_FAILURE); }
 	const unsigned long long xsum = sum_matrix(m->xmodel), ysum = sum_vector(m->training_vector);
 	if (changed) *changed = 0;
 	if (e->xdata != m->xmodel->data || e->xsum != xsum || e->N != o->nmodel_points || e->d != o->nparams || e->kind != kind ||
@@ -389,6 +393,17 @@ void gpemu_host_group_destroy(void *group)
 	free(G);
 }
 
+/* GPEMU_FAULT_ENQUEUE=K (test hook): the K-th value+gradient round of the process's lock-step groups (1-based) reports a
+ * device error instead of enqueueing -- the way to see what a device failure in the middle of a threaded search does to the
+ * process (message, status 1: fatal.c) without having to break a GPU */
+static int fault_injected(void)
+{
+	static long seen = 0;
+	const char *e = getenv("GPEMU_FAULT_ENQUEUE");
+	if (!e || atol(e) < 1) return 0;
+	return __sync_add_and_fetch(&seen, 1) == atol(e);
+}
+
 /* all live members have deposited a request: the value+gradient requests go to the device as ONE lock-step batch; the
  * value-only requests of the same round (rare: the two end-of-run calls are answered from the members' caches) as a
  * second one, enqueued right behind it on the same stream before the first is collected.  Results into the slots and
@@ -423,6 +438,7 @@ static void group_run_round(struct group *G)
 	for (int k = 0; k < 2 && !rc; k++) {
 		const int pass = k == 0 ? first : 1 - first;
 		if (!m[pass]) continue;
+		if (pass && fault_injected()) die(NULL, GPEMU_ERR_HIP, "lock-step group (GPEMU_FAULT_ENQUEUE: injected device error)");
 		rc = pass ? gpemu_loglik_grad_batch_enqueue(ctx, m[1], th + (size_t)n * nt, nt) : gpemu_loglik_batch_enqueue(ctx, m[0], th, nt);
 	}
 	if (rc) die(ctx, rc, "lock-step group");
@@ -557,7 +573,7 @@ double evalFnMulti(const gsl_vector *theta_vec_less_amp, void *params_in)
 		val = GSL_NAN;
 	} else if (rc == GPEMU_ERR_REGRESSION) {
 		fprintf(stderr, "# err: estimateBeta\n# trying to cholesky a non postive def matrix, sorry...\n");
-		exit(1);                                          /* regression.c:134-160 */
+		gpemu_host_exit(1);                                          /* regression.c:134-160 */
 	} else if (rc) {
 		die(ctx, rc, "evalFnMulti");
 	}
@@ -601,7 +617,7 @@ void evalFnMultiList(const gsl_matrix *theta_rows_less_amp, void *params_in, dou
 					answer[p0 + b] = GSL_NAN;
 				} else if (status[b] == GPEMU_ERR_REGRESSION) {
 					fprintf(stderr, "# err: estimateBeta\n# trying to cholesky a non postive def matrix, sorry...\n");
-					exit(1);                                      /* regression.c:134-160 */
+					gpemu_host_exit(1);                                      /* regression.c:134-160 */
 				} else if (status[b]) {
 					die(ctx[k], status[b], "evalFnMultiList");
 				}
@@ -628,7 +644,7 @@ static void grad_failure(gpemu_ctx *ctx, int rc, const double *th, int nthetas)
 {
 	if (rc == GPEMU_ERR_NOT_PD) {
 		note_not_pd("gradFnMulti", th, nthetas);
-		exit(EXIT_FAILURE);                               /* maxmultimin.c:495 */
+		gpemu_host_exit(EXIT_FAILURE);                               /* maxmultimin.c:495 */
 	}
 	die(ctx, rc, "gradFnMulti");
 }
@@ -668,7 +684,7 @@ void evalFnGradMulti(const gsl_vector *theta_vec, void *params_in, double *fnval
 		if (rc == GPEMU_OK || rc == GPEMU_ERR_NOT_PD) vcache_put(&en->vc, th, nthetas, *fnval, s2, rc);
 	}
 	if (rc == GPEMU_ERR_NOT_PD) {
-		/* The reference would return GSL_NAN from evalFnMulti and then exit(EXIT_FAILURE) inside gradFnMulti
+		/* The reference would return GSL_NAN from evalFnMulti and then gpemu_host_exit(EXIT_FAILURE) inside gradFnMulti
 		 * (maxmultimin.c:349,495) -- a line-search trial point that is numerically not positive definite kills
 		 * the whole training run.  Here the pair reports NaN value AND NaN gradient and the line search backs off. */
 		note_not_pd("evalFnGradMulti", th, nthetas);
@@ -722,6 +738,7 @@ int gpemu_host_emulator_setup_fails(modelstruct *model)
 
 emulator_struct *alloc_emulator_struct(modelstruct *model)
 {
+	const double t0 = now_s();
 	emulator_struct *e = (emulator_struct *)malloc(sizeof(emulator_struct));
 	e->nparams = model->options->nparams;
 	e->nmodel_points = model->options->nmodel_points;
@@ -732,14 +749,21 @@ emulator_struct *alloc_emulator_struct(modelstruct *model)
 	e->beta_vector = gsl_vector_alloc(e->nregression_fns);
 	e->h_matrix = gsl_matrix_alloc(e->nmodel_points, e->nregression_fns);
 
+	/* GPEMU_SETUP_TRACE=1: host timestamps of the phases below on stderr (where an emulator's start-up time goes) */
+	const int trace = getenv("GPEMU_SETUP_TRACE") != NULL;
+	struct entry *en0 = lookup(e, 1);                 /* device context (the first one of a process also starts the HIP runtime) */
+	(void)en0;
+	const double t1 = now_s();
 	gpemu_ctx *ctx = bind_model(e, model, "alloc_emulator_struct");
+	const double t2 = now_s();
 	double *th = pack_vector(model->thetas);
 	double *beta = (double *)malloc(sizeof(double) * (size_t)e->nregression_fns);
 	int info = 0;
 	int rc = gpemu_predict_setup(ctx, th, e->nthetas, beta, &info);
+	const double t3 = now_s();
 	if (rc == GPEMU_ERR_NOT_PD) {
 		fprintf(stderr, "trying to cholesky a non postive def matrix, in emulate-fns.c sorry...\n");
-		exit(1);                                          /* emulate-fns.c:282-285 */
+		gpemu_host_exit(1);                                          /* emulate-fns.c:282-285 */
 	}
 	if (rc) die(ctx, rc, "alloc_emulator_struct");
 	for (int a = 0; a < e->nregression_fns; a++) gsl_vector_set(e->beta_vector, a, beta[a]);
@@ -749,6 +773,9 @@ emulator_struct *alloc_emulator_struct(modelstruct *model)
 		if (rc) die(ctx, rc, "alloc_emulator_struct(cinverse)");
 	}
 	free(th); free(beta);
+	if (trace)
+		fprintf(stderr, "# setup trace: host_allocs+context %.3f ms  upload_model %.3f ms  predict_setup %.3f ms  h_matrix+cinverse %.3f ms\n",
+		        (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (now_s() - t3) * 1e3);
 	return e;
 }
 
@@ -765,7 +792,7 @@ void free_emulator_struct(emulator_struct *e)
 void emulate_points(emulator_struct *e, gsl_matrix *points, double *mean, double *variance)
 {
 	struct entry *en = lookup(e, 0);
-	if (!en) { fprintf(stderr, "emulate_point: emulator_struct was not made by alloc_emulator_struct\n"); exit(EXIT_FAILURE); }
+	if (!en) { fprintf(stderr, "emulate_point: emulator_struct was not made by alloc_emulator_struct\n"); gpemu_host_exit(EXIT_FAILURE); }
 	double *q = pack_matrix(points);
 	int rc = gpemu_predict_batch(en->ctx, (int)points->size1, q, mean, variance);
 	free(q);
@@ -776,7 +803,7 @@ void emulate_points(emulator_struct *e, gsl_matrix *points, double *mean, double
 void emulate_points_enqueue(emulator_struct *e, gsl_matrix *points)
 {
 	struct entry *en = lookup(e, 0);
-	if (!en) { fprintf(stderr, "emulate_point: emulator_struct was not made by alloc_emulator_struct\n"); exit(EXIT_FAILURE); }
+	if (!en) { fprintf(stderr, "emulate_point: emulator_struct was not made by alloc_emulator_struct\n"); gpemu_host_exit(EXIT_FAILURE); }
 	double *q = pack_matrix(points);
 	int rc = gpemu_predict_batch_enqueue(en->ctx, (int)points->size1, q);
 	free(q);
@@ -786,7 +813,7 @@ void emulate_points_enqueue(emulator_struct *e, gsl_matrix *points)
 void emulate_points_collect(emulator_struct *e, int npoints, double *mean, double *variance)
 {
 	struct entry *en = lookup(e, 0);
-	if (!en) { fprintf(stderr, "emulate_point: emulator_struct was not made by alloc_emulator_struct\n"); exit(EXIT_FAILURE); }
+	if (!en) { fprintf(stderr, "emulate_point: emulator_struct was not made by alloc_emulator_struct\n"); gpemu_host_exit(EXIT_FAILURE); }
 	int rc = gpemu_predict_batch_collect(en->ctx, npoints, mean, variance);
 	if (rc) die(en->ctx, rc, "emulate_point");
 }

@@ -263,7 +263,7 @@ static void fmt_part(void *a, int part, int nparts)
 			if (j->cap[part] - used < 800) {                    /* two numbers of up to 328 characters each */
 				j->cap[part] = j->cap[part] * 2 + 4096;
 				j->buf[part] = (char *)realloc(j->buf[part], j->cap[part]);
-				if (!j->buf[part]) { perror("realloc"); exit(EXIT_FAILURE); }
+				if (!j->buf[part]) { perror("realloc"); gpemu_host_exit(EXIT_FAILURE); }
 			}
 			const double m = i < nout ? j->s->mean[(size_t)q * nout + i] : 0.0, v = i < nout ? j->s->var[(size_t)q * nout + i] : 0.0;
 			used += (size_t)snprintf(j->buf[part] + used, j->cap[part] - used, "%.17f\n%.17f\n", m, v);
@@ -346,12 +346,12 @@ int gpemu_host_interactive_loop(int fd_in, int fd_out, int nparams, int nout, in
 		slots[i].pts = (double *)malloc(sizeof(double) * (size_t)IO_BATCH_MAX * nparams);
 		slots[i].mean = (double *)malloc(sizeof(double) * (size_t)IO_BATCH_MAX * nout);
 		slots[i].var = (double *)malloc(sizeof(double) * (size_t)IO_BATCH_MAX * nout);
-		if (!slots[i].pts || !slots[i].mean || !slots[i].var) { perror("malloc"); exit(EXIT_FAILURE); }
+		if (!slots[i].pts || !slots[i].mean || !slots[i].var) { perror("malloc"); gpemu_host_exit(EXIT_FAILURE); }
 		q_push(&S->free_q, &slots[i]);
 	}
 	const double t0 = now_s();
 	pthread_t rd, wr;
-	if (pthread_create(&rd, NULL, reader_main, S) || pthread_create(&wr, NULL, writer_main, S)) { perror("pthread_create"); exit(EXIT_FAILURE); }
+	if (pthread_create(&rd, NULL, reader_main, S) || pthread_create(&wr, NULL, writer_main, S)) { perror("pthread_create"); gpemu_host_exit(EXIT_FAILURE); }
 	for (;;) {
 		struct io_slot *s = q_pop(&S->work_q);
 		const int last = s->last;

@@ -235,6 +235,13 @@ void callEmulateMCMulti(double *point_in, int *nydims_in, double *final_mean, do
 void freeEmulateMCMulti(int *nydims_in);
 
 /* ---- knobs of this implementation (not in the reference) ------------------------ */
+/* How the layer ends the process where the reference calls exit(1) (fatal.c): single entry -- the first caller wins, later
+ * ones sleep --, message, flush, _exit(status): no atexit handler or static destructor (the HIP runtime's) runs beside the
+ * host threads that are still inside device calls.  gpemu_host_fatal prints its message INSIDE the gate (one message however
+ * many threads fail together) and leaves with EXIT_FAILURE. */
+void gpemu_host_exit(int status) __attribute__((noreturn));
+void gpemu_host_fatal(const char *fmt, ...) __attribute__((noreturn, format(printf, 1, 2)));
+void gpemu_host_on_exit(void (*hook)(int status));
 void gpemu_host_set_device(int device);          /* pin the whole process to ONE HIP device (before the first device call) */
 /* device slots: GPEMU_DEVICES=0,1,... (repeats allowed), else every visible device, else the pinned one.  Independent
  * work (PCA components, restart groups, component emulators) is dealt to the slots; a thread working for a slot

@@ -28,7 +28,7 @@ extern gpemu_ctx *gpemu_host_scratch_ctx(const char *where);
 static void die_ll(gpemu_ctx *ctx, int rc, const char *where)
 {
 	fprintf(stderr, "%s: gpemu error %d: %s\n", where, rc, gpemu_last_error(ctx));
-	exit(EXIT_FAILURE);
+	gpemu_host_exit(EXIT_FAILURE);
 }
 
 /* rows: y (optional), then the columns of H -> C^-1 applied to each; returns nvec x N (caller frees) */
@@ -91,7 +91,7 @@ void chol_inverse_cov_matrix(optstruct *options, gsl_matrix *temp_matrix, gsl_ma
 	int rc = gpemu_chol_inverse(ctx, N, temp_matrix->data, (int)temp_matrix->tda, &logdet, &info);
 	if (rc == GPEMU_ERR_NOT_PD) {
 		fprintf(stderr, "trying to cholesky a non postive def matrix, in emulate-fns.c sorry...\n");
-		exit(1);
+		gpemu_host_exit(1);
 	}
 	if (rc) die_ll(ctx, rc, "chol_inverse_cov_matrix");
 	gsl_matrix_memcpy(result_matrix, temp_matrix);
@@ -115,7 +115,7 @@ void estimateBeta(gsl_vector *beta_vector, gsl_matrix *h_matrix, gsl_matrix *cin
 	}
 	if (!small_spd_inverse(A, nreg)) {
 		fprintf(stderr, "# err: estimateBeta\n# trying to cholesky a non postive def matrix, sorry...\n");
-		exit(1);                                          /* regression.c:134-160 */
+		gpemu_host_exit(1);                                          /* regression.c:134-160 */
 	}
 	for (int a = 0; a < nreg; a++) {
 		double s = 0.0;
@@ -209,7 +209,7 @@ double makeEmulatedVariance(gsl_matrix *inverse_cov_matrix, gsl_vector *kplus_ve
 	}
 	if (!small_spd_inverse(A, nreg)) {
 		fprintf(stderr, "trying to cholesky a non postive def matrix, sorry...\n");          /* emulator.c:751-766 */
-		exit(1);
+		gpemu_host_exit(1);
 	}
 	double reg = 0.0;
 	for (int a = 0; a < nreg; a++) {

@@ -82,7 +82,7 @@ void setup_optimization_ranges(optstruct *options, modelstruct *the_model)
 				fprintf(stderr, "#ranges failed\n");
 				printf("# %d ranges: %lf %lf\n", i, rangeMin, rangeMax);
 				printf("# sampleScale: %lf\n", s);
-				exit(EXIT_FAILURE);
+				gpemu_host_exit(EXIT_FAILURE);
 			}
 		}
 		gsl_matrix_set(options->grad_ranges, i, 0, rangeMin);
@@ -170,8 +170,8 @@ void dump_modelstruct_2(FILE *fptr, modelstruct *m)
 	fprintf(fptr, "\n");
 }
 
-static int rd_int(FILE *f) { int v = 0; if (fscanf(f, "%d%*c", &v) != 1) { fprintf(stderr, "snapshot: read error\n"); exit(EXIT_FAILURE); } return v; }
-static double rd_dbl(FILE *f) { double v = 0; if (fscanf(f, "%lf%*c", &v) != 1) { fprintf(stderr, "snapshot: read error\n"); exit(EXIT_FAILURE); } return v; }
+static int rd_int(FILE *f) { int v = 0; if (fscanf(f, "%d%*c", &v) != 1) { fprintf(stderr, "snapshot: read error\n"); gpemu_host_exit(EXIT_FAILURE); } return v; }
+static double rd_dbl(FILE *f) { double v = 0; if (fscanf(f, "%lf%*c", &v) != 1) { fprintf(stderr, "snapshot: read error\n"); gpemu_host_exit(EXIT_FAILURE); } return v; }
 
 /* modelstruct.c:419-467 */
 modelstruct *load_modelstruct_2(FILE *fptr)

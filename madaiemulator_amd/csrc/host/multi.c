@@ -195,8 +195,8 @@ void dump_multi_modelstruct(FILE *fptr, multi_modelstruct *m)
 		fprintf(fptr, "#gpemu matern_log_scale 1\n");
 }
 
-static int rd_int(FILE *f) { int v = 0; if (fscanf(f, "%d%*c", &v) != 1) { fprintf(stderr, "snapshot: read error\n"); exit(EXIT_FAILURE); } return v; }
-static double rd_dbl(FILE *f) { double v = 0; if (fscanf(f, "%lf%*c", &v) != 1) { fprintf(stderr, "snapshot: read error\n"); exit(EXIT_FAILURE); } return v; }
+static int rd_int(FILE *f) { int v = 0; if (fscanf(f, "%d%*c", &v) != 1) { fprintf(stderr, "snapshot: read error\n"); gpemu_host_exit(EXIT_FAILURE); } return v; }
+static double rd_dbl(FILE *f) { double v = 0; if (fscanf(f, "%lf%*c", &v) != 1) { fprintf(stderr, "snapshot: read error\n"); gpemu_host_exit(EXIT_FAILURE); } return v; }
 
 /* multi_modelstruct.c:406-472 */
 multi_modelstruct *load_multi_modelstruct(FILE *fptr)
@@ -326,10 +326,10 @@ void estimate_multi(multi_modelstruct *m, FILE *outfp)
 		struct component_job *jobs = (struct component_job *)calloc((size_t)nslots, sizeof *jobs);
 		for (int s = 0; s < nslots; s++) {
 			jobs[s].m = m; jobs[s].slot = s; jobs[s].nslots = nslots;
-			if (pthread_create(&tid[s], NULL, component_main, &jobs[s])) { perror("pthread_create"); exit(EXIT_FAILURE); }
+			if (pthread_create(&tid[s], NULL, component_main, &jobs[s])) { perror("pthread_create"); gpemu_host_exit(EXIT_FAILURE); }
 		}
 		for (int s = 0; s < nslots; s++)
-			if (pthread_join(tid[s], NULL)) { perror("pthread_join"); exit(EXIT_FAILURE); }
+			if (pthread_join(tid[s], NULL)) { perror("pthread_join"); gpemu_host_exit(EXIT_FAILURE); }
 		free(tid); free(jobs);
 	}
 	dump_multi_modelstruct(outfp, m);

@@ -470,7 +470,7 @@ void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 	int glo[512], ghi[512], gslot[512];
 	if (lockstep > 1) {
 		ngroups = gpemu_host_plan_groups(local_total > 0 ? local_total : 1, lockstep, per_slot, nslots, &nthreads, glo, ghi, gslot, 512);
-		if (ngroups < 1) { fprintf(stderr, "estimate_thetas_threaded: cannot lay out the lock-step groups\n"); exit(EXIT_FAILURE); }
+		if (ngroups < 1) { fprintf(stderr, "estimate_thetas_threaded: cannot lay out the lock-step groups\n"); gpemu_host_exit(EXIT_FAILURE); }
 	} else if (nthreads > local_total) nthreads = local_total > 0 ? local_total : 1;
 	env = getenv("GPEMU_NUGGET_FLOOR");
 	g_nugget_floor = (env && *env) ? atof(env) : -HUGE_VAL;       /* (set before the worker threads exist) */
@@ -520,16 +520,16 @@ void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 			gpemu_host_thread_device(dev);            /* the group's context is created on the creator's device */
 			groups[g] = gpemu_host_group_create(members, hi - lo);
 			gpemu_host_thread_device(pinned);
-			if (!groups[g]) { fprintf(stderr, "estimate_thetas_threaded: cannot create the lock-step group\n"); exit(EXIT_FAILURE); }
+			if (!groups[g]) { fprintf(stderr, "estimate_thetas_threaded: cannot create the lock-step group\n"); gpemu_host_exit(EXIT_FAILURE); }
 		}
 		free(members);
 	} else {
 		for (int i = 0; i < nthreads; i++) W[i].device = pinned >= 0 ? pinned : gpemu_host_slot_device(i);
 	}
 	for (int i = 0; i < nthreads; i++)
-		if (pthread_create(&tid[i], NULL, worker_main, &W[i])) { perror("pthread_create"); exit(EXIT_FAILURE); }
+		if (pthread_create(&tid[i], NULL, worker_main, &W[i])) { perror("pthread_create"); gpemu_host_exit(EXIT_FAILURE); }
 	for (int i = 0; i < nthreads; i++)
-		if (pthread_join(tid[i], NULL)) { perror("pthread_join"); exit(EXIT_FAILURE); }
+		if (pthread_join(tid[i], NULL)) { perror("pthread_join"); gpemu_host_exit(EXIT_FAILURE); }
 
 	printf("-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=-=\n");
 	for (int i = 0; i < nthreads; i++) {

@@ -41,7 +41,7 @@ int gpemu_host_world_size(void)
 int gpemu_host_rank(void)
 {
 	const int w = gpemu_host_world_size(), r = env_int("GPEMU_RANK", 0);
-	if (r < 0 || r >= w) { fprintf(stderr, "GPEMU_RANK %d outside [0, GPEMU_WORLD_SIZE = %d)\n", r, w); exit(EXIT_FAILURE); }
+	if (r < 0 || r >= w) { fprintf(stderr, "GPEMU_RANK %d outside [0, GPEMU_WORLD_SIZE = %d)\n", r, w); gpemu_host_exit(EXIT_FAILURE); }
 	return r;
 }
 
@@ -63,7 +63,7 @@ void gpemu_host_allgather(const double *send, int count, double *recv)
 	const int world = gpemu_host_world_size(), rank = gpemu_host_rank();
 	if (world == 1) { memcpy(recv, send, sizeof(double) * (size_t)count); return; }
 	const char *dir = getenv("GPEMU_RENDEZVOUS_DIR");
-	if (!dir || !*dir) { fprintf(stderr, "GPEMU_WORLD_SIZE > 1 needs GPEMU_RENDEZVOUS_DIR (a directory every rank can reach)\n"); exit(EXIT_FAILURE); }
+	if (!dir || !*dir) { fprintf(stderr, "GPEMU_WORLD_SIZE > 1 needs GPEMU_RENDEZVOUS_DIR (a directory every rank can reach)\n"); gpemu_host_exit(EXIT_FAILURE); }
 	const unsigned seq = g_gather_seq++;
 	const char *how = getenv("GPEMU_GATHER");
 	char path[4096];
@@ -73,9 +73,9 @@ void gpemu_host_allgather(const double *send, int count, double *recv)
 		snprintf(path, sizeof path, "%s/gather_%u_%d.bin", dir, seq, rank);
 		snprintf(tmp, sizeof tmp, "%s.tmp", path);
 		FILE *f = fopen(tmp, "wb");
-		if (!f || fwrite(send, sizeof(double), (size_t)count, f) != (size_t)count) { perror(tmp); exit(EXIT_FAILURE); }
+		if (!f || fwrite(send, sizeof(double), (size_t)count, f) != (size_t)count) { perror(tmp); gpemu_host_exit(EXIT_FAILURE); }
 		fclose(f);
-		if (rename(tmp, path)) { perror(path); exit(EXIT_FAILURE); }
+		if (rename(tmp, path)) { perror(path); gpemu_host_exit(EXIT_FAILURE); }
 		for (int r = 0; r < world; r++) {
 			snprintf(path, sizeof path, "%s/gather_%u_%d.bin", dir, seq, r);
 			int waited = 0;
@@ -86,7 +86,7 @@ void gpemu_host_allgather(const double *send, int count, double *recv)
 					fclose(f);
 					if (got == (size_t)count) break;
 				}
-				if ((waited += 5) > 3600 * 1000) { fprintf(stderr, "rank %d never delivered %s\n", r, path); exit(EXIT_FAILURE); }
+				if ((waited += 5) > 3600 * 1000) { fprintf(stderr, "rank %d never delivered %s\n", r, path); gpemu_host_exit(EXIT_FAILURE); }
 				sleep_ms(5);
 			}
 		}
@@ -95,5 +95,5 @@ void gpemu_host_allgather(const double *send, int count, double *recv)
 	char err[512] = "";
 	snprintf(path, sizeof path, "%s/rccl_id_%u", dir, seq);
 	const int rc = gpemu_rccl_allgather(gpemu_host_device(), rank, world, path, send, count, recv, err, sizeof err);
-	if (rc) { fprintf(stderr, "RCCL all-gather failed (%d): %s\n", rc, err); exit(EXIT_FAILURE); }
+	if (rc) { fprintf(stderr, "RCCL all-gather failed (%d): %s\n", rc, err); gpemu_host_exit(EXIT_FAILURE); }
 }

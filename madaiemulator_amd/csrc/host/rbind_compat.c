@@ -146,7 +146,7 @@ void setupEmulateMC(double *xmodel_in, int *nparams_in, double *training_in, int
 
 void callEmulateMC(double *point_in, double *mean_out, double *var_out)
 {
-	if (!emuMCData.emu) { fprintf(stderr, "callEmulateMC: setupEmulateMC has not been called\n"); exit(EXIT_FAILURE); }   /* rbind.c:416-419 asserts */
+	if (!emuMCData.emu) { fprintf(stderr, "callEmulateMC: setupEmulateMC has not been called\n"); gpemu_host_exit(EXIT_FAILURE); }   /* rbind.c:416-419 asserts */
 	const int d = emuMCData.model->options->nparams;
 	gsl_vector *pt = gsl_vector_alloc(d);
 	for (int i = 0; i < d; i++) gsl_vector_set(pt, i, point_in[i]);
@@ -181,7 +181,7 @@ void callEmulateMCMulti(double *point_in, int *nydims_in, double *final_mean, do
 	const int nydims = *nydims_in;
 	if (!emuMCDataMulti || nydims > emuMCDataMulti_n) {
 		fprintf(stderr, "callEmulateMCMulti: setupEmulateMCMulti has not been called for %d outputs\n", nydims);
-		exit(EXIT_FAILURE);
+		gpemu_host_exit(EXIT_FAILURE);
 	}
 	const int d = emuMCDataMulti[0].model->options->nparams;
 	gsl_matrix *pt = gsl_matrix_alloc(1, d);

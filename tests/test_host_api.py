@@ -120,6 +120,31 @@ def test_host_logic_without_gpu(tmp_path):
     assert not np.allclose(dd[0], dd[0].T)               # path dependent: not even symmetric
 
 
+def _noisy_model_file(path, N=150, d=2, seed=31337, nt=1):
+    X, y = synth.design(N, d, seed)
+    Y = np.stack([y + 0.15 * synth.normal(99 + t, N) + 0.3 * t * X[:, t % d] for t in range(nt)], axis=1)
+    with open(path, "w") as f:
+        f.write(f"{nt}\n{d}\n{N}\n")
+        np.savetxt(f, X, fmt="%.17g")
+        np.savetxt(f, Y, fmt="%.17g")
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="needs a machine WITHOUT a HIP device (the GPU form is test_device_error_in_a_threaded_search...)")
+def test_threaded_search_without_a_device_ends_with_status_1_not_a_signal(tmp_path):
+    """the host error path (csrc/host/fatal.c): a threaded search whose device context cannot be made -- every lock-step group
+    of every component thread fails at its first round, under the group mutex, with the sibling threads waiting -- ends
+    like the reference does where it cannot go on (maxmultimin.c:495: message, exit status 1): ONE message, status 1, no
+    signal, promptly.  Three components over three device slots, two groups each: six failing threads at once."""
+    build.build_all()
+    inp, snap = tmp_path / "in.dat", tmp_path / "snap.txt"
+    _noisy_model_file(inp, nt=4)
+    env = dict(os.environ, GPEMU_DEVICES="0,0,0", GPEMU_SEED="7", GPEMU_RESTARTS="24")
+    out = subprocess.run([build.CLI_BIN, "estimate_thetas", str(inp), str(snap), "--pca_variance=0.999"], env=env, capture_output=True,
+                         text=True, timeout=60)
+    assert out.returncode == 1, (out.returncode, out.stderr[-2000:])
+    assert out.stderr.count("gpemu error") == 1 and "no usable HIP device" in out.stderr, out.stderr[-2000:]
+
+
 def test_run_list_layout_over_threads_groups_and_slots():
     """how estimate_thetas_threaded deals a run list to host threads, lock-step groups and device slots
     (optimizer.c gpemu_host_plan_groups: pure arithmetic, no GPU): full groups of 16 first, two groups per slot, every slot
@@ -514,6 +539,29 @@ def test_training_in_lockstep_group_matches_per_thread_scheme(driver, tmp_path):
     for other in ("1", "threads"):
         assert abs(best["8"][0] - best[other][0]) < 1.0, best
         assert np.max(np.abs(best["8"][1] - best[other][1])) < 0.3, best
+
+
+@pytest.mark.gpu
+def test_device_error_in_a_threaded_search_ends_with_status_1_and_one_message(tmp_path):
+    """round-4 record: a device error inside a threaded search (a failed graph capture) ended the CLI with signal 11 --
+    exit() from a group thread under the group mutex, beside ~30 sibling threads inside HIP calls, two threads entering it
+    together.  GPEMU_FAULT_ENQUEUE=3 makes the third value+gradient round of the process report GPEMU_ERR_HIP in the middle
+    of a search over three component threads x two lock-step groups: the process must end as the reference does where it
+    cannot go on (maxmultimin.c:495, emulate-fns.c:282-285): message on stderr, exit status 1 -- not a signal, not a hang,
+    and the message ONCE (csrc/host/fatal.c: single entry, no atexit teardown of the HIP runtime)."""
+    build.build_all()
+    inp, snap = tmp_path / "in.dat", tmp_path / "snap.txt"
+    _noisy_model_file(inp, nt=4)
+    env = dict(os.environ, GPEMU_DEVICES="0,0,0", GPEMU_SEED="7", GPEMU_RESTARTS="24", GPEMU_FAULT_ENQUEUE="3")
+    out = subprocess.run([build.CLI_BIN, "estimate_thetas", str(inp), str(snap), "--pca_variance=0.999"], env=env, capture_output=True,
+                         text=True, timeout=120)
+    assert out.returncode == 1, (out.returncode, out.stderr[-2000:])
+    assert out.stderr.count("gpemu error 3") == 1 and "injected device error" in out.stderr, out.stderr[-2000:]
+    # the same search without the fault trains and writes its snapshot
+    del env["GPEMU_FAULT_ENQUEUE"]
+    ok = subprocess.run([build.CLI_BIN, "estimate_thetas", str(inp), str(snap), "--pca_variance=0.999"], env=env, capture_output=True,
+                        text=True, timeout=300)
+    assert ok.returncode == 0 and snap.stat().st_size > 1000, ok.stderr[-2000:]
 
 
 @pytest.mark.gpu
