@@ -738,6 +738,11 @@ int gpemu_host_emulator_setup_fails(modelstruct *model)
 
 emulator_struct *alloc_emulator_struct(modelstruct *model)
 {
+	return gpemu_host_alloc_emulator(model, getenv("GPEMU_SKIP_CINVERSE") == NULL);
+}
+
+emulator_struct *gpemu_host_alloc_emulator(modelstruct *model, int fill_cinverse)
+{
 	const double t0 = now_s();
 	emulator_struct *e = (emulator_struct *)malloc(sizeof(emulator_struct));
 	e->nparams = model->options->nparams;
@@ -768,7 +773,7 @@ emulator_struct *alloc_emulator_struct(modelstruct *model)
 	if (rc) die(ctx, rc, "alloc_emulator_struct");
 	for (int a = 0; a < e->nregression_fns; a++) gsl_vector_set(e->beta_vector, a, beta[a]);
 	makeHMatrix_fnptr(e->h_matrix, model->xmodel, e->nmodel_points, e->nparams, e->nregression_fns, model->makeHVector);
-	if (!getenv("GPEMU_SKIP_CINVERSE")) {
+	if (fill_cinverse) {
 		rc = gpemu_get_cinverse(ctx, e->cinverse->data);
 		if (rc) die(ctx, rc, "alloc_emulator_struct(cinverse)");
 	}

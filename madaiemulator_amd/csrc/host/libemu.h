@@ -21,6 +21,7 @@
 #define GPEMU_LIBEMU_H
 
 #include <stdio.h>
+#include <pthread.h>
 #include "gsl_compat.h"
 
 #ifdef __cplusplus
@@ -131,6 +132,9 @@ void makeKVector(gsl_vector *kvector, gsl_matrix *xmodel, gsl_vector *xnew, gsl_
                  int nparams);
 void makeHMatrix(gsl_matrix *h_matrix, gsl_matrix *xmodel, int nmodel_points, int nparams, int nregression_fns);
 
+void print_matrix(gsl_matrix *m, int nx, int ny);
+void initialise_new_x(gsl_matrix *new_x, int nparams, int nemulate_points, double emulate_min, double emulate_max);
+
 /* ---- libEmu/regression.h ------------------------------------------------ */
 void makeHVector_trivial(gsl_vector *h_vector, gsl_vector *x_location, int nparams);
 void makeHVector_linear(gsl_vector *h_vector, gsl_vector *x_location, int nparams);
@@ -171,8 +175,44 @@ void set_random_init_value(gsl_rng *rand, gsl_vector *x, gsl_matrix *ranges, int
 /* ---- libEmu/estimate_threaded.h ------------------------------------------ */
 void estimate_thetas_threaded(modelstruct *the_model, optstruct *options);
 int get_number_cpus(void);
+void setup_params(struct estimate_thetas_params *params_array, modelstruct *the_model, optstruct *options, int nthreads, int max_tries);
+void *estimate_thread_function(void *args);
+void fprintPt(FILE *f, pthread_t pt);
+
+/* ---- resultstruct.h:20-36 + libEmu/emulate-fns.h:13-27 (legacy_api.c) ------- */
+typedef struct resultstruct {
+	gsl_matrix *new_x;                /* nemulate_points x nparams */
+	gsl_vector *emulated_mean;
+	gsl_vector *emulated_var;
+	optstruct *options;
+	modelstruct *model;
+} resultstruct;
+void alloc_resultstruct(resultstruct *res, optstruct *opts);
+void free_resultstruct(resultstruct *res);
+void copy_resultstruct(resultstruct *dst, resultstruct *src);
+void fill_resultstruct(resultstruct *res, optstruct *options, char **input_data);
+void emulate_model_results(modelstruct *the_model, optstruct *options, resultstruct *results);
+void emulateAtPoint(modelstruct *the_model, gsl_vector *the_point, optstruct *options, double *the_mean, double *the_variance);
+void emulateAtPointList(modelstruct *the_model, gsl_matrix *point_list, optstruct *options, double *the_mean, double *the_variance);
+void emulateQuick(modelstruct *the_model, gsl_vector *the_point, optstruct *options, double *mean_out, double *var_out,
+                  gsl_matrix *h_matrix, gsl_matrix *cinverse, gsl_vector *beta_vector);
+void emulate_ith_location(modelstruct *the_model, optstruct *options, resultstruct *results, int i, gsl_matrix *h_matrix,
+                          gsl_matrix *cinverse, gsl_vector *beta_vector);
 
 /* ---- modelstruct.h / optstruct.h ------------------------------------------ */
+/* the older, optstruct-sized forms and the optstruct helpers (legacy_api.c; callers: libRbind, estimate_threaded.c:57-68) */
+void alloc_modelstruct(modelstruct *the_model, optstruct *options);
+void free_modelstruct(modelstruct *the_model);
+void copy_modelstruct(modelstruct *dst, modelstruct *src);
+void fill_modelstruct(modelstruct *the_model, optstruct *options, char **input_data);
+void dump_modelstruct(FILE *fptr, modelstruct *the_model, optstruct *opts);
+void load_modelstruct(FILE *fptr, modelstruct *the_model, optstruct *opts);
+void free_optstruct(optstruct *opts);
+void copy_optstruct(optstruct *dst, optstruct *src);
+void dump_optstruct(FILE *fptr, optstruct *opts);
+void load_optstruct(FILE *fptr, optstruct *opts);
+void setup_cov_fn(optstruct *opts);
+void setup_regression(optstruct *opts);
 modelstruct *alloc_modelstruct_2(gsl_matrix *xmodel, gsl_vector *training_vector, int cov_fn_index, int regression_order);
 void free_modelstruct_2(modelstruct *model);
 void dump_modelstruct_2(FILE *fptr, modelstruct *the_model);
@@ -189,6 +229,9 @@ void makeHMatrix_es(gsl_matrix *h_matrix, emulator_struct *e);
 void makeCovMatrix_es(gsl_matrix *cov_matrix, emulator_struct *e);
 void makeKVector_es(gsl_vector *kvector, gsl_vector *point, emulator_struct *e);
 void estimateBeta_es(gsl_vector *beta_vector, emulator_struct *e);
+/* alloc_emulator_struct with the say on the host copy of C^-1 (a public field, N x N doubles downloaded and mirrored:
+ * most of the call's time at large N): 0 leaves e->cinverse allocated but unfilled for callers that never read it */
+emulator_struct *gpemu_host_alloc_emulator(modelstruct *model, int fill_cinverse);
 /* extension: npoints query rows (npoints x nparams), mean/variance arrays of npoints */
 void emulate_points(emulator_struct *e, gsl_matrix *points, double *mean, double *variance);
 /* emulate_points in two halves (device work runs in between): used to query all PCA components at the same time */

@@ -234,6 +234,33 @@ int main(int argc, char **argv)
 		double *mm = (double *)malloc(sizeof(double) * q->size1), *vv = (double *)malloc(sizeof(double) * q->size1);
 		emulate_points(e, q, mm, vv);
 		for (size_t i = 0; i < q->size1; i++) printf("batch %.17g %.17g\n", mm[i], vv[i]);
+		{
+			/* libEmu/emulate-fns.h (legacy_api.c): the list form, the one-point form (process-wide pointers), the
+			 * caller's-matrices form and the resultstruct form give what emulate_point gives */
+			optstruct *o = model->options;
+			const int keep = o->nemulate_points;
+			o->nemulate_points = (int)q->size1;
+			emulateAtPointList(model, q, o, mm, vv);
+			for (size_t i = 0; i < q->size1; i++) printf("atlist %.17g %.17g\n", mm[i], vv[i]);
+			gsl_vector_view q0 = gsl_matrix_row(q, 0);
+			double m1, v1, m2, v2;
+			emulateAtPoint(model, &q0.vector, o, &m1, &v1);
+			emulateQuick(model, &q0.vector, o, &m2, &v2, e->h_matrix, e->cinverse, e->beta_vector);
+			printf("atpoint %.17g %.17g\nquick %.17g %.17g\n", m1, v1, m2, v2);
+			resultstruct res;
+			alloc_resultstruct(&res, o);
+			gsl_matrix_memcpy(res.new_x, q);
+			fflush(stdout);
+			FILE *keep_out = stdout;
+			stdout = stderr;                              /* (emulate_model_results prints the first coordinates on stdout) */
+			emulate_model_results(model, o, &res);
+			stdout = keep_out;
+			for (size_t i = 0; i < q->size1; i++) printf("results %.17g %.17g\n", gsl_vector_get(res.emulated_mean, i), gsl_vector_get(res.emulated_var, i));
+			emulate_ith_location(model, o, &res, 1, e->h_matrix, e->cinverse, e->beta_vector);
+			printf("ith %.17g %.17g\n", gsl_vector_get(res.emulated_mean, 1), gsl_vector_get(res.emulated_var, 1));
+			free_resultstruct(&res);
+			o->nemulate_points = keep;
+		}
 		free_emulator_struct(e);
 	}
 	return 0;
