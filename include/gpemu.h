@@ -63,6 +63,17 @@ int  gpemu_device_memory(int device, size_t *free_bytes, size_t *total_bytes);
  * receives the message of a failure. */
 int gpemu_rccl_allgather(int device, int rank, int world, const char *id_path, const double *send, int count,
                          double *recv, char *errbuf, size_t errlen);
+/* The same gather in three steps, for ranks that meet when they START (csrc/host/ranks.c: the communicator exists before
+ * the training begins, so a rank never sits in a rendezvous for as long as the slowest rank trains):
+ *   gpemu_rccl_unique_id       rank 0 makes the id (GPEMU_RCCL_ID_BYTES bytes = ncclUniqueId); the caller carries it over
+ *   gpemu_rccl_comm_create     every rank joins (ncclCommInitRank, collective); *comm_out is an opaque handle
+ *   gpemu_rccl_comm_allgather  ncclAllGather of count doubles per rank on the communicator's own stream, host buffers
+ *   gpemu_rccl_comm_destroy    the end of the communicator */
+#define GPEMU_RCCL_ID_BYTES 128
+int gpemu_rccl_unique_id(void *id_out, char *errbuf, size_t errlen);
+int gpemu_rccl_comm_create(int device, int rank, int world, const void *id, void **comm_out, char *errbuf, size_t errlen);
+int gpemu_rccl_comm_allgather(void *comm, const double *send, int count, double *recv, char *errbuf, size_t errlen);
+void gpemu_rccl_comm_destroy(void *comm);
 
 /* ---- model data (modelstruct.h:28-98: xmodel, training_vector) ------
  * Uploads the N x d design and the N training values to HBM and builds the

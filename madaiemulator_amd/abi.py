@@ -30,6 +30,10 @@ SYMBOLS = {
     "gpemu_device_count": (C.c_int, []),
     "gpemu_device_memory": (C.c_int, [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "gpemu_rccl_allgather": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_char_p, _dp, C.c_int, _dp, C.c_char_p, C.c_size_t]),
+    "gpemu_rccl_unique_id": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "gpemu_rccl_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]),
+    "gpemu_rccl_comm_allgather": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, C.c_char_p, C.c_size_t]),
+    "gpemu_rccl_comm_destroy": (None, [C.c_void_p]),
     "gpemu_set_model": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp]),
     "gpemu_set_training": (C.c_int, [C.c_void_p, _dp]),
     "gpemu_cov_matrix": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp]),

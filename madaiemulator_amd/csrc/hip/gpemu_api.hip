@@ -128,8 +128,10 @@ extern "C" int gpemu_device_memory(int device, size_t *free_bytes, size_t *total
 	if (device < 0 || device >= n) return GPEMU_ERR_ARG;
 	size_t fr = 0, tot = 0;
 	(void)hipGetDevice(&cur);
-	if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return GPEMU_ERR_HIP; }
-	(void)hipSetDevice(cur);
+	const bool ok = hipSetDevice(device) == hipSuccess && hipMemGetInfo(&fr, &tot) == hipSuccess;
+	if (!ok) (void)hipGetLastError();
+	(void)hipSetDevice(cur);                   // the caller's current device, on the error path too
+	if (!ok) return GPEMU_ERR_HIP;
 	if (free_bytes) *free_bytes = fr;
 	if (total_bytes) *total_bytes = tot;
 	return GPEMU_OK;

@@ -473,14 +473,17 @@ static int group_member_index(const struct group *G, const void *params)
 /* one member's request; returns the device status of ITS element */
 static int group_eval(struct group *G, const void *params, const double *th, int want_grad, double *val, double *sigma2, double *grad)
 {
+	/* (the checksums of a cache answer are taken BEFORE the group's mutex: N*(d+1) doubles per value-only request, and the
+	 * members of a group would otherwise queue behind each other's sums) */
+	unsigned long long xs = 0, ys = 0;
+	if (!want_grad) { xs = sum_matrix(G->model->xmodel); ys = sum_vector(G->model->training_vector); }
 	pthread_mutex_lock(&G->mu);
 	const int me = group_member_index(G, params);
 	if (!want_grad) {
 		/* value / sigma^2 at a point this member has already evaluated: no device work, no round -- provided the cached
 		 * numbers still belong to the model as it is NOW (same checksums of design and training values, same modes: the
 		 * check bind_model_entry makes in front of every device round is made here in front of every cache answer) */
-		if (G->vc_bound && (G->vc_modes != gpemu_host_modes() || G->vc_xsum != sum_matrix(G->model->xmodel) ||
-		                    G->vc_ysum != sum_vector(G->model->training_vector))) {
+		if (G->vc_bound && (G->vc_modes != gpemu_host_modes() || G->vc_xsum != xs || G->vc_ysum != ys)) {
 			for (int i = 0; i < G->nmembers; i++) vcache_clear(&G->vc[i]);
 			G->vc_bound = 0;
 		}

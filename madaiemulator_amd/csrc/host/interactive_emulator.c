@@ -97,6 +97,7 @@ static int estimate_thetas(struct cmdLineOpts *o)
 	if (!model) return perr("Failed to allocated multi_modelstruct.\n");
 	estimate_multi(model, out);
 	fclose(out);
+	gpemu_host_ranks_finish();                       /* (ranks.c: the one gather is behind us) */
 	if (gpemu_host_rank() == 0 && !getenv("GPEMU_NO_SNAPSHOT_CHECK")) {
 		/* (not in the reference, which lets interactive_mode find out) */
 		for (int i = 0; i < model->nr; i++)

@@ -329,6 +329,9 @@ int gpemu_host_world_size(void);
 int gpemu_host_rank(void);
 void gpemu_host_rank_device(void);
 void gpemu_host_allgather(const double *send, int count, double *recv);
+/* this rank's part in the run is over (after the last gather; idempotent, also run by a regular exit()): the RCCL communicator
+ * goes, the exit is marked as a regular one, rank 0 removes the run's files from the rendezvous directory */
+void gpemu_host_ranks_finish(void);
 
 /* interactive_mode's request/response loop (src/interactive_emulator.c:398-440) as a reader -> device -> writer pipeline
  * (interactive_io.c): reads points of nparams numbers from fd_in -- text, the reference's fscanf("%lf%*c") framing, or raw

@@ -66,6 +66,7 @@ struct fdf {
 	void *args;
 	int n;
 	int nevals;
+	double nugget_floor;     /* GPEMU_NUGGET_FLOOR of THIS run (below); -inf: none */
 };
 
 static double dot(const double *a, const double *b, int n) { double s = 0; for (int i = 0; i < n; i++) s += a[i] * b[i]; return s; }
@@ -74,14 +75,22 @@ static double dot(const double *a, const double *b, int n) { double s = 0; for (
 /* GPEMU_NUGGET_FLOOR (not in the reference; unset = no floor): a lower wall for the log nugget, the first of the optimised
  * thetas (maxmultimin.c:281).  Training data without noise drive the unbounded search to nugget -> 0 and a numerically
  * singular model (the reference's own test/uni-2d-param: e^-33); with the wall a trial point below it counts as unusable --
- * exactly as one whose matrix does not factor -- and the line search backs off. */
-static double g_nugget_floor = -HUGE_VAL;
+ * exactly as one whose matrix does not factor -- and the line search backs off.  A START point below the wall (the search
+ * box of the log nugget is [-5, -2], optstruct.c:142-250: only a floor above -5 can cut into it) is moved onto the wall:
+ * evaluated where it was drawn, every trial of its run would count as unusable and the run would end where it began.
+ * The floor is read per run and travels in the run's own struct fdf: concurrent searches (the component threads of
+ * estimate_multi) share nothing. */
+static double nugget_floor_from_env(void)
+{
+	const char *env = getenv("GPEMU_NUGGET_FLOOR");
+	return (env && *env) ? atof(env) : -HUGE_VAL;
+}
 
 static double phi(struct fdf *F, const double *x, const double *p, double alpha, double *gout, double *dphi, gsl_vector *xt, gsl_vector *gt)
 {
 	double f;
 	for (int i = 0; i < F->n; i++) gsl_vector_set(xt, i, x[i] + alpha * p[i]);
-	if (gsl_vector_get(xt, 0) < g_nugget_floor) {
+	if (gsl_vector_get(xt, 0) < F->nugget_floor) {
 		for (int i = 0; i < F->n; i++) gout[i] = 0.0;
 		*dphi = INFINITY;
 		return INFINITY;
@@ -206,7 +215,7 @@ int doOptimizeMultiMin(double (*fn)(const gsl_vector *, void *),
 	const double stepSizeInit = 1.5, tolerance = 0.5, epsAbs = 0.1;
 	int status = GSL_CONTINUE, stepcount = 0;
 
-	struct fdf F = {fnGradFn, args, n, 0};
+	struct fdf F = {fnGradFn, args, n, 0, nugget_floor_from_env()};
 	double *x = (double *)malloc(sizeof(double) * (size_t)n), *g = (double *)malloc(sizeof(double) * (size_t)n);
 	double *p = (double *)malloc(sizeof(double) * (size_t)n), *gn = (double *)malloc(sizeof(double) * (size_t)n);
 	double *s = (double *)malloc(sizeof(double) * (size_t)n), *yv = (double *)malloc(sizeof(double) * (size_t)n);
@@ -214,6 +223,7 @@ int doOptimizeMultiMin(double (*fn)(const gsl_vector *, void *),
 	double *H = (double *)calloc((size_t)n * n, sizeof(double));
 	gsl_vector *xt = gsl_vector_alloc(n), *gt = gsl_vector_alloc(n);
 	for (int i = 0; i < n; i++) { x[i] = gsl_vector_get(thetaInit, i + 1); H[i * n + i] = 1.0; }
+	if (x[0] < F.nugget_floor) x[0] = F.nugget_floor;              /* a start point below the wall starts ON it */
 
 	double f, dd;
 	{
@@ -472,8 +482,6 @@ void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 		ngroups = gpemu_host_plan_groups(local_total > 0 ? local_total : 1, lockstep, per_slot, nslots, &nthreads, glo, ghi, gslot, 512);
 		if (ngroups < 1) { fprintf(stderr, "estimate_thetas_threaded: cannot lay out the lock-step groups\n"); gpemu_host_exit(EXIT_FAILURE); }
 	} else if (nthreads > local_total) nthreads = local_total > 0 ? local_total : 1;
-	env = getenv("GPEMU_NUGGET_FLOOR");
-	g_nugget_floor = (env && *env) ? atof(env) : -HUGE_VAL;       /* (set before the worker threads exist) */
 	unsigned long seed = g_seed;
 	env = getenv("GPEMU_SEED");
 	if (env && atol(env) > 0) seed = (unsigned long)atol(env);

@@ -738,6 +738,95 @@ def test_rank_gather_file_transport_three_processes(tmp_path):
     assert bad.returncode != 0 and "GPEMU_RENDEZVOUS_DIR" in bad.stderr
 
 
+_RANK_CODE = (
+    "import ctypes, os, signal, sys, time\n"
+    "from madaiemulator_amd import build\n"
+    "L = ctypes.CDLL(build.HOST_LIB)\n"
+    "L.gpemu_host_allgather.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.POINTER(ctypes.c_double)]\n"
+    "r, w = L.gpemu_host_rank(), L.gpemu_host_world_size()\n"
+    "time.sleep(float(os.environ.get('TEST_SLEEP_BEFORE_JOIN', '0')))\n"
+    "L.gpemu_host_rank_device()\n"                         # the start-up rendezvous (ranks.c join_run)
+    "what = os.environ.get('TEST_AFTER_JOIN', '')\n"
+    "if what == 'fatal': L.gpemu_host_fatal(b'rank %d: boom\\n', r)\n"
+    "if what == 'kill': os.kill(os.getpid(), signal.SIGKILL)\n"
+    "time.sleep(float(os.environ.get('TEST_SLEEP_BEFORE_GATHER', '0')))\n"
+    "send = (ctypes.c_double * 2)(10.0 * r, 10.0 * r + 1)\n"
+    "recv = (ctypes.c_double * (2 * w))()\n"
+    "L.gpemu_host_allgather(send, 2, recv)\n"
+    "L.gpemu_host_ranks_finish()\n"
+    "print(r, list(recv))\n")
+
+
+def _start_ranks(world, rdv, per_rank_env=None, ranks=None, **common):
+    procs = {}
+    for r in (range(world) if ranks is None else ranks):
+        env = dict(os.environ, GPEMU_RANK=str(r), GPEMU_WORLD_SIZE=str(world), GPEMU_GATHER="file", GPEMU_RENDEZVOUS_DIR=str(rdv))
+        env.update({k: str(v) for k, v in common.items()})
+        env.update((per_rank_env or {}).get(r, {}))
+        procs[r] = subprocess.Popen([sys.executable, "-c", _RANK_CODE], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env)
+    return procs
+
+
+def test_ranks_second_run_in_a_directory_that_holds_an_earlier_runs_files(tmp_path):
+    """ranks.c run nonce (round-4 advisor: file names carried only a per-process sequence number, so a reused
+    GPEMU_RENDEZVOUS_DIR handed a run the previous run's shares -- wrong thetas, no error -- or a dead communicator's id):
+    a directory littered with what a crashed run leaves (its run_id, a go file, acks, gather files under the old AND the new
+    naming, an rccl id) does not disturb a new run; a delayed rank 0 is waited for; a clean run leaves the directory as it
+    found it."""
+    import time
+    stale = {"run_id": b"4242-deadbeef00000".ljust(48, b"\0"), "go_4242-deadbeef00000": b"4242-deadbeef00000".ljust(48, b"\0") * 3 + b"\0" * 128,
+             "ack_4242-deadbeef00000_1": b"77-1".ljust(48, b"\0"), "gather_0_0.bin": np.array([666.0, 666.0]).tobytes(),
+             "gather_0_1.bin": np.array([666.0, 666.0]).tobytes(), "gather_4242-deadbeef00000_0_1.bin": np.array([666.0, 666.0]).tobytes(),
+             "rccl_id_0": b"x" * 128}
+    for name, data in stale.items():
+        (tmp_path / name).write_bytes(data)
+    want = [10.0 * r + i for r in range(3) for i in range(2)]
+    t0 = time.time()
+    procs = _start_ranks(3, tmp_path, per_rank_env={0: {"TEST_SLEEP_BEFORE_JOIN": "1.5"}})      # ranks 1, 2 meet the stale run_id first
+    for r, p in procs.items():
+        so, se = p.communicate(timeout=60)
+        assert p.returncode == 0, (r, se[-2000:])
+        assert so.strip() == f"{r} {want}"
+    assert time.time() - t0 < 30
+    left = sorted(f.name for f in tmp_path.iterdir())
+    assert left == sorted(n for n in stale if n != "run_id" and n != "ack_4242-deadbeef00000_1") or left == sorted(n for n in stale if n != "run_id"), left
+    # a second run right behind it, same directory
+    procs = _start_ranks(3, tmp_path)
+    for r, p in procs.items():
+        so, se = p.communicate(timeout=60)
+        assert p.returncode == 0 and so.strip() == f"{r} {want}", (r, se[-2000:])
+
+
+@pytest.mark.parametrize("how", ["fatal", "kill"])
+def test_ranks_do_not_wait_for_a_rank_that_is_gone(tmp_path, how):
+    """a rank that ends on the layer's error path after the rendezvous (fatal.c drops failed_<run>_<rank>) or is killed
+    outright (its pid disappears): the others sit in the gather, which has no deadline of its own (training may take
+    hours), and must end promptly with a message and status 1 instead of waiting (round 4: 600 s / 3600 s) -- the watchdog
+    thread of ranks.c."""
+    import time
+    t0 = time.time()
+    procs = _start_ranks(3, tmp_path, per_rank_env={1: {"TEST_AFTER_JOIN": how}})
+    so1, se1 = procs[1].communicate(timeout=60)                   # (reaped: a zombie's pid still answers kill(pid, 0))
+    assert procs[1].returncode == (1 if how == "fatal" else -9), se1
+    if how == "fatal":
+        assert "rank 1: boom" in se1
+    for r in (0, 2):
+        so, se = procs[r].communicate(timeout=60)
+        assert procs[r].returncode == 1, (r, so, se[-2000:])
+        # (rank 1's end, or the end it caused in the other survivor: whichever marker the watchdog met first)
+        assert f"rank {r}: rank " in se and "of this run" in se and "not waiting for it" in se, se
+    assert time.time() - t0 < 30
+
+
+def test_ranks_rendezvous_gives_up_on_a_rank_that_never_starts(tmp_path):
+    """the start-up rendezvous has a deadline (launch skew, GPEMU_RENDEZVOUS_WAIT_S), the only one there is"""
+    for ranks, msg in (((1,), "rank 1: rank 0 has not opened a run"), ((0,), "rank 0: rank 1 has not joined")):
+        procs = _start_ranks(2, tmp_path, ranks=ranks, GPEMU_RENDEZVOUS_WAIT_S="1")
+        for r, p in procs.items():
+            so, se = p.communicate(timeout=60)
+            assert p.returncode == 1 and msg in se, (r, se[-2000:])
+
+
 def _run_ranks(cmd, world, rendezvous, env, snap_of_rank):
     """start `world` processes of the CLI, rank r writing to snap_of_rank(r); returns their stdouts"""
     procs = []
