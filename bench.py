@@ -317,8 +317,31 @@ def pca8_emulator_cli(dev, npts=100000):
     with tempfile.TemporaryDirectory(prefix="gpemu_bench_") as tmp:
         snap, qf, res = os.path.join(tmp, "snap.txt"), os.path.join(tmp, "q.txt"), os.path.join(tmp, "out.txt")
         open(snap, "w").write(synth.snapshot_text(X, Y, evals, evecs, Z, 1, 0, ths))
-        np.savetxt(qf, synth.queries(npts, d, 5), fmt="%.17g")
+        Xq = synth.queries(npts, d, 5)
+        np.savetxt(qf, Xq, fmt="%.17g")
         env = dict(os.environ, GPEMU_DEVICE=str(dev), GPEMU_IO_STATS="1")
+        # parity gate in front of the clock: the first 64 points through the same CLI against an all-numpy / LAPACK chain
+        # (tests/gradref.py: emulator.c:578-593, 672-785 and the back-projection of multivar_support.c:126-151 restated;
+        # nothing of it comes from the device library): 8 components x one LAPACK factorisation at N = 4096
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+        import gradref
+        g64 = os.path.join(tmp, "q64.txt")
+        np.savetxt(g64, Xq[:64], fmt="%.17g")
+        try:
+            g = subprocess.run([build.CLI_BIN, "interactive_mode", snap, "-q"], stdin=open(g64, "rb"), capture_output=True, env=env, timeout=600)
+        except (subprocess.TimeoutExpired, OSError) as ex:
+            return {"error": "parity gate: " + repr(ex)[:300]}
+        if g.returncode != 0:
+            return {"error": "parity gate: " + g.stderr.decode(errors="replace")[-600:]}
+        got = np.array(g.stdout.split(), dtype=float).reshape(64, nt, 2)
+        mo, vo = np.empty((64, nr)), np.empty((64, nr))
+        for c in range(nr):
+            mo[:, c], vo[:, c] = gradref.predict(X, Z[:, c], 0, ths[c], Xq[:64])
+        ym, yv = gradref.backproject(mo, vo, evals, evecs, ybar)
+        gate = {"points": 64, "reference": "numpy/LAPACK (tests/gradref.py predict + backproject), 8 factorisations at N=4096",
+                "max_abs_mean_error": float(np.max(np.abs(got[:, :, 0] - ym))), "max_abs_variance_error": float(np.max(np.abs(got[:, :, 1] - yv))),
+                "mean_scale": float(np.max(np.abs(ym))), "variance_scale": float(np.max(yv)), "tolerance": "1e-8 of the scale"}
+        assert gate["max_abs_mean_error"] <= 1e-8 * gate["mean_scale"] and gate["max_abs_variance_error"] <= 1e-8 * gate["variance_scale"], gate
         try:
             p = subprocess.run([build.CLI_BIN, "interactive_mode", snap, "-q"], stdin=open(qf, "rb"), stdout=open(res, "wb"),
                                stderr=subprocess.PIPE, env=env, timeout=600)
@@ -329,7 +352,7 @@ def pca8_emulator_cli(dev, npts=100000):
             return {"error": p.stderr.decode(errors="replace")[-600:]}
         vals = np.loadtxt(res, max_rows=2 * nt * 256).reshape(-1, nt, 2)
         assert np.all(np.isfinite(vals)) and np.all(vals[:, :, 1] > 0.0)
-        return {"components": st["components"], "outputs": nt, "load_snapshot_s": st["load_snapshot_s"],
+        return {"parity_gate": gate, "components": st["components"], "outputs": nt, "load_snapshot_s": st["load_snapshot_s"],
                 "alloc_multi_emulator_s": st["alloc_multi_emulator_s"], "points": npts,
                 "points_per_s": npts / st["loop_wall_s"], "component_predictions_per_s": nr * npts / st["loop_wall_s"],
                 "stage_busy_s": {"read_parse": st["parse_s"], "device": st["device_s"], "format_write": st["format_s"]},
@@ -374,6 +397,10 @@ def pca8_train_ranks_cli(dev, rank, world, local_rank, rendezvous, restarts=4):
     nvg = [int(v) for v in re.findall(r"value_grad_evals (\d+)", out.stderr)]
     res = {"cli_wall_seconds": wall, "components_trained_here": len(secs), "search_seconds_here": sum(secs),
            "value_grad_evals_here": sum(nvg)}
+    ph = re.search(r"# cli phases: rendezvous_read_input_s ([0-9.]+) pca_alloc_s ([0-9.]+) train_and_dump_s ([0-9.]+) snapshot_check_s ([0-9.]+)", out.stderr)
+    if ph:
+        res.update(rendezvous_read_input_s=float(ph.group(1)), pca_alloc_s=float(ph.group(2)), train_and_dump_s=float(ph.group(3)),
+                   snapshot_check_s=float(ph.group(4)))
     if rank == 0:
         res["snapshot_sha256"] = hashlib.sha256(open(snap, "rb").read()).hexdigest()
         res["gather"] = ("none (one process)" if world == 1 else "files (GPEMU_GATHER=file: ranks sharing a device)"
@@ -433,7 +460,37 @@ def pca8_region(abi, shard, synth, dev, rank, world_size, steps, barrier, reduce
     for c in mine:
         for cx in ctxs[c]:
             cx.close()
-    return {"value": nr * steps * B / t, "contexts_per_component": nctx, "unit": "likelihood-evals/s over the 8 components (total work fixed: strong scaling)",
+    # the raw value+gradient rate at this size (N=4096, d=16; exact gradient as region F's search uses): two contexts x
+    # lock-step batches of 16 through gpemu_loglik_grad_batch_enqueue / collect_back, every batch collected -- what the CLI
+    # search of region F (pca8_trained_by_cli_ranks) is measured against.  Rank 0, one GPU's worth.
+    raw_vg = None
+    if rank == 0:
+        gcs = [abi.Context(dev) for _ in range(2)]
+        for gc in gcs:
+            gc.set_model(1, 0, X, Z[:, 0].copy())
+            gc.set_mode(abi.MODE_EXACT_GRAD)
+        Bg, nsteps = 16, 12
+        thg = lambda j: np.array([synth.perturbed_thetas(1, d, seed + 5, j * Bg + i) for i in range(Bg)])
+        for j in range(4):
+            gcs[j % 2].loglik_grad_batch(thg(j))
+        pend = [False, False]
+        tg0 = time.perf_counter()
+        for j in range(nsteps):
+            k = j % 2
+            if pend[k]:
+                r = gcs[k].loglik_grad_batch_collect_back(0, Bg)
+                assert np.all(r["status"] == 0) and np.all(np.isfinite(r["grad"]))
+            gcs[k].loglik_grad_batch_enqueue(thg(10 + j))
+            pend[k] = True
+        for k in range(2):
+            r = gcs[k].loglik_grad_batch_collect_back(0, Bg)
+            assert np.all(r["status"] == 0) and np.all(np.isfinite(r["grad"]))
+        tg = time.perf_counter() - tg0
+        for gc in gcs:
+            gc.close()
+        raw_vg = {"value": nsteps * Bg / tg, "unit": "value+gradient evaluations/s (exact gradient), 2 contexts x batches of 16, every batch collected",
+                  "roofline_frac_of_N3_flops": nsteps * Bg / tg * float(N) ** 3 / 1e12 / PEAK_FP64_MFMA_TFLOPS}
+    return {"value": nr * steps * B / t, "raw_value_grad": raw_vg, "contexts_per_component": nctx, "unit": "likelihood-evals/s over the 8 components (total work fixed: strong scaling)",
             "components": nr, "components_this_rank": len(mine), "batches_per_component": steps, "evaluations_per_batch": B,
             "seconds": t, "workload": f"N={N}, d={d}, t={nt} outputs -> {nr} PCA components, pow-exp, regression_order=0",
             "best_neg_loglik_per_component": rows[:, 0].tolist()}
@@ -927,6 +984,13 @@ def main():
             train = mine
         if train and vg and "value_grad_evals_per_s" in train:
             train["fraction_of_raw_value_grad"] = train["value_grad_evals_per_s"] / vg["value"]
+        if not distributed and not args.train_literal and train and "error" not in train:
+            # the same search with the reference's LITERAL gradient formulas (the CLI's default mode, emulator.c:173-209 /
+            # maxmultimin.c:416-550): the reference's own behaviour, driver-timed beside the exact one
+            lit = train_through_cli(N, d, seed + 1, dev, args.train_runs, exact=False)
+            if vg and "value_grad_evals_per_s" in lit:
+                lit["fraction_of_raw_value_grad"] = lit["value_grad_evals_per_s"] / vg["value"]
+            train["literal_gradient_search"] = lit
         note("region D (estimate_thetas through the C layer) done")
 
     # ---- region E: BASELINE configs[3] -- the 8 PCA components of an N=4096, d=16, t=9 multi-output model
@@ -950,7 +1014,8 @@ def main():
         barrier()
         t0 = time.perf_counter()
         with tempfile.TemporaryDirectory(prefix="gpemu_bench_") as own:
-            mine = pca8_train_ranks_cli(dev, rank, world_size, local_rank, rdv[0] if distributed else own, restarts=16)
+            # 50 runs per component: the reference's own restart count per job (estimate_threaded.c:113)
+            mine = pca8_train_ranks_cli(dev, rank, world_size, local_rank, rdv[0] if distributed else own, restarts=50)
         f_wall, f_fail, f_evals = time.perf_counter() - t0, 1.0 if "error" in mine else 0.0, float(mine.get("value_grad_evals_here", 0))
         if distributed:
             f_wall, f_fail = allreduce_max(f_wall), allreduce_max(f_fail)
@@ -961,6 +1026,14 @@ def main():
             ranks_cli = dict(mine, wall_seconds_max_over_ranks=f_wall, ranks_failed=bool(f_fail > 0), processes=world_size,
                              value_grad_evals_all_ranks=int(f_evals),
                              value_grad_evals_per_s_wall=f_evals / f_wall if f_wall > 0 else None)
+            raw = (pca8 or {}).get("raw_value_grad")
+            if raw and f_wall > 0:
+                # against the raw C-ABI rate of ONE GPU at this size (pca8.raw_value_grad): at --gpus 1 the fraction of the device
+                # rate the whole CLI process -- start-up, parsing, PCA, the searches, the snapshot -- delivers; at N GPUs N x raw
+                ranks_cli["raw_value_grad_evals_per_s_one_gpu"] = raw["value"]
+                ranks_cli["fraction_of_raw_wall"] = ranks_cli["value_grad_evals_per_s_wall"] / (raw["value"] * world_size)
+                if mine.get("train_and_dump_s"):
+                    ranks_cli["fraction_of_raw_in_training_phase_rank0"] = float(mine.get("value_grad_evals_here", 0)) / mine["train_and_dump_s"] / raw["value"]
         note("region F (configs[3] trained as one CLI process per GPU) done")
     # ---- roofline of the prediction GEMM (the likelihood rooflines were taken right behind region A)
     if rank == 0:

@@ -187,6 +187,19 @@ int gpemu_loglik_grad_batch_collect_back(gpemu_ctx *ctx, int back, int nb, doubl
  * Factorises C(thetas) once and keeps L^-1, C^-1 [y|H], beta and
  * (H^T C^-1 H)^-1 resident in HBM.  beta_out[nreg] optional. */
 int gpemu_predict_setup(gpemu_ctx *ctx, const double *thetas, int nthetas, double *beta_out, int *info);
+/* alloc_multi_emulator (multivar_support.c:30-52: alloc_emulator_struct for each of the nr PCA components of a multi-output
+ * model) as ONE lock-step batch: ctxs[0 .. n-1] hold the same design, covariance function, regression order and modes on the
+ * same device and a training vector of their own each (gpemu_set_model / gpemu_set_training); component c is factored at
+ * thetas[c * nthetas ..] with its inverse rows beside the others (one launch sequence for all, in ctxs[0]'s workspace) and
+ * ctxs[c] receives the prediction state gpemu_predict_setup(ctxs[c], ...) would have given it, bit for bit.  beta_out
+ * (n x nreg), info (n, 1-based failed pivot or 0) and status (n, GPEMU_OK / GPEMU_ERR_NOT_PD / GPEMU_ERR_REGRESSION per
+ * component) are optional; the return value is the first failure (contexts of failed components are left without a set-up). */
+int gpemu_predict_setup_batch(gpemu_ctx *const *ctxs, int n, const double *thetas, int nthetas, double *beta_out, int *info,
+                              int *status);
+/* Pays what a process pays once -- the HIP runtime's start, the loading of this library's device code, its tables -- on a
+ * throw-away context with a 64-point model, so that a caller can do it on a thread of its own while it is still reading its
+ * input (interactive_mode: the snapshot).  Returns GPEMU_OK or the first error (GPEMU_ERR_NO_DEVICE ...). */
+int gpemu_warm_start(int device);
 /* optional: explicit C^-1 (N*N, both triangles) for emulator_struct.cinverse */
 int gpemu_get_cinverse(gpemu_ctx *ctx, double *cinv_out);
 

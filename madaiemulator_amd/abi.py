@@ -52,6 +52,8 @@ SYMBOLS = {
     "gpemu_loglik_grad_batch_collect": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _ip, _ip]),
     "gpemu_loglik_grad_batch_collect_back": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _ip, _ip]),
     "gpemu_predict_setup": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _ip]),
+    "gpemu_predict_setup_batch": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, _dp, C.c_int, _dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gpemu_warm_start": (C.c_int, [C.c_int]),
     "gpemu_get_cinverse": (C.c_int, [C.c_void_p, _dp]),
     "gpemu_predict_batch": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
     "gpemu_predict_batch_enqueue": (C.c_int, [C.c_void_p, C.c_int, _dp]),
@@ -120,6 +122,22 @@ def _p(a):
 
 def nthetas_for(kind, d):
     return d + 2 if kind == POWEREXP else 3
+
+
+def predict_setup_batch(ctxs, thetas):
+    """gpemu_predict_setup_batch: the contexts of the components of a multi-output model (same design, own training vector)
+    set up as ONE lock-step batch.  Returns (beta [n x nreg], info [n], status [n], rc)."""
+    th = _a(thetas).reshape(len(ctxs), -1)
+    n = len(ctxs)
+    hs = (C.c_void_p * n)(*[c.h for c in ctxs])
+    beta = np.full((n, ctxs[0].nreg), np.nan)
+    info = np.zeros(n, dtype=np.int32)
+    status = np.zeros(n, dtype=np.int32)
+    rc = ctxs[0].L.gpemu_predict_setup_batch(hs, n, _p(th), th.shape[1], _p(beta), info.ctypes.data_as(C.POINTER(C.c_int)),
+                                            status.ctypes.data_as(C.POINTER(C.c_int)))
+    if rc not in (OK, ERR_NOT_PD, ERR_REGRESSION):
+        raise GpemuError(rc, ctxs[0].L.gpemu_last_error(ctxs[0].h).decode())
+    return beta, info, status, rc
 
 
 class Context:

@@ -178,19 +178,15 @@ extern "C" int gpemu_ctx_create(gpemu_ctx **out, int device)
 	ctx->sched = read_environment();
 	ctx->device = device;
 	ctx->res_len = 64 * 64 + 8;
-	ctx->batch_cap = 1;
+	// the per-matrix result slots (three device and three pinned allocations: milliseconds) are made by the first
+	// factorisation (ensure_batch_slots): a context that only ever answers queries -- a component of a multi-output emulator
+	// set up by gpemu_predict_setup_batch -- never needs them
+	ctx->batch_cap = 0;
 	int least = 0, greatest = 0;
 	if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = 0; greatest = 0; }
 	bool ok = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, greatest) == hipSuccess;
-	ok = ok && hipMalloc(&ctx->dInfo, sizeof(int)) == hipSuccess &&
-	     hipMalloc(&ctx->dRes, ctx->res_len * sizeof(double)) == hipSuccess &&
-	     hipHostMalloc((void **)&ctx->hResRing, (size_t)gpemu_ctx::RES_RING * ctx->res_len * sizeof(double)) == hipSuccess &&
-	     hipHostMalloc((void **)&ctx->hInfoRing, (size_t)gpemu_ctx::RES_RING * sizeof(int)) == hipSuccess &&
-	     hipMalloc(&ctx->dGradSum, (size_t)gpemu_ctx::GRAD_NP_MAX * sizeof(double)) == hipSuccess &&
-	     hipHostMalloc((void **)&ctx->hGradRing, (size_t)gpemu_ctx::RES_RING * gpemu_ctx::GRAD_NP_MAX * sizeof(double)) == hipSuccess;
 	for (int i = 0; ok && i < gpemu_ctx::RES_RING; i++)
 		ok = hipEventCreateWithFlags(&ctx->res_ev[i], hipEventDisableTiming) == hipSuccess;
-	ctx->hRes = ctx->hResRing; ctx->hInfo = ctx->hInfoRing;
 	const char *tr = getenv("GPEMU_TRACE");
 	if (ok && tr && atoi(tr) > 0) {                 // in-kernel timestamps: 4096 launch slots of 8 x u64
 		ctx->trace_cap = 4096;
@@ -328,7 +324,7 @@ static int ensure_T(gpemu_ctx *ctx, size_t rows_each, int nb = 1)
 // per-matrix result slots (info word, Gram partials, Gram + log det, pinned mirrors) for a batch of nb
 static int ensure_batch_slots(gpemu_ctx *ctx, int nb)
 {
-	if (nb <= ctx->batch_cap && ctx->dGramPart) return GPEMU_OK;
+	if (nb <= ctx->batch_cap && ctx->dGramPart && ctx->dInfo) return GPEMU_OK;
 	if (nb < ctx->batch_cap) nb = ctx->batch_cap;
 	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 	free_graphs(ctx);                      // captured launches hold the old pointers
@@ -374,7 +370,8 @@ extern "C" int gpemu_set_model(gpemu_ctx *ctx, int kind, int order, int N, int d
 	HIPCHK(ctx, hipMalloc(&ctx->dX, (size_t)N * d * sizeof(double)));
 	HIPCHK(ctx, hipMalloc(&ctx->dY, (size_t)N * sizeof(double)));
 	HIPCHK(ctx, hipMalloc(&ctx->dRrows, (size_t)ctx->Rp * ctx->Np * sizeof(double)));
-	HIPCHK(ctx, hipMalloc(&ctx->dGramPart, (size_t)ctx->batch_cap * (ctx->Np / 64) * ctx->Rp * ctx->Rp * sizeof(double)));
+	if (ctx->batch_cap > 0)
+		HIPCHK(ctx, hipMalloc(&ctx->dGramPart, (size_t)ctx->batch_cap * (ctx->Np / 64) * ctx->Rp * ctx->Rp * sizeof(double)));
 	HIPCHK(ctx, hipMemcpyAsync(ctx->dX, ctx->hX.data(), (size_t)N * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
 	HIPCHK(ctx, hipMemcpyAsync(ctx->dY, ctx->hY.data(), (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
 	{
@@ -406,8 +403,9 @@ extern "C" int gpemu_set_model(gpemu_ctx *ctx, int kind, int order, int N, int d
 	}
 	HIPCHK(ctx, launch_build_rrows(ctx->stream, ctx->dRrows, ctx->Np, ctx->Rp, ctx->dX, ctx->dY, N, d, order));
 	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-	int rc = ensure_T(ctx, (size_t)ctx->Np + ctx->Rp);
-	return rc;
+	// (the factorisation workspace is made by the first factorisation, stage_matrices: a context whose prediction state comes
+	// from gpemu_predict_setup_batch never factors anything itself)
+	return GPEMU_OK;
 }
 
 extern "C" int gpemu_set_training(gpemu_ctx *ctx, const double *y)
@@ -625,7 +623,9 @@ static int run_potrf(gpemu_ctx *ctx, int inv)
 // fill C(theta_b) into matrix b of T (lower tiles only), load the RHS rows, reset the info words
 constexpr unsigned PARAM_RING = 4;
 
-static int stage_matrices(gpemu_ctx *ctx, const CovParams *ps, int nb, int inv)
+// rrows / rstride: right-hand-side rows of the batch when they are not the context's own (rstride != 0: matrix b takes
+// rrows + b * rstride -- the components of a multi-output model, gpemu_predict_setup_batch)
+static int stage_matrices(gpemu_ctx *ctx, const CovParams *ps, int nb, int inv, const double *rrows = nullptr, long rstride = 0)
 {
 	const int Np = ctx->Np, Rp = ctx->Rp;
 	int rc = ensure_batch_slots(ctx, nb);
@@ -656,7 +656,8 @@ static int stage_matrices(gpemu_ctx *ctx, const CovParams *ps, int nb, int inv)
 		bool all_gram = ctx->dXg != nullptr;
 		for (int b = 0; b < nb; b++) all_gram = all_gram && ps[b].gram;
 		HIPCHK(ctx, launch_cov_stage_batch(ctx->stream, ctx->dT, Np, (long)ctx->T_stride, nb, ctx->dX, ctx->N, Np, ctx->d,
-		                                   ctx->dParams, FILL_LOWER | FILL_IDENT_PAD, ctx->dRrows, Rp, ctx->dXg, all_gram, ctx->kind));
+		                                   ctx->dParams, FILL_LOWER | FILL_IDENT_PAD, rrows ? rrows : ctx->dRrows, Rp, ctx->dXg, all_gram,
+		                                   ctx->kind, rrows ? rstride : 0));
 	}
 	if (inv)
 		HIPCHK(ctx, launch_set_identity_rows(ctx->stream, ctx->dT + (size_t)(Np + Rp) * Np, Np, Np, nb, (long)ctx->T_stride));
@@ -959,6 +960,57 @@ static int factor_with_inverse(gpemu_ctx *ctx, const double *thetas, int nthetas
 	return GPEMU_OK;
 }
 
+// The prediction state of `dst` from element b of the factorisation (with inverse rows) that sits in `src`'s workspace and
+// whose results have been collected (src == dst, b == 0: the single call).  Everything runs on src's stream, which is
+// synchronised before the function returns; dst's own stream has nothing in flight (checked by the callers).
+static int build_prediction_state(gpemu_ctx *src, int b, gpemu_ctx *dst, const CovParams &p, const HostLik &r, const double *thetas,
+                                  int nthetas)
+{
+	const int Np = src->Np, Rp = src->Rp, nreg = src->nreg, N = src->N;
+	const size_t la_rows = (size_t)Np + Rp;
+	if (!dst->dLinvAug) HIPCHK(src, hipMalloc(&dst->dLinvAug, la_rows * Np * sizeof(double)));
+	if (!dst->dBetaQ) HIPCHK(src, hipMalloc(&dst->dBetaQ, (size_t)(nreg + nreg * nreg) * sizeof(double)));
+	const double *Tb = src->dT + (size_t)b * src->T_stride;
+	const double *Zt = Tb + (size_t)Np * Np;
+	const double *U = Tb + (size_t)(Np + Rp) * Np;
+	// rows [0,Np): L^-1 = U^T
+	HIPCHK(src, launch_transpose(src->stream, dst->dLinvAug, Np, U, Np, Np));
+	// (C^-1 [y|H])^T = Z^T U^T : rows Np.. of LinvAug used as scratch first
+	GemmArgs g;
+	memset(&g, 0, sizeof g);
+	g.C = dst->dLinvAug + (size_t)Np * Np; g.ldc = Np;
+	g.A = Zt; g.lda = Np;
+	g.B = U; g.ldb = Np;
+	g.m = Rp; g.n = Np; g.k0 = 0; g.k1 = Np; g.alpha = 1.0; g.beta = 0;
+	HIPCHK(src, gemm(src, g));
+	std::vector<double> cr((size_t)Rp * Np);
+	HIPCHK(src, hipMemcpyAsync(cr.data(), dst->dLinvAug + (size_t)Np * Np, cr.size() * sizeof(double),
+	                           hipMemcpyDeviceToHost, src->stream));
+	HIPCHK(src, hipStreamSynchronize(src->stream));
+	// row 0 <- gamma = C^-1 y - (C^-1 H) beta = C^-1 (y - H beta); rows 1.. keep W^T = (C^-1 H)^T
+	for (int j = 0; j < Np; j++) {
+		double s = cr[j];
+		for (int a = 0; a < nreg; a++) s -= r.beta[a] * cr[(size_t)(1 + a) * Np + j];
+		cr[j] = (j < N) ? s : 0.0;
+	}
+	for (int a = src->nrhs; a < Rp; a++)
+		for (int j = 0; j < Np; j++) cr[(size_t)a * Np + j] = 0.0;
+	HIPCHK(src, hipMemcpyAsync(dst->dLinvAug + (size_t)Np * Np, cr.data(), cr.size() * sizeof(double),
+	                           hipMemcpyHostToDevice, src->stream));
+	std::vector<double> bq(nreg + (size_t)nreg * nreg);
+	for (int a = 0; a < nreg; a++) bq[a] = r.beta[a];
+	for (int a = 0; a < nreg * nreg; a++) bq[nreg + a] = r.Q[a];
+	HIPCHK(src, hipMemcpyAsync(dst->dBetaQ, bq.data(), bq.size() * sizeof(double), hipMemcpyHostToDevice, src->stream));
+	HIPCHK(src, hipStreamSynchronize(src->stream));
+	dst->h_beta = r.beta; dst->h_Q = r.Q;
+	dst->pred_cov = p;
+	dst->kappa = p.amp + p.nug;                       // cov(x*,x*): emulator_struct.c:135 (nugget included)
+	dst->pred_ready = true;
+	dst->cinv_ready = false;
+	dst->last_thetas.assign(thetas, thetas + nthetas);
+	return GPEMU_OK;
+}
+
 extern "C" int gpemu_predict_setup(gpemu_ctx *ctx, const double *thetas, int nthetas, double *beta_out, int *info)
 {
 	if (!ctx) return GPEMU_ERR_ARG;
@@ -969,49 +1021,110 @@ extern "C" int gpemu_predict_setup(gpemu_ctx *ctx, const double *thetas, int nth
 	if (rc) return rc;
 	HostLik r = host_likelihood(ctx);
 	if (r.status) return fail(ctx, r.status, "H^T C^-1 H is not positive definite");
-
-	const int Np = ctx->Np, Rp = ctx->Rp, nreg = ctx->nreg, N = ctx->N;
-	const size_t la_rows = (size_t)Np + Rp;
-	if (!ctx->dLinvAug) HIPCHK(ctx, hipMalloc(&ctx->dLinvAug, la_rows * Np * sizeof(double)));
-	if (!ctx->dBetaQ) HIPCHK(ctx, hipMalloc(&ctx->dBetaQ, (size_t)(nreg + nreg * nreg) * sizeof(double)));
-	const double *Zt = ctx->dT + (size_t)Np * Np;
-	const double *U = ctx->dT + (size_t)(Np + Rp) * Np;
-	// rows [0,Np): L^-1 = U^T
-	HIPCHK(ctx, launch_transpose(ctx->stream, ctx->dLinvAug, Np, U, Np, Np));
-	// (C^-1 [y|H])^T = Z^T U^T : rows Np.. of LinvAug used as scratch first
-	GemmArgs g;
-	memset(&g, 0, sizeof g);
-	g.C = ctx->dLinvAug + (size_t)Np * Np; g.ldc = Np;
-	g.A = Zt; g.lda = Np;
-	g.B = U; g.ldb = Np;
-	g.m = Rp; g.n = Np; g.k0 = 0; g.k1 = Np; g.alpha = 1.0; g.beta = 0;
-	HIPCHK(ctx, gemm(ctx, g));
-	std::vector<double> cr((size_t)Rp * Np);
-	HIPCHK(ctx, hipMemcpyAsync(cr.data(), ctx->dLinvAug + (size_t)Np * Np, cr.size() * sizeof(double),
-	                           hipMemcpyDeviceToHost, ctx->stream));
-	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-	// row 0 <- gamma = C^-1 y - (C^-1 H) beta = C^-1 (y - H beta); rows 1.. keep W^T = (C^-1 H)^T
-	for (int j = 0; j < Np; j++) {
-		double s = cr[j];
-		for (int a = 0; a < nreg; a++) s -= r.beta[a] * cr[(size_t)(1 + a) * Np + j];
-		cr[j] = (j < N) ? s : 0.0;
-	}
-	for (int a = ctx->nrhs; a < Rp; a++)
-		for (int j = 0; j < Np; j++) cr[(size_t)a * Np + j] = 0.0;
-	HIPCHK(ctx, hipMemcpyAsync(ctx->dLinvAug + (size_t)Np * Np, cr.data(), cr.size() * sizeof(double),
-	                           hipMemcpyHostToDevice, ctx->stream));
-	std::vector<double> bq(nreg + (size_t)nreg * nreg);
-	for (int a = 0; a < nreg; a++) bq[a] = r.beta[a];
-	for (int a = 0; a < nreg * nreg; a++) bq[nreg + a] = r.Q[a];
-	HIPCHK(ctx, hipMemcpyAsync(ctx->dBetaQ, bq.data(), bq.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-	ctx->h_beta = r.beta; ctx->h_Q = r.Q;
-	ctx->pred_cov = p;
-	ctx->kappa = p.amp + p.nug;                       // cov(x*,x*): emulator_struct.c:135 (nugget included)
-	ctx->pred_ready = true;
-	ctx->last_thetas.assign(thetas, thetas + nthetas);
-	if (beta_out) for (int a = 0; a < nreg; a++) beta_out[a] = r.beta[a];
+	rc = build_prediction_state(ctx, 0, ctx, p, r, thetas, nthetas);
+	if (rc) return rc;
+	if (beta_out) for (int a = 0; a < ctx->nreg; a++) beta_out[a] = r.beta[a];
 	return GPEMU_OK;
+}
+
+// alloc_multi_emulator (multivar_support.c:30-52) loops alloc_emulator_struct over the nr PCA components of a multi-output
+// model: same design, covariance function and regression order, a training vector and thetas of its own each.  Here the nr
+// factorisations with their inverse rows run as ONE lock-step batch in the first context's workspace (blockIdx.y = component,
+// every component under its own right-hand-side rows), and each context receives its own prediction state; afterwards the
+// contexts answer queries on their own streams as if gpemu_predict_setup had been called on each -- with the same bits: an
+// element of a lock-step batch is the evaluation done alone.
+extern "C" int gpemu_predict_setup_batch(gpemu_ctx *const *ctxs, int n, const double *thetas, int nthetas, double *beta_out, int *info,
+                                         int *status)
+{
+	if (!ctxs || n < 1 || !ctxs[0]) return GPEMU_ERR_ARG;
+	gpemu_ctx *lead = ctxs[0];
+	if (n > GPEMU_MAX_BATCH) return fail(lead, GPEMU_ERR_ARG, "at most GPEMU_MAX_BATCH components per call");
+	if (!lead->dX) return fail(lead, GPEMU_ERR_STATE, "model not set");
+	for (int c = 0; c < n; c++) {
+		gpemu_ctx *x = ctxs[c];
+		if (!x || !x->dX) return fail(lead, GPEMU_ERR_STATE, "model not set in every context");
+		for (int e = 0; e < c; e++) if (ctxs[e] == x) return fail(lead, GPEMU_ERR_ARG, "the same context twice");
+		if (x->device != lead->device || x->kind != lead->kind || x->order != lead->order || x->N != lead->N || x->d != lead->d ||
+		    x->mode != lead->mode || x->hX != lead->hX)
+			return fail(lead, GPEMU_ERR_ARG, "the contexts of a batched set-up share device, design, covariance function, regression order and modes");
+		if (x->pred_pending) return fail(lead, GPEMU_ERR_STATE, "a prediction batch is enqueued in one of the contexts: collect it first");
+		x->pred_ready = false; x->cinv_ready = false;
+	}
+	std::vector<CovParams> ps((size_t)n);
+	for (int c = 0; c < n; c++) {
+		int rc = make_cov_params(lead, thetas ? thetas + (size_t)c * nthetas : nullptr, nthetas, &ps[c]);
+		if (rc) return rc;
+	}
+	HIPCHK(lead, hipSetDevice(lead->device));
+	const int Np = lead->Np, Rp = lead->Rp, nreg = lead->nreg;
+	// the components' right-hand-side rows [y_c | H]^T side by side (each context built its own at gpemu_set_model /
+	// gpemu_set_training, synchronously)
+	double *rr = nullptr;
+	const size_t rlen = (size_t)Rp * Np;
+	HIPCHK(lead, hipMalloc(&rr, (size_t)n * rlen * sizeof(double)));
+	hipError_t e = hipSuccess;
+	for (int c = 0; c < n && e == hipSuccess; c++)
+		e = hipMemcpyAsync(rr + (size_t)c * rlen, ctxs[c]->dRrows, rlen * sizeof(double), hipMemcpyDeviceToDevice, lead->stream);
+	int rc = GPEMU_OK;
+	if (e != hipSuccess) { lead->err = std::string("right-hand-side rows: ") + hipGetErrorString(e); rc = GPEMU_ERR_HIP; }
+	if (!rc) rc = stage_matrices(lead, ps.data(), n, 1, rr, (long)rlen);
+	if (!rc) rc = run_potrf(lead, 1);
+	if (!rc) rc = enqueue_results(lead);
+	if (!rc && hipStreamSynchronize(lead->stream) != hipSuccess) { lead->err = "stream synchronisation failed"; rc = GPEMU_ERR_HIP; }
+	hipFree(rr);
+	if (rc) return rc;
+	int worst = GPEMU_OK;
+	for (int c = 0; c < n; c++) {
+		const int inf = (lead->hInfo[c] >= INFO_NONE) ? 0 : lead->hInfo[c];
+		if (info) info[c] = inf;
+		int st = GPEMU_OK;
+		if (inf) st = GPEMU_ERR_NOT_PD;
+		else {
+			HostLik r = host_likelihood(lead, c);
+			if (r.status) st = r.status;
+			else {
+				st = build_prediction_state(lead, c, ctxs[c], ps[c], r, thetas + (size_t)c * nthetas, nthetas);
+				if (st == GPEMU_OK && beta_out) for (int a = 0; a < nreg; a++) beta_out[(size_t)c * nreg + a] = r.beta[a];
+			}
+		}
+		if (status) status[c] = st;
+		if (st != GPEMU_OK && worst == GPEMU_OK) worst = st;
+	}
+	if (worst == GPEMU_ERR_NOT_PD) return fail(lead, worst, "covariance matrix is not positive definite");
+	if (worst == GPEMU_ERR_REGRESSION) return fail(lead, worst, "H^T C^-1 H is not positive definite");
+	return worst;
+}
+
+// Everything a process pays once before its first result -- the HIP runtime, the device's code objects (loaded at the first
+// launch from each of this library's translation units), the exp and tile tables -- on a throw-away context with a 64-point
+// model: one evaluation, one prediction set-up, one prediction.  Meant for a thread of its own while the caller is still
+// reading its input (csrc/host: gpemu_host_warm_start).
+extern "C" int gpemu_warm_start(int device)
+{
+	gpemu_ctx *ctx = nullptr;
+	int rc = gpemu_ctx_create(&ctx, device);
+	if (rc) return rc;
+	const int N = 64, d = 2;
+	std::vector<double> X((size_t)N * d), y(N);
+	for (int i = 0; i < N; i++) {
+		X[(size_t)i * d] = (i % 8) / 8.0 + 0.01 * i;
+		X[(size_t)i * d + 1] = (i / 8) / 8.0;
+		y[i] = std::sin(0.3 * i);
+	}
+	for (int kind = GPEMU_POWEREXP; kind <= GPEMU_MATERN52 && !rc; kind += 2) {
+		const double th_pe[4] = {0.0, -3.0, -1.0, -1.0}, th_m[3] = {1.0, 0.05, -0.5};
+		const double *th = kind == GPEMU_POWEREXP ? th_pe : th_m;
+		const int nth = kind == GPEMU_POWEREXP ? 4 : 3;
+		rc = gpemu_set_model(ctx, kind, 1, N, d, X.data(), y.data());
+		double v, s2, m, var;
+		int info = 0;
+		if (!rc) rc = gpemu_loglik(ctx, th, nth, &v, &s2, nullptr, nullptr, nullptr, &info);
+		if (!rc) rc = gpemu_predict_setup(ctx, th, nth, nullptr, &info);
+		if (!rc) rc = gpemu_predict_batch(ctx, 1, X.data(), &m, &var);
+		if (!rc) { std::vector<double> mm(70), vv(70), q((size_t)70 * d, 0.3); rc = gpemu_predict_batch(ctx, 70, q.data(), mm.data(), vv.data()); }
+	}
+	gpemu_ctx_destroy(ctx);
+	return rc;
 }
 
 constexpr int PRED_SPLIT_MAX = 16;

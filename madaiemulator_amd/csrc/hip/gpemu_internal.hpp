@@ -212,7 +212,7 @@ hipError_t launch_build_rrows(hipStream_t s, double *R, int Np, int Rp, const do
 hipError_t launch_set_identity_rows(hipStream_t s, double *T, long ld, int n, int nbatch = 1, long bstride = 0);
 hipError_t launch_cov_stage_batch(hipStream_t s, double *T, long ld, long bstride, int nb, const double *X, int N, int Np, int d,
                                   const CovParams *pp_dev, int mode, const double *Rrows, int Rp, const double *Xg = nullptr,
-                                  bool all_gram = false, int kind = GPEMU_POWEREXP);
+                                  bool all_gram = false, int kind = GPEMU_POWEREXP, long rstride = 0);
 hipError_t launch_transpose(hipStream_t s, double *dst, long ldd, const double *src, long lds, int n);
 hipError_t launch_predict_finish(hipStream_t s, const double *V, long ldv, int M, int Np, int nreg, int order, int d,
                                  const double *Xq, const double *betaQ, double kappa, double *mean, double *var,

@@ -405,14 +405,16 @@ __global__ __launch_bounds__(256) void cov_fill_kernel(double *out, long ld, con
 
 // Staging of a lock-step batch in ONE launch: matrix blockIdx.y gets its lower-triangular fill with its own
 // hyper-parameters pp[blockIdx.y] (workgroups 0 .. ntiles-1) and a copy of the shared R rows [y H]^T below it
-// (workgroups ntiles ..: one FT x FT block each).  Per-matrix launches and copies cost ~12 us each on the host and the
+// (workgroups ntiles ..: one FT x FT block each; with rstride != 0 matrix b takes ITS OWN rows Rrows + b * rstride: the
+// components of a multi-output model share the design and differ in the training vector).  Per-matrix launches and copies cost ~12 us each on the host and the
 // stream: 1 ms per batch of 64, which is all a batch of small models (N < 1000) takes.
 template <int KIND>
 __global__ __launch_bounds__(256) void cov_stage_batch_kernel(double *T, long ld, long bstride, const double *X, int N, int Np,
                                                               int d, const CovParams *pp, int mode, const double *Rrows, int Rp,
-                                                              const double *Xg)
+                                                              const double *Xg, long rstride)
 {
 	double *out = T + (long)blockIdx.y * bstride;
+	Rrows += (long)blockIdx.y * rstride;              // rstride 0: every matrix gets the same right-hand sides
 	const long nt = Np / FT, ntiles = nt * (nt + 1) / 2;
 	if ((long)blockIdx.x < ntiles) {
 		// this matrix's hyper-parameters through LDS (the per-dimension scales are indexed per lane)
@@ -448,9 +450,10 @@ constexpr int GRAM_TPW = 4;
 template <int KIND>
 __global__ __launch_bounds__(256) void cov_stage_gram_kernel(double *T, long ld, long bstride, const double *X, int N, int Np,
                                                              int d, const CovParams *pp, int mode, const double *Rrows, int Rp,
-                                                             const double *Xg)
+                                                             const double *Xg, long rstride)
 {
 	double *out = T + (long)blockIdx.y * bstride;
+	Rrows += (long)blockIdx.y * rstride;              // rstride 0: every matrix gets the same right-hand sides
 	const long nt = Np / FT, ntiles = nt * (nt + 1) / 2, ngroups = (ntiles + GRAM_TPW - 1) / GRAM_TPW;
 	if ((long)blockIdx.x < ngroups) {
 		__shared__ CovParams ps;
@@ -502,7 +505,7 @@ static hipError_t ensure_exp_table(hipStream_t s)
 // (every matrix of a batch has the model's covariance function: `kind` selects the instantiation)
 hipError_t launch_cov_stage_batch(hipStream_t s, double *T, long ld, long bstride, int nb, const double *X, int N, int Np, int d,
                                   const CovParams *pp_dev, int mode, const double *Rrows, int Rp, const double *Xg, bool all_gram,
-                                  int kind)
+                                  int kind, long rstride)
 {
 	if (Np % FT || FT != 64) return hipErrorInvalidValue;
 	if (kind < GPEMU_POWEREXP || kind > GPEMU_MATERN52) return hipErrorInvalidValue;
@@ -516,21 +519,21 @@ hipError_t launch_cov_stage_batch(hipStream_t s, double *T, long ld, long bstrid
 		const long blocks = (ntiles + GRAM_TPW - 1) / GRAM_TPW + ((Rp + FT - 1) / FT) * nt;
 		const dim3 grid((unsigned)blocks, nb);
 		if (kind == GPEMU_POWEREXP)
-			hipLaunchKernelGGL(cov_stage_gram_kernel<GPEMU_POWEREXP>, grid, dim3(256), 0, s, T, ld, bstride, X, N, Np, d, pp_dev, mode, Rrows, Rp, Xg);
+			hipLaunchKernelGGL(cov_stage_gram_kernel<GPEMU_POWEREXP>, grid, dim3(256), 0, s, T, ld, bstride, X, N, Np, d, pp_dev, mode, Rrows, Rp, Xg, rstride);
 		else if (kind == GPEMU_MATERN32)
-			hipLaunchKernelGGL(cov_stage_gram_kernel<GPEMU_MATERN32>, grid, dim3(256), 0, s, T, ld, bstride, X, N, Np, d, pp_dev, mode, Rrows, Rp, Xg);
+			hipLaunchKernelGGL(cov_stage_gram_kernel<GPEMU_MATERN32>, grid, dim3(256), 0, s, T, ld, bstride, X, N, Np, d, pp_dev, mode, Rrows, Rp, Xg, rstride);
 		else
-			hipLaunchKernelGGL(cov_stage_gram_kernel<GPEMU_MATERN52>, grid, dim3(256), 0, s, T, ld, bstride, X, N, Np, d, pp_dev, mode, Rrows, Rp, Xg);
+			hipLaunchKernelGGL(cov_stage_gram_kernel<GPEMU_MATERN52>, grid, dim3(256), 0, s, T, ld, bstride, X, N, Np, d, pp_dev, mode, Rrows, Rp, Xg, rstride);
 		return hipGetLastError();
 	}
 	const long blocks = nt * (nt + 1) / 2 + ((Rp + FT - 1) / FT) * nt;
 	const dim3 grid((unsigned)blocks, nb);
 	if (kind == GPEMU_POWEREXP)
-		hipLaunchKernelGGL(cov_stage_batch_kernel<GPEMU_POWEREXP>, grid, dim3(256), 0, s, T, ld, bstride, X, N, Np, d, pp_dev, mode, Rrows, Rp, Xg);
+		hipLaunchKernelGGL(cov_stage_batch_kernel<GPEMU_POWEREXP>, grid, dim3(256), 0, s, T, ld, bstride, X, N, Np, d, pp_dev, mode, Rrows, Rp, Xg, rstride);
 	else if (kind == GPEMU_MATERN32)
-		hipLaunchKernelGGL(cov_stage_batch_kernel<GPEMU_MATERN32>, grid, dim3(256), 0, s, T, ld, bstride, X, N, Np, d, pp_dev, mode, Rrows, Rp, Xg);
+		hipLaunchKernelGGL(cov_stage_batch_kernel<GPEMU_MATERN32>, grid, dim3(256), 0, s, T, ld, bstride, X, N, Np, d, pp_dev, mode, Rrows, Rp, Xg, rstride);
 	else
-		hipLaunchKernelGGL(cov_stage_batch_kernel<GPEMU_MATERN52>, grid, dim3(256), 0, s, T, ld, bstride, X, N, Np, d, pp_dev, mode, Rrows, Rp, Xg);
+		hipLaunchKernelGGL(cov_stage_batch_kernel<GPEMU_MATERN52>, grid, dim3(256), 0, s, T, ld, bstride, X, N, Np, d, pp_dev, mode, Rrows, Rp, Xg, rstride);
 	return hipGetLastError();
 }
 

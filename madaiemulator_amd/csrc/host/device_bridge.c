@@ -31,6 +31,7 @@ static int g_device = -1;                       /* pinned device (gpemu_host_set
 static int g_slots[64], g_nslots = 0;
 static pthread_once_t g_slots_once = PTHREAD_ONCE_INIT;
 static __thread int tls_device = -1;            /* device of the slot this thread works for, -1: slot 0 */
+static __thread int tls_share = 1;              /* searches that run side by side on this thread's device (estimate_multi) */
 
 static void slots_init(void)
 {
@@ -59,6 +60,8 @@ int gpemu_host_device_slots(void) { pthread_once(&g_slots_once, slots_init); ret
 int gpemu_host_slot_device(int slot) { pthread_once(&g_slots_once, slots_init); return g_slots[((slot % g_nslots) + g_nslots) % g_nslots]; }
 void gpemu_host_thread_device(int device) { tls_device = device; }
 int gpemu_host_thread_device_get(void) { return tls_device; }
+void gpemu_host_thread_share(int n) { tls_share = n > 1 ? n : 1; }
+int gpemu_host_thread_share_get(void) { return tls_share; }
 int gpemu_host_device(void) { return tls_device >= 0 ? tls_device : gpemu_host_slot_device(0); }
 
 /* ---------------------------------------------------------------- modes
@@ -70,6 +73,7 @@ int gpemu_host_device(void) { return tls_device >= 0 ? tls_device : gpemu_host_s
 static int g_modes = -1;
 struct entry;
 static void apply_modes_to_entries(int flags);
+void gpemu_host_warm_wait(void);
 
 int gpemu_host_modes(void)
 {
@@ -135,6 +139,13 @@ static void vcache_put(struct vcache *c, const double *th, int nthetas, double v
 
 /* evaluation counters of the whole process (gpemu_host_eval_stats): device evaluations by kind and cache answers */
 static long g_n_value = 0, g_n_valgrad = 0, g_n_cached = 0, g_n_rounds = 0, g_n_round_elems = 0;
+/* ... and of ONE search: the threads of a search (optimizer.c worker_main) point this at their pool's five counters
+ * {value, value+gradient, cached, rounds, round elements}, so that searches running side by side (the component threads of
+ * estimate_multi) each report their own figures; a lock-step round is counted by the member that sends it, which belongs to
+ * the group's search */
+static __thread long *tls_counters = NULL;
+void gpemu_host_thread_counters(long *five) { tls_counters = five; }
+#define COUNT(global_, idx_, n_) do { __sync_fetch_and_add(&(global_), (n_)); if (tls_counters) __sync_fetch_and_add(&tls_counters[idx_], (n_)); } while (0)
 void gpemu_host_eval_stats(long *value_evals, long *valgrad_evals, long *cached, long *rounds, long *round_elements)
 {
 	if (value_evals) *value_evals = __sync_fetch_and_add(&g_n_value, 0);
@@ -161,6 +172,7 @@ static struct entry *lookup(const void *key, int create)
 	for (e = g_entries; e; e = e->next)
 		if (e->key == key) break;
 	if (!e && create) {
+		gpemu_host_warm_wait();
 		e = (struct entry *)calloc(1, sizeof *e);
 		e->key = key;
 		int rc = gpemu_ctx_create(&e->ctx, gpemu_host_device());
@@ -456,10 +468,10 @@ static void group_run_round(struct group *G)
 			vcache_put(&G->vc[G->who[i]], G->th + (size_t)i * nt, nt, val[j], s2[j], st[j]);
 		}
 	}
-	__sync_fetch_and_add(&g_n_valgrad, m[1]);
-	__sync_fetch_and_add(&g_n_value, m[0]);
-	__sync_fetch_and_add(&g_n_rounds, 1);
-	__sync_fetch_and_add(&g_n_round_elems, n);
+	COUNT(g_n_valgrad, 1, m[1]);
+	COUNT(g_n_value, 0, m[0]);
+	COUNT(g_n_rounds, 3, 1);
+	COUNT(g_n_round_elems, 4, n);
 	free(th); free(val); free(s2); free(gr); free(st); free(idx);
 }
 
@@ -493,7 +505,7 @@ static int group_eval(struct group *G, const void *params, const double *th, int
 			if (sigma2) *sigma2 = G->vc[me].sigma2[c];
 			const int st = G->vc[me].status[c];
 			pthread_mutex_unlock(&G->mu);
-			__sync_fetch_and_add(&g_n_cached, 1);
+			COUNT(g_n_cached, 2, 1);
 			return st;
 		}
 	}
@@ -548,13 +560,13 @@ static int own_value(struct estimate_thetas_params *params, const char *where, c
 	if (c >= 0) {
 		if (val) *val = e->vc.val[c];
 		if (sigma2) *sigma2 = e->vc.sigma2[c];
-		__sync_fetch_and_add(&g_n_cached, 1);
+		COUNT(g_n_cached, 2, 1);
 		return e->vc.status[c];
 	}
 	double v = GSL_NAN, s2 = GSL_NAN;
 	int info = 0;
 	const int rc = gpemu_loglik(e->ctx, th, nthetas, &v, &s2, NULL, NULL, NULL, &info);
-	__sync_fetch_and_add(&g_n_value, 1);
+	COUNT(g_n_value, 0, 1);
 	if (rc == GPEMU_OK || rc == GPEMU_ERR_NOT_PD) vcache_put(&e->vc, th, nthetas, v, s2, rc);
 	if (val) *val = v;
 	if (sigma2) *sigma2 = s2;
@@ -637,7 +649,7 @@ void evalFnMultiList(const gsl_matrix *theta_rows_less_amp, void *params_in, dou
 		}
 		int rc = gpemu_loglik_batch_enqueue(ctx[k], nb, tk, nthetas);
 		if (rc) die(ctx[k], rc, "evalFnMultiList");
-		__sync_fetch_and_add(&g_n_value, nb);
+		COUNT(g_n_value, 0, nb);
 		pend_p0[k] = p0; pend_nb[k] = nb;
 	}
 	free(status); free(th);
@@ -663,7 +675,7 @@ void gradFnMulti(const gsl_vector *theta_vec_less_amp, void *params_in, gsl_vect
 	double *g = (double *)malloc(sizeof(double) * (size_t)(nthetas - 1));
 	int info = 0;
 	int rc = G ? group_eval(G, params, th, 1, NULL, NULL, g) : gpemu_grad(ctx, th, nthetas, g, &info);
-	if (!G) __sync_fetch_and_add(&g_n_valgrad, 1);
+	if (!G) COUNT(g_n_valgrad, 1, 1);
 	if (rc) grad_failure(ctx, rc, th, nthetas);
 	for (int i = 0; i < nthetas - 1; i++) gsl_vector_set(grad_vec, i, g[i]);
 	free(g); free(th);
@@ -683,7 +695,7 @@ void evalFnGradMulti(const gsl_vector *theta_vec, void *params_in, double *fnval
 	double s2 = GSL_NAN;
 	int rc = G ? group_eval(G, params, th, 1, fnval, NULL, g) : gpemu_loglik_grad(ctx, th, nthetas, fnval, &s2, NULL, g, &info);
 	if (en) {
-		__sync_fetch_and_add(&g_n_valgrad, 1);
+		COUNT(g_n_valgrad, 1, 1);
 		if (rc == GPEMU_OK || rc == GPEMU_ERR_NOT_PD) vcache_put(&en->vc, th, nthetas, *fnval, s2, rc);
 	}
 	if (rc == GPEMU_ERR_NOT_PD) {
@@ -742,6 +754,88 @@ int gpemu_host_emulator_setup_fails(modelstruct *model)
 emulator_struct *alloc_emulator_struct(modelstruct *model)
 {
 	return gpemu_host_alloc_emulator(model, getenv("GPEMU_SKIP_CINVERSE") == NULL);
+}
+
+/* alloc_emulator_struct for the n components of a multi-output model (multivar_support.c:30-52 loops it) with ONE lock-step
+ * factorisation for all of them (gpemu_predict_setup_batch): same design, covariance function and regression order, a
+ * training vector and thetas of its own each.  out[c] is what alloc_emulator_struct(models[c]) returns, bit for bit.  The
+ * contexts live on the calling thread's device. */
+void gpemu_host_alloc_emulators(modelstruct **models, int n, int fill_cinverse, emulator_struct **out)
+{
+	const int trace = getenv("GPEMU_SETUP_TRACE") != NULL;
+	const double t0 = now_s();
+	gpemu_ctx **ctxs = (gpemu_ctx **)malloc(sizeof(gpemu_ctx *) * (size_t)n);
+	const int nthetas = models[0]->options->nthetas, nreg = models[0]->options->nregression_fns;
+	double *th = (double *)malloc(sizeof(double) * (size_t)n * nthetas), *beta = (double *)malloc(sizeof(double) * (size_t)n * nreg);
+	int *status = (int *)calloc((size_t)n, sizeof(int));
+	for (int c = 0; c < n; c++) {
+		modelstruct *model = models[c];
+		emulator_struct *e = (emulator_struct *)malloc(sizeof(emulator_struct));
+		e->nparams = model->options->nparams;
+		e->nmodel_points = model->options->nmodel_points;
+		e->nregression_fns = model->options->nregression_fns;
+		e->nthetas = model->options->nthetas;
+		e->model = model;
+		e->cinverse = gsl_matrix_alloc(e->nmodel_points, e->nmodel_points);
+		e->beta_vector = gsl_vector_alloc(e->nregression_fns);
+		e->h_matrix = gsl_matrix_alloc(e->nmodel_points, e->nregression_fns);
+		out[c] = e;
+		ctxs[c] = bind_model(e, model, "alloc_multi_emulator");
+		if (e->nthetas != nthetas || e->nregression_fns != nreg)
+			gpemu_host_fatal("alloc_multi_emulator: the components of a multi-output model share covariance function and regression order\n");
+		for (int t = 0; t < nthetas; t++) th[(size_t)c * nthetas + t] = gsl_vector_get(model->thetas, t);
+	}
+	const double t1 = now_s();
+	int rc = gpemu_predict_setup_batch(ctxs, n, th, nthetas, beta, NULL, status);
+	if (rc == GPEMU_ERR_NOT_PD) {
+		fprintf(stderr, "trying to cholesky a non postive def matrix, in emulate-fns.c sorry...\n");
+		gpemu_host_exit(1);                               /* emulate-fns.c:282-285 */
+	}
+	if (rc) die(ctxs[0], rc, "alloc_multi_emulator");
+	const double t2 = now_s();
+	for (int c = 0; c < n; c++) {
+		emulator_struct *e = out[c];
+		for (int a = 0; a < nreg; a++) gsl_vector_set(e->beta_vector, a, beta[(size_t)c * nreg + a]);
+		makeHMatrix_fnptr(e->h_matrix, e->model->xmodel, e->nmodel_points, e->nparams, e->nregression_fns, e->model->makeHVector);
+		if (fill_cinverse) {
+			rc = gpemu_get_cinverse(ctxs[c], e->cinverse->data);
+			if (rc) die(ctxs[c], rc, "alloc_multi_emulator(cinverse)");
+		}
+	}
+	if (trace)
+		fprintf(stderr, "# setup trace (%d components, one lock-step batch): host_allocs+contexts+uploads %.3f ms  predict_setup_batch %.3f ms  "
+		        "h_matrices+cinverse %.3f ms\n", n, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (now_s() - t2) * 1e3);
+	free(ctxs); free(th); free(beta); free(status);
+}
+
+/* What a process pays once before its first device result (the HIP runtime's start, the loading of the device code, tables)
+ * paid on a thread of its own while the caller reads its input: gpemu_host_warm_start() starts it (GPEMU_WARM_START=0: not),
+ * gpemu_host_warm_wait() waits for it -- every entry of this file that makes a context does. */
+static pthread_t g_warm_thread;
+static volatile int g_warm_state = 0;           /* 0: none, 1: running, 2: joined */
+static pthread_mutex_t g_warm_mu = PTHREAD_MUTEX_INITIALIZER;
+
+static void *warm_main(void *arg)
+{
+	(void)gpemu_warm_start((int)(long)arg);      /* (a failure here shows up again, with its message, at the first real call) */
+	return NULL;
+}
+
+void gpemu_host_warm_start(void)
+{
+	const char *e = getenv("GPEMU_WARM_START");
+	if (e && atoi(e) == 0) return;
+	pthread_mutex_lock(&g_warm_mu);
+	if (g_warm_state == 0 && pthread_create(&g_warm_thread, NULL, warm_main, (void *)(long)gpemu_host_device()) == 0) g_warm_state = 1;
+	pthread_mutex_unlock(&g_warm_mu);
+}
+
+void gpemu_host_warm_wait(void)
+{
+	if (g_warm_state != 1) return;
+	pthread_mutex_lock(&g_warm_mu);
+	if (g_warm_state == 1) { pthread_join(g_warm_thread, NULL); g_warm_state = 2; }
+	pthread_mutex_unlock(&g_warm_mu);
 }
 
 emulator_struct *gpemu_host_alloc_emulator(modelstruct *model, int fill_cinverse)

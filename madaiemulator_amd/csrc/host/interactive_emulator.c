@@ -84,10 +84,13 @@ static int estimate_thetas(struct cmdLineOpts *o)
 {
 	gsl_matrix *xmodel = NULL, *training = NULL;
 	double varfrac = 0.95;
-	if (!open_model_file(o->inputfile, &xmodel, &training)) return perr("Input File read failed.");
+	const double t_start = wall_s();
 	/* one process per GPU (GPEMU_RANK / GPEMU_WORLD_SIZE, ranks.c): every rank trains its share and ends with the whole
-	 * model; rank 0 alone writes MODEL_SNAPSHOT_FILE */
+	 * model; rank 0 alone writes MODEL_SNAPSHOT_FILE.  The ranks meet here, before anything else (ranks.c join_run). */
 	gpemu_host_rank_device();
+	gpemu_host_warm_start();                             /* the HIP runtime starts while the input file is being parsed */
+	if (!open_model_file(o->inputfile, &xmodel, &training)) return perr("Input File read failed.");
+	const double t_read = wall_s();
 	FILE *out = fopen(gpemu_host_rank() == 0 ? o->statefile : "/dev/null", "w");
 	if (!out) return perr("Opening statefile failed.");
 	if (o->pca_variance <= 1.0 && o->pca_variance > 0) varfrac = o->pca_variance;
@@ -95,8 +98,10 @@ static int estimate_thetas(struct cmdLineOpts *o)
 	if (o->regOrder < 0 || o->regOrder > 3) { fprintf(stderr, "#ERROR regression_order %d not supported\n", o->regOrder); exit(EXIT_FAILURE); }
 	multi_modelstruct *model = alloc_multimodelstruct(xmodel, training, o->covFn, o->regOrder, varfrac);
 	if (!model) return perr("Failed to allocated multi_modelstruct.\n");
+	const double t_alloc = wall_s();
 	estimate_multi(model, out);
 	fclose(out);
+	const double t_train = wall_s();
 	gpemu_host_ranks_finish();                       /* (ranks.c: the one gather is behind us) */
 	if (gpemu_host_rank() == 0 && !getenv("GPEMU_NO_SNAPSHOT_CHECK")) {
 		/* (not in the reference, which lets interactive_mode find out) */
@@ -108,6 +113,9 @@ static int estimate_thetas(struct cmdLineOpts *o)
 				        "gives the search a lower wall.\n", i,
 				        gsl_vector_get(model->pca_model_array[i]->thetas, 0), gsl_vector_get(model->pca_model_array[i]->thetas, 1));
 	}
+	if (getenv("GPEMU_SEARCH_STATS"))
+		fprintf(stderr, "# cli phases: rendezvous_read_input_s %.3f pca_alloc_s %.3f train_and_dump_s %.3f snapshot_check_s %.3f\n",
+		        t_read - t_start, t_alloc - t_read, t_train - t_alloc, wall_s() - t_train);
 	free_multimodelstruct(model);
 	return EXIT_SUCCESS;
 }
@@ -128,6 +136,7 @@ static int interactive_mode(struct cmdLineOpts *o)
 	FILE *fp = fopen(o->statefile, "r");
 	if (!fp) return perr("Error opening file");
 	const double t_start = wall_s();
+	gpemu_host_warm_start();                             /* the HIP runtime starts while the snapshot is being parsed */
 	/* nobody in this program reads emulator_struct.cinverse (the reference's interactive_mode does not either): spare every
 	 * component the N x N download (512 MB at N = 8192) -- the library keeps filling it for callers that link libEmu */
 	setenv("GPEMU_SKIP_CINVERSE", "1", 0);

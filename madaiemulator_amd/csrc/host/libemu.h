@@ -232,6 +232,11 @@ void estimateBeta_es(gsl_vector *beta_vector, emulator_struct *e);
 /* alloc_emulator_struct with the say on the host copy of C^-1 (a public field, N x N doubles downloaded and mirrored:
  * most of the call's time at large N): 0 leaves e->cinverse allocated but unfilled for callers that never read it */
 emulator_struct *gpemu_host_alloc_emulator(modelstruct *model, int fill_cinverse);
+/* ... for the n components of a multi-output model at once: one lock-step factorisation (gpemu_predict_setup_batch) */
+void gpemu_host_alloc_emulators(modelstruct **models, int n, int fill_cinverse, emulator_struct **out);
+/* the process's one-off device start-up costs on a thread of its own while the caller reads its input (device_bridge.c) */
+void gpemu_host_warm_start(void);
+void gpemu_host_warm_wait(void);
 /* extension: npoints query rows (npoints x nparams), mean/variance arrays of npoints */
 void emulate_points(emulator_struct *e, gsl_matrix *points, double *mean, double *variance);
 /* emulate_points in two halves (device work runs in between): used to query all PCA components at the same time */
@@ -294,6 +299,12 @@ int gpemu_host_slot_device(int slot);
 void gpemu_host_thread_device(int device);       /* -1: back to slot 0 */
 int gpemu_host_thread_device_get(void);
 int gpemu_host_device(void);                     /* device a context created by the calling thread would get */
+/* n searches run side by side on the calling thread's device (the component threads of estimate_multi): the search this
+ * thread starts sizes its lock-step groups for 1/n of the device's free memory */
+void gpemu_host_thread_share(int n);
+int gpemu_host_thread_share_get(void);
+/* device bytes ONE lock-step group of `lockstep` value+gradient evaluations at nmodel_points holds (optimizer.c) */
+double gpemu_host_group_bytes(int nmodel_points, int lockstep);
 void gpemu_host_set_seed(unsigned long seed);    /* 0 = /dev/urandom as the reference (estimate_threaded.c:159) */
 void gpemu_host_set_search(int nthreads, int restarts_per_job);   /* defaults: 1 thread (1 GPU stream), 50 restarts */
 /* what the BFGS runs did so far in this process: runs, runs that ended at |g| < 0.1, runs that ended with "no progress",

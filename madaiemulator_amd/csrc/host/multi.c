@@ -14,6 +14,7 @@
 #include <math.h>
 #include <pthread.h>
 #include "libemu.h"
+#include "gpemu.h"
 
 double vector_elt_sum(gsl_vector *vec, int nstop)
 {
@@ -262,21 +263,97 @@ void free_multimodelstruct(multi_modelstruct *m)
 	free(m);
 }
 
-/* multivar_support.c:20-28: the nr scalar GPs are independent; the reference trains them one after the other.  Here
- * component c is trained on device slot c mod S (S = gpemu_host_device_slots()), one host thread per slot, each
- * thread walking its components in order with its whole restart search on its slot's device; no exchange between
- * the slots -- the results meet in the modelstructs and the snapshot is written once all threads have joined.  A
- * component's search does not depend on which slot ran it (same seeds, same lock-step group size), so the snapshot is
- * the one the serial loop writes. */
-struct component_job { multi_modelstruct *m; int slot, nslots; };
+/* multivar_support.c:20-28: the nr scalar GPs are independent; the reference trains them one after the other.  Here a
+ * list of components is trained by a pool of host threads: component list[p] belongs to device slot p mod S
+ * (S = gpemu_host_device_slots(), or the one device the caller is pinned to), and on every slot up to C components are
+ * trained SIDE BY SIDE (GPEMU_COMPONENTS_PER_SLOT; default: as many of the slot's components as fit the device's free
+ * memory with two lock-step groups each, at most 8) -- a search leaves the device idle between the rounds of its lock-step
+ * groups (the BFGS arithmetic of its host threads, the latency-bound panel chains of its small batches), which the other
+ * components' rounds fill.  Each thread runs the whole restart search of one component after the other on its slot's
+ * device; no exchange between the threads -- the results meet in the modelstructs.  A component's search depends on the
+ * seed, its data and the lock-step group size alone, not on which slot or thread ran it or what ran beside it, so the thetas
+ * (and the snapshot) are the ones the serial loop gives. */
+struct component_pool {
+	multi_modelstruct *m;
+	const int *list;             /* component indices of this slot, in order */
+	int n, next;
+	pthread_mutex_t mu;
+	int device, share;
+};
 
 static void *component_main(void *arg)
 {
-	struct component_job *j = (struct component_job *)arg;
-	gpemu_host_thread_device(gpemu_host_slot_device(j->slot));
-	for (int i = j->slot; i < j->m->nr; i += j->nslots)
-		estimate_thetas_threaded(j->m->pca_model_array[i], j->m->pca_model_array[i]->options);
+	struct component_pool *P = (struct component_pool *)arg;
+	gpemu_host_thread_device(P->device);
+	gpemu_host_thread_share(P->share);
+	for (;;) {
+		pthread_mutex_lock(&P->mu);
+		const int p = P->next < P->n ? P->next++ : -1;
+		pthread_mutex_unlock(&P->mu);
+		if (p < 0) break;
+		modelstruct *c = P->m->pca_model_array[P->list[p]];
+		estimate_thetas_threaded(c, c->options);
+	}
 	return NULL;
+}
+
+static void train_components(multi_modelstruct *m, const int *list, int nlist)
+{
+	if (nlist < 1) return;
+	const int pinned = gpemu_host_thread_device_get();
+	int nslots = pinned >= 0 ? 1 : gpemu_host_device_slots();
+	if (nslots > nlist) nslots = nlist;
+	int want = 0;                                                /* components side by side on one slot: 0 = by memory */
+	const char *e = getenv("GPEMU_COMPONENTS_PER_SLOT");
+	if (e && atoi(e) > 0) want = atoi(e);
+	struct component_pool *pools = (struct component_pool *)calloc((size_t)nslots, sizeof *pools);
+	int *order = (int *)malloc(sizeof(int) * (size_t)nlist), *nthreads = (int *)calloc((size_t)nslots, sizeof(int));
+	int filled = 0, total_threads = 0;
+	for (int s = 0; s < nslots; s++) {
+		struct component_pool *P = &pools[s];
+		P->m = m; P->list = order + filled; P->next = 0;
+		pthread_mutex_init(&P->mu, NULL);
+		P->device = pinned >= 0 ? pinned : gpemu_host_slot_device(s);
+		for (int p = s; p < nlist; p += nslots) order[filled++] = list[p];
+		P->n = (int)(order + filled - P->list);
+	}
+	for (int s = 0; s < nslots; s++) {
+		/* slots of this call on the same physical device share its memory (GPEMU_DEVICES=0,0,0: three slots, one GPU) */
+		int same = 0;
+		for (int t = 0; t < nslots; t++) same += pools[t].device == pools[s].device;
+		int c = want;
+		if (!c) {
+			const optstruct *o = m->pca_model_array[pools[s].list[0]]->options;
+			const double need = 2.0 * gpemu_host_group_bytes(o->nmodel_points, 16);
+			size_t fr = 0, tot = 0;
+			c = 8;
+			if (gpemu_device_memory(pools[s].device, &fr, &tot) == GPEMU_OK && fr > 0)
+				while (c > 1 && (double)c * same * need > 0.9 * (double)fr) c--;
+		}
+		if (c > pools[s].n) c = pools[s].n;
+		nthreads[s] = c;
+		pools[s].share = c * same;
+		total_threads += c;
+	}
+	if (total_threads == 1) {
+		/* one component at a time on the caller's own thread, which stays as it is: unpinned, the search of a lone
+		 * component deals its lock-step groups to EVERY device slot (estimate_thetas_threaded) */
+		for (int p = 0; p < pools[0].n; p++) {
+			modelstruct *c = m->pca_model_array[pools[0].list[p]];
+			estimate_thetas_threaded(c, c->options);
+		}
+	} else {
+		pthread_t *tid = (pthread_t *)calloc((size_t)total_threads, sizeof *tid);
+		int t = 0;
+		for (int s = 0; s < nslots; s++)
+			for (int k = 0; k < nthreads[s]; k++, t++)
+				if (pthread_create(&tid[t], NULL, component_main, &pools[s])) { perror("pthread_create"); gpemu_host_exit(EXIT_FAILURE); }
+		for (t = 0; t < total_threads; t++)
+			if (pthread_join(tid[t], NULL)) { perror("pthread_join"); gpemu_host_exit(EXIT_FAILURE); }
+		free(tid);
+	}
+	for (int s = 0; s < nslots; s++) pthread_mutex_destroy(&pools[s].mu);
+	free(pools); free(order); free(nthreads);
 }
 
 /* one process per GPU (ranks.c): rank r trains the components c = r, r + W, ...; the thetas of all components meet in ONE
@@ -290,10 +367,12 @@ static void estimate_multi_ranks(multi_modelstruct *m, FILE *outfp)
 	const int world = gpemu_host_world_size(), rank = gpemu_host_rank();
 	const int nthetas = (int)m->pca_model_array[0]->thetas->size;
 	const int share = (m->nr + world - 1) / world;                  /* components per rank, padded */
+	int *mine = (int *)malloc(sizeof(int) * (size_t)(share > 0 ? share : 1)), nmine = 0;
+	for (int i = rank; i < m->nr; i += world) mine[nmine++] = i;
 	g_components_over_ranks = 1;
-	for (int i = rank; i < m->nr; i += world)
-		estimate_thetas_threaded(m->pca_model_array[i], m->pca_model_array[i]->options);
+	train_components(m, mine, nmine);
 	g_components_over_ranks = 0;
+	free(mine);
 	double *send = (double *)calloc((size_t)share * nthetas, sizeof(double));
 	double *recv = (double *)calloc((size_t)share * nthetas * world, sizeof(double));
 	for (int j = 0, i = rank; i < m->nr; i += world, j++)
@@ -316,22 +395,10 @@ void estimate_multi(multi_modelstruct *m, FILE *outfp)
 		if (gpemu_host_rank() == 0) dump_multi_modelstruct(outfp, m);
 		return;
 	}
-	int nslots = gpemu_host_thread_device_get() >= 0 ? 1 : gpemu_host_device_slots();
-	if (nslots > m->nr) nslots = m->nr;
-	if (nslots <= 1) {
-		for (int i = 0; i < m->nr; i++)
-			estimate_thetas_threaded(m->pca_model_array[i], m->pca_model_array[i]->options);
-	} else {
-		pthread_t *tid = (pthread_t *)calloc((size_t)nslots, sizeof *tid);
-		struct component_job *jobs = (struct component_job *)calloc((size_t)nslots, sizeof *jobs);
-		for (int s = 0; s < nslots; s++) {
-			jobs[s].m = m; jobs[s].slot = s; jobs[s].nslots = nslots;
-			if (pthread_create(&tid[s], NULL, component_main, &jobs[s])) { perror("pthread_create"); gpemu_host_exit(EXIT_FAILURE); }
-		}
-		for (int s = 0; s < nslots; s++)
-			if (pthread_join(tid[s], NULL)) { perror("pthread_join"); gpemu_host_exit(EXIT_FAILURE); }
-		free(tid); free(jobs);
-	}
+	int *all = (int *)malloc(sizeof(int) * (size_t)m->nr);
+	for (int i = 0; i < m->nr; i++) all[i] = i;
+	train_components(m, all, m->nr);
+	free(all);
 	dump_multi_modelstruct(outfp, m);
 }
 
@@ -344,13 +411,32 @@ multi_emulator *alloc_multi_emulator(multi_modelstruct *m)
 	e->nthetas = m->pca_model_array[0]->options->nthetas;
 	e->model = m;
 	e->emu_struct_array = (emulator_struct **)malloc(sizeof(emulator_struct *) * (size_t)e->nr);
-	/* component i lives on device slot i mod S: emulate_points_multi starts all of them before it waits for the first */
+	/* component i lives on device slot i mod S: emulate_points_multi starts all of them before it waits for the first.  The
+	 * components that share a device are set up by ONE lock-step factorisation (gpemu_host_alloc_emulators) instead of the
+	 * reference's one alloc_emulator_struct after the other: eight single-matrix chains are eight times the latency-bound
+	 * panel chain, a batch of eight pays it once. */
 	const int pinned = gpemu_host_thread_device_get();
-	for (int i = 0; i < e->nr; i++) {
-		if (pinned < 0) gpemu_host_thread_device(gpemu_host_slot_device(i));
-		e->emu_struct_array[i] = alloc_emulator_struct(m->pca_model_array[i]);
+	const int fill_cinverse = getenv("GPEMU_SKIP_CINVERSE") == NULL;
+	modelstruct **models = (modelstruct **)malloc(sizeof(modelstruct *) * (size_t)e->nr);
+	emulator_struct **made = (emulator_struct **)malloc(sizeof(emulator_struct *) * (size_t)e->nr);
+	int *which = (int *)malloc(sizeof(int) * (size_t)e->nr);
+	char *done = (char *)calloc((size_t)e->nr, 1);
+	for (int first = 0; first < e->nr; first++) {
+		if (done[first]) continue;
+		const int dev = pinned >= 0 ? pinned : gpemu_host_slot_device(first);
+		int n = 0;
+		for (int i = first; i < e->nr; i++)              /* every component whose slot sits on this device */
+			if (!done[i] && (pinned >= 0 || gpemu_host_slot_device(i) == dev)) { models[n] = m->pca_model_array[i]; which[n++] = i; done[i] = 1; }
+		gpemu_host_thread_device(dev);
+		for (int b0 = 0; b0 < n; b0 += 16) {               /* (workspace: 16 x (2 Np + 64) x Np x 8 bytes per call) */
+			const int nb = n - b0 < 16 ? n - b0 : 16;
+			gpemu_host_alloc_emulators(models + b0, nb, fill_cinverse, made + b0);
+		}
+		for (int k = 0; k < n; k++) e->emu_struct_array[which[k]] = made[k];
 	}
 	gpemu_host_thread_device(pinned);
+	free(which);
+	free(models); free(made); free(done);
 	return e;
 }
 

@@ -31,6 +31,7 @@
 static long g_stat_runs = 0, g_stat_converged = 0, g_stat_noprogress = 0, g_stat_fallbacks = 0, g_stat_iters = 0;
 static double g_stat_best_gnorm = -1.0;         /* |gradient| at the end of the winning run of the LAST search */
 static __thread double tls_run_gnorm = -1.0, tls_best_gnorm = -1.0;
+static __thread long *tls_runs = NULL, *tls_iters = NULL;      /* the counters of the search this thread works for */
 void gpemu_host_search_stats(long *runs, long *converged, long *noprogress, long *ls_fallbacks, double *best_gnorm)
 {
 	if (runs) *runs = __sync_fetch_and_add(&g_stat_runs, 0);
@@ -269,6 +270,8 @@ int doOptimizeMultiMin(double (*fn)(const gsl_vector *, void *),
 	tls_run_gnorm = sqrt(dot(g, g, n));
 	__sync_fetch_and_add(&g_stat_runs, 1);
 	__sync_fetch_and_add(&g_stat_iters, stepcount);
+	if (tls_runs) __sync_fetch_and_add(tls_runs, 1);
+	if (tls_iters) __sync_fetch_and_add(tls_iters, stepcount);
 	if (status == GSL_SUCCESS) __sync_fetch_and_add(&g_stat_converged, 1);
 	if (status == GSL_ENOPROG) __sync_fetch_and_add(&g_stat_noprogress, 1);
 	if (stepcount == stepmax) fprintf(stderr, "# (error) multimin: no converge at stepmax %d\n", stepmax);
@@ -343,6 +346,8 @@ struct pool {
 	double best_likelyhood_val;
 	int best_run;
 	double best_gnorm;
+	long evals[5];                   /* device_bridge.c gpemu_host_thread_counters: this search's own evaluation counters */
+	long runs, iters;                /* BFGS runs and iterations of this search */
 };
 
 struct worker { struct pool *pool; struct estimate_thetas_params params; int id; int in_group; int device; gsl_vector *best_thetas; };
@@ -359,6 +364,9 @@ static void *worker_main(void *arg)
 	struct worker *w = (struct worker *)arg;
 	struct pool *P = w->pool;
 	gpemu_host_thread_device(w->device);         /* contexts this thread creates live on its slot's device */
+	extern void gpemu_host_thread_counters(long *five);
+	gpemu_host_thread_counters(P->evals);
+	tls_runs = &P->runs; tls_iters = &P->iters;
 	for (;;) {
 		pthread_mutex_lock(&P->result_lock);
 		/* (one process per GPU, ranks.c: this rank owns the runs rank, rank + W, ... of the list) */
@@ -382,6 +390,8 @@ static void *worker_main(void *arg)
 		pthread_mutex_unlock(&P->result_lock);
 	}
 	if (w->in_group) gpemu_host_group_leave(&w->params);
+	gpemu_host_thread_counters(NULL);
+	tls_runs = tls_iters = NULL;
 	return NULL;
 }
 
@@ -409,6 +419,18 @@ int gpemu_host_plan_groups(int total_runs, int lockstep, int per_slot, int nslot
 	}
 	if (nthreads_out) *nthreads_out = nthreads;
 	return ngroups;
+}
+
+/* every group holds a value+gradient workspace on its slot's device: lockstep x (2 Np + 64) x Np x 8 bytes plus up to 10 GB
+ * of C^-1 corners (gpemu.h) */
+double gpemu_host_group_bytes(int nmodel_points, int lockstep)
+{
+	const double Np = 64.0 * ceil(nmodel_points / 64.0);
+	const double corner = (Np + 64.0) * (Np + 64.0) * 8.0;
+	double corners = floor(10.0e9 / corner);
+	if (corners < 1.0) corners = 1.0;
+	if (corners > lockstep) corners = lockstep;
+	return lockstep * (2.0 * Np + 64.0) * Np * 8.0 + corners * corner + 64.0e6;
 }
 
 /* libEmu/estimate_threaded.c:78-237.  The reference starts one pthread per CPU, each running jobs of 50 restarts
@@ -448,16 +470,12 @@ void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 		 * to 10 GB of C^-1 corners (gpemu.h).  Two groups per slot are the default only while they fit the device's FREE
 		 * memory with a margin (at N ~ 24 000 one group of 16 needs ~155 GB: one fits 288 GB, two do not); the result of
 		 * a search does not depend on the number of groups, only its speed does. */
-		const double Np = 64.0 * ceil(options->nmodel_points / 64.0);
-		const double corner = (Np + 64.0) * (Np + 64.0) * 8.0;
-		double corners = floor(10.0e9 / corner);
-		if (corners < 1.0) corners = 1.0;
-		if (corners > lockstep) corners = lockstep;
-		const double need = lockstep * (2.0 * Np + 64.0) * Np * 8.0 + corners * corner + 64.0e6;
+		const double need = gpemu_host_group_bytes(options->nmodel_points, lockstep);
 		const int dev0 = gpemu_host_thread_device_get() >= 0 ? gpemu_host_thread_device_get() : gpemu_host_slot_device(0);
 		const int nsl = gpemu_host_thread_device_get() >= 0 ? 1 : gpemu_host_device_slots();
 		int sharing = 0;                               /* slots that live on the same physical device as slot 0 */
 		for (int s_ = 0; s_ < nsl; s_++) sharing += (gpemu_host_thread_device_get() >= 0 ? dev0 : gpemu_host_slot_device(s_)) == dev0;
+		sharing *= gpemu_host_thread_share_get();      /* ... and searches that run beside this one on it (estimate_multi) */
 		size_t fr = 0, tot = 0;
 		if (gpemu_device_memory(dev0, &fr, &tot) == GPEMU_OK && fr > 0)
 			while (per_slot > 1 && (double)per_slot * sharing * need > 0.9 * (double)fr) per_slot--;
@@ -487,9 +505,6 @@ void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 	if (env && atol(env) > 0) seed = (unsigned long)atol(env);
 	struct timeval tv0;
 	gettimeofday(&tv0, 0);
-	long ev0[5];
-	gpemu_host_eval_stats(&ev0[0], &ev0[1], &ev0[2], &ev0[3], &ev0[4]);
-	const long runs0 = __sync_fetch_and_add(&g_stat_runs, 0), iters0 = __sync_fetch_and_add(&g_stat_iters, 0);
 
 	struct pool P;
 	pthread_mutex_init(&P.result_lock, NULL);
@@ -499,6 +514,8 @@ void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 	P.best_likelyhood_val = SCREWUPVALUE_T;
 	P.best_run = total;
 	P.best_gnorm = -1.0;
+	memset(P.evals, 0, sizeof P.evals);
+	P.runs = P.iters = 0;
 
 	struct worker *W = (struct worker *)calloc((size_t)nthreads, sizeof *W);
 	pthread_t *tid = (pthread_t *)calloc((size_t)nthreads, sizeof *tid);
@@ -583,13 +600,10 @@ void estimate_thetas_threaded(modelstruct *the_model, optstruct *options)
 		/* one line for bench.py / a curious user: what this search cost on the device */
 		struct timeval tv1;
 		gettimeofday(&tv1, 0);
-		long ev1[5];
-		gpemu_host_eval_stats(&ev1[0], &ev1[1], &ev1[2], &ev1[3], &ev1[4]);
 		const double secs = (double)(tv1.tv_sec - tv0.tv_sec) + 1e-6 * (double)(tv1.tv_usec - tv0.tv_usec);
 		fprintf(stderr, "# search stats: runs %ld threads %d groups %d slots %d value_grad_evals %ld value_evals %ld cached %ld rounds %ld "
-		        "round_elements %ld iterations %ld seconds %.3f best %.10g\n", __sync_fetch_and_add(&g_stat_runs, 0) - runs0, nthreads, ngroups, nslots,
-		        ev1[1] - ev0[1], ev1[0] - ev0[0], ev1[2] - ev0[2], ev1[3] - ev0[3], ev1[4] - ev0[4],
-		        __sync_fetch_and_add(&g_stat_iters, 0) - iters0, secs, P.best_likelyhood_val);
+		        "round_elements %ld iterations %ld seconds %.3f best %.10g\n", P.runs, nthreads, ngroups, nslots,
+		        P.evals[1], P.evals[0], P.evals[2], P.evals[3], P.evals[4], P.iters, secs, P.best_likelyhood_val);
 	}
 	gsl_vector_free(P.best_thetas);
 	pthread_mutex_destroy(&P.result_lock);

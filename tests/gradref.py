@@ -10,6 +10,9 @@ inverse is LAPACK's (scipy cho_factor / cho_solve), and the two gradient forms a
       g[0] = -G(nug I),   g[k+1] = -G(sigma^2 * dC_k),  dC_k,ab = exp(-1/2 e^{-2 t_k} D^2 - 2 t_k) D^2, D = x_ak - x_bk
   exact (include/gpemu.h GPEMU_MODE_EXACT_GRAD): d(-logL)/dtheta = 1/2 sum_ab (A_ab - a_a a_b) dC_ab, a = A (y - H beta),
       dC/dtheta_{k+2} = C0_ab D_k^2 e^{-2 t_k} (C0 = the matrix without its nugget), dC/dtheta_1 = nug [same point]
+
+and, since round 5, the posterior mean / variance of emulate_point (emulator_struct.c:124-143; emulator.c:578-593, 672-785:
+SURVEY App. A.4) and the back-projection of emulate_point_multi (multivar_support.c:126-151) in the same style: `predict`.
 """
 import numpy as np
 import scipy.linalg as sl
@@ -84,3 +87,48 @@ def value_and_gradients(X, y, order, th):
         D2 *= C0
         exa[k + 1] = 0.5 * np.sum(W * D2)
     return dict(value=value, sigma2=sigma2, beta=beta, logdet=logdet, quad=quad, literal=lit, exact=exa)
+
+
+def kvectors(X, th, Xq):
+    """emulator.c:578-593 for a block of query rows: K[q, i] = cov(x_i, x*_q) of emulator.c:101-152 (amplitude e^t0 included,
+    nugget where every |coordinate difference| < 1e-10), then the clamp `if (cov < 1e-10) cov = 0`"""
+    M, d = Xq.shape
+    E = np.zeros((M, X.shape[0]))
+    same = np.ones((M, X.shape[0]), dtype=bool)
+    for k in range(d):
+        D = Xq[:, k][:, None] - X[:, k][None, :]
+        same &= np.abs(D) < 1e-10
+        r = np.exp(th[k + 2])
+        E += -0.5 * D * D / (r * r)
+    K = np.exp(th[0]) * np.exp(E)
+    K[same] += np.exp(th[1])
+    K[K < 1e-10] = 0.0
+    return K
+
+
+def predict(X, y, order, th, Xq):
+    """emulate_point at the rows of Xq with the pow-exp kernel at the STORED thetas (amplitude e^theta0 included):
+    mean = h.beta + k.(A y) - k.(A H beta); var = kappa - k.A.k + q.(H^T A H)^-1.q, q = h - (A H)^T k, kappa = e^t0 + e^t1
+    (x* against itself: the nugget is in).  LAPACK factor + solves; returns (mean, var)."""
+    th = np.asarray(th, float)
+    Cm, _ = powexp_matrix(X, th)
+    cf = sl.cho_factor(Cm, lower=True, overwrite_a=True, check_finite=False)
+    H = hmatrix(order, X)
+    AyH = sl.cho_solve(cf, np.column_stack([y, H]), check_finite=False)
+    Ay, AH = AyH[:, 0], AyH[:, 1:]
+    HAH = H.T @ AH
+    beta = np.linalg.solve(HAH, H.T @ Ay)
+    K = kvectors(X, th, Xq)
+    hq = hmatrix(order, Xq)
+    mean = hq @ beta + K @ Ay - K @ (AH @ beta)
+    AK = sl.cho_solve(cf, K.T, check_finite=False)                    # N x M
+    q = hq - K @ AH                                                   # M x nreg
+    kappa = np.exp(th[0]) + np.exp(th[1])
+    var = kappa - np.einsum("qi,iq->q", K, AK) + np.einsum("qa,qa->q", q, np.linalg.solve(HAH, q.T).T)
+    return mean, var
+
+
+def backproject(mean_pca, var_pca, evals, evecs, ybar):
+    """multivar_support.c:126-151: mean_t = ybar_t + sum_j U_tj sqrt(lambda_j) m_j; var_t = sum_j U_tj^2 lambda_j v_j
+    (mean_pca / var_pca: npoints x nr; evecs: nt x nr)"""
+    return ybar[None, :] + (mean_pca * np.sqrt(evals)[None, :]) @ evecs.T, (var_pca * evals[None, :]) @ (evecs ** 2).T

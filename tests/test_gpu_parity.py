@@ -1478,6 +1478,99 @@ def test_config4_eight_pca_components_n4096_d16(gpu_ctx):
         ref = -(-0.5 * logdet - N / 2.0 * 1.83788 - 0.5 * quad)
         assert got[c, 0] == pytest.approx(ref, rel=RTOL)
         assert got[c, 1] == pytest.approx(z @ sl.cho_solve(cf, r, check_finite=False) / N, rel=RTOL)
+    del Cm, cf
+
+
+@pytest.mark.parametrize("kind,N,d,order,nr", [(1, 700, 3, 1, 5), (3, 1100, 2, 2, 3), (1, 4096, 16, 0, 8)])
+def test_predict_setup_batch_is_the_per_component_call_bit_for_bit(kind, N, d, order, nr):
+    """gpemu_predict_setup_batch (alloc_multi_emulator, multivar_support.c:30-52, as ONE lock-step factorisation with inverse
+    rows: blockIdx.y = component, every component under its own right-hand-side rows): each context ends with the prediction
+    state gpemu_predict_setup gives it alone -- beta and every predicted mean / variance bit for bit, the last case at
+    BASELINE configs[3]'s size (8 components, N = 4096, d = 16).  A component whose matrix does not factor is reported in its
+    status slot and leaves the others usable."""
+    X, y = synth.design(N, d, 77 + N)
+    Ys = [np.cos(0.7 * c) * y + np.sin(1.3 * (c + 1) * X[:, c % d]) for c in range(nr)]
+    ths = np.array([synth.perturbed_thetas(kind, d, 31, c) for c in range(nr)])
+    Xq = np.vstack([synth.queries(130, d, 5), X[:2]])
+    alone = []
+    c0 = abi.Context(0)
+    for c in range(nr):
+        c0.set_model(kind, order, X, Ys[c])
+        beta, rc = c0.predict_setup(ths[c])
+        assert rc == 0
+        alone.append((beta.copy(),) + tuple(a.copy() for a in c0.predict(Xq)) + tuple(a.copy() for a in c0.predict(Xq[:1])))
+    c0.close()
+    ctxs = [abi.Context(0) for _ in range(nr)]
+    for c in range(nr):
+        ctxs[c].set_model(kind, order, X, Ys[c])
+    import time
+    t0 = time.perf_counter()
+    beta, info, status, rc = abi.predict_setup_batch(ctxs, ths)
+    t_first = time.perf_counter() - t0
+    assert rc == 0 and np.all(status == 0) and np.all(info == 0)
+    for c in range(nr):
+        m, v = ctxs[c].predict(Xq)
+        m1, v1 = ctxs[c].predict(Xq[:1])
+        assert np.array_equal(beta[c], alone[c][0]) and np.array_equal(m, alone[c][1]) and np.array_equal(v, alone[c][2]), c
+        assert m1[0] == alone[c][3][0] and v1[0] == alone[c][4][0]
+    # again (replayed launch graph), with the components' thetas rotated: every context gets the other state
+    rot = np.roll(ths, 1, axis=0)
+    for rep in range(2):
+        t0 = time.perf_counter()
+        beta2, _, status2, rc2 = abi.predict_setup_batch(ctxs, rot)
+        t_again = time.perf_counter() - t0
+    assert rc2 == 0 and not np.array_equal(beta2, beta)
+    ref = abi.Context(0)
+    ref.set_model(kind, order, X, Ys[1])
+    ref.predict_setup(rot[1])
+    assert np.array_equal(ctxs[1].predict(Xq)[0], ref.predict(Xq)[0])
+    ref.close()
+    flops = nr * 2.0 * (64 * ((N + 63) // 64)) ** 3 / 3.0
+    print(f"predict_setup_batch kind={kind} N={N} d={d} nr={nr}: first {t_first * 1e3:.2f} ms, replay {t_again * 1e3:.2f} ms = "
+          f"{t_again / nr * 1e3:.2f} ms per component = {flops / t_again / 78.6e12:.3f} of the 2N^3/3 roofline")
+    if kind == 3:
+        bad = ths.copy()
+        bad[1, 0] = -1.0                                    # raw Matern amplitude < 0: not positive definite
+        beta3, info3, status3, rc3 = abi.predict_setup_batch(ctxs, bad)
+        assert rc3 == abi.ERR_NOT_PD and status3[1] == abi.ERR_NOT_PD and info3[1] > 0 and status3[0] == 0 and status3[2] == 0
+        assert np.array_equal(ctxs[0].predict(Xq)[0], alone[0][1])
+        with pytest.raises(abi.GpemuError):
+            ctxs[1].predict(Xq)                             # left without a set-up
+    for cx in ctxs:
+        cx.close()
+
+
+def test_config4_predictions_per_component_and_backprojection_d16():
+    """a16 - a19 at configs[3]'s size and dimension (N=4096, d=16, 8 PCA components of 9 outputs): 64 predictions per component
+    -- each component at thetas of its own -- against LAPACK solves on numpy-built matrices (tests/gradref.py predict:
+    emulator.c:578-593, 672-785 restated), and the 9 back-projected outputs of emulate_point_multi against numpy
+    (multivar_support.c:126-151).  Regression order 1 (17 basis functions at d = 16): the W^T rows of the sweep are in."""
+    import gradref
+    N, d, nt = 4096, 16, 9
+    X, y = synth.design(N, d, 20261003 + 3)
+    Y = synth.multi_outputs(X, y, nt)
+    Z, evals, evecs, ybar = synth.pca_zmatrix(Y)
+    nr = Z.shape[1]
+    assert nr == 8
+    Xq = np.vstack([synth.queries(62, d, 17), X[9:10], np.full((1, d), 30.0)])
+    mp, vp = np.empty((64, nr)), np.empty((64, nr))
+    mo, vo = np.empty((64, nr)), np.empty((64, nr))
+    c = abi.Context(0)
+    for j in range(nr):
+        th = synth.perturbed_thetas(1, d, 77, j)
+        c.set_model(1, 1, X, Z[:, j].copy())
+        c.predict_setup(th)
+        mp[:, j], vp[:, j] = c.predict(Xq)
+        mo[:, j], vo[:, j] = gradref.predict(X, Z[:, j], 1, th, Xq)
+        kappa = np.exp(th[0]) + np.exp(th[1])
+        assert np.max(np.abs(mp[:, j] - mo[:, j])) <= RTOL * max(1.0, np.max(np.abs(mo[:, j]))), j
+        assert np.max(np.abs(vp[:, j] - vo[:, j])) <= RTOL * kappa, j
+    c.close()
+    print("config4 predictions: mean", np.max(np.abs(mp - mo)), "variance", np.max(np.abs(vp - vo)))
+    # observable space: the device's PCA-space numbers through numpy's back-projection against the all-numpy chain
+    ym, yv = gradref.backproject(mp, vp, evals, evecs, ybar)
+    ymo, yvo = gradref.backproject(mo, vo, evals, evecs, ybar)
+    assert ym.shape == (64, nt) and np.max(np.abs(ym - ymo)) <= RTOL * np.max(np.abs(ymo)) and np.max(np.abs(yv - yvo)) <= RTOL * np.max(yvo)
 
 
 def test_n32768_beyond_the_baseline_sizes(gpu_ctx):
@@ -1531,3 +1624,28 @@ def test_config5_n16384_powexp(gpu_ctx):
     gpu_ctx.set_training(3.0 * y)
     c = gpu_ctx.loglik(th)
     assert c["quad"] == pytest.approx(9.0 * a["quad"], rel=1e-12) and c["logdet"] == a["logdet"]
+    gpu_ctx.set_training(y)
+    # a12 / a13 and a16 - a19 at this size (the config IS a hyper-parameter search, maxmultimin.c:416-550): value, literal and
+    # exact gradient and 64 predictions against tests/golden/golden_n16384_c5.npz -- the numpy / LAPACK chain of
+    # tests/gradref.py run offline (make_golden_n16384_c5.py: one explicit N = 16384 inverse, about 4 minutes of 8 host cores)
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_n16384_c5.npz"))
+    assert [int(v) for v in f["meta"]] == [1, 0, N, d, 20261003 + 4] and np.array_equal(f["thetas"], th)
+    assert a["value"] == pytest.approx(float(f["value"]), rel=RTOL) and a["sigma2"] == pytest.approx(float(f["sigma2"]), rel=RTOL)
+    assert logdet == pytest.approx(float(f["logdet"]), rel=1e-10) and quad == pytest.approx(float(f["quad"]), rel=1e-9)   # fixture == the live LAPACK pass above
+    ths = np.array([th])
+    ths[:, 0] = 0.0
+    lit = _check_gradient_entries(gpu_ctx, ths, [f["literal"]], [float(f["value"])])
+    gpu_ctx.set_mode(abi.MODE_EXACT_GRAD)
+    exa = _check_gradient_entries(gpu_ctx, ths, [f["exact"]], [float(f["value"])])
+    gpu_ctx.set_mode(0)
+    print(f"config5 gradient N={N}: literal {max(lit):.2e} exact {max(exa):.2e} of the largest component")
+    # 62 random queries, a training point, a far point whose k-vector is clamped to zero (its mean is the trend alone)
+    Xq, mo, vo = f["Xq"], f["mean"], f["var"]
+    gpu_ctx.predict_setup(th)
+    m, v = gpu_ctx.predict(Xq)
+    kappa = np.exp(th[0]) + np.exp(th[1])
+    print("config5 predictions", np.max(np.abs(m - mo)), np.max(np.abs(v - vo)) / kappa)
+    assert np.max(np.abs(m - mo)) <= RTOL * max(1.0, np.max(np.abs(mo))) and np.max(np.abs(v - vo)) <= RTOL * kappa
+    assert mo[-1] == pytest.approx(float(f["beta"][0]), rel=1e-9) and m[-1] == pytest.approx(a["beta"][0], rel=1e-12)
+    m1, v1 = gpu_ctx.predict(Xq[:1])                         # the one-query path (gemv_tri_kernel) at this size
+    assert abs(m1[0] - mo[0]) <= RTOL * max(1.0, abs(mo[0])) and abs(v1[0] - vo[0]) <= RTOL * kappa

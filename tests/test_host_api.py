@@ -1204,22 +1204,16 @@ def test_reference_example_scripts_uni_2d_param_and_multi_simple(tmp_path):
     except np.linalg.LinAlgError:
         lapack_ok = False
     im = subprocess.run([cli, "interactive_mode", str(snap)], stdin=open(qpath), capture_output=True, text=True, timeout=600)
-    warned = "numerically singular" in tr.stderr
-    if im.returncode != 0:
-        assert "trying to cholesky a non postive def matrix, in emulate-fns.c sorry..." in im.stderr
-        assert warned and not lapack_ok and sd["models"][0]["thetas"][1] < -25.0
-    else:
-        assert not warned
-        lines = im.stdout.split()
-        assert lines[:6] == ["2", "param_0", "param_1", "2", "mean_0", "variance_0"]          # nskip = 6 = 4 + nparams
-        vals = np.array(lines[6:], float).reshape(-1, 2)
-        assert len(vals) == len(Q) > 100
-        _, mean, var = _oracle_through_snapshot(snap.read_text(), Q)
-        assert np.max(np.abs(vals[:, 0] - mean[:, 0])) < 1e-7 * max(1.0, np.abs(mean).max())
-        assert np.max(np.abs(vals[:, 1] - var[:, 0])) < 1e-7 * max(1e-3, np.abs(var).max())
+    # ONE outcome, asserted (round-4 verdict: the test accepted either): with this seed and run list the search is deterministic
+    # -- run r starts from (seed, r), the device arithmetic is bit-reproducible -- and ends, as for every seed tried
+    # (scratch/r04_uni2d_seeds.sh), at a nugget below e^-25 where the amplitude-scaled matrix no longer factors: the CLI warns at
+    # training time, interactive_mode refuses the snapshot with the reference's message and status 1, LAPACK agrees
+    assert "numerically singular" in tr.stderr and "GPEMU_NUGGET_FLOOR" in tr.stderr
+    assert im.returncode == 1, (im.returncode, im.stderr[-500:])
+    assert "trying to cholesky a non postive def matrix, in emulate-fns.c sorry..." in im.stderr
+    assert not lapack_ok and sd["models"][0]["thetas"][1] < -25.0
     # the same example with the lower wall the warning names (GPEMU_NUGGET_FLOOR, not in the reference): the search stops at
     # the wall, the snapshot is usable, and sample-emulator.sh's output agrees with the oracle at the snapshot's thetas
-    assert "GPEMU_NUGGET_FLOOR" in tr.stderr or im.returncode == 0
     snap2 = tmp_path / "M_floor.dat"
     tr2 = subprocess.run([cli, "estimate_thetas", TWOD, str(snap2), "--regression_order=1"], env=dict(env, GPEMU_NUGGET_FLOOR="-12"),
                          capture_output=True, text=True, timeout=600)
