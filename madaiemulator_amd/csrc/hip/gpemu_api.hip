@@ -158,6 +158,7 @@ static Sched read_environment()
 	sc.gemv_point = geti("GPEMU_GEMV_POINT", 1) != 0;
 	sc.idle_waves = geti("GPEMU_IDLE_WAVES", 1) != 0;
 	sc.neg_modifier = geti("GPEMU_NEG_MODIFIER", 1) != 0;
+	sc.grad_gram = geti("GPEMU_GRAD_GRAM", 1) != 0;
 	sc.stagger_us = std::max(0, std::min(1000, geti("GPEMU_STAGGER_US", 20)));
 	sc.factor_ahead = geti("GPEMU_FACTOR_AHEAD", 1) != 0;
 	v = geti("GPEMU_NB_TOP", 0);
@@ -455,16 +456,19 @@ static int make_cov_params(gpemu_ctx *ctx, const double *thetas, int nthetas, Co
 	}
 	// Gram form of the training fill (kernels_cov.hip): only while the centred, scaled design stays small -- the
 	// cancellation error of |x'|^2 + |y'|^2 - 2 x'.y' is a few ulp of 2 * norm2
-	p->gram = 0; p->cand_g = 0.0;
-	if (ctx->sched.fill_gram && ctx->dXg && (int)ctx->xhalf.size() == ctx->d) {
+	p->gram = 0; p->cand_g = 0.0; p->cand_w = p->cand;
+	if (ctx->dXg && (int)ctx->xhalf.size() == ctx->d) {
 		double norm2 = 0.0;
 		for (int k = 0; k < ctx->d; k++) {
 			const double t = ctx->xhalf[k] * p->w[ctx->kind == GPEMU_POWEREXP ? k : 0];
 			norm2 += t * t;
 		}
-		if (norm2 <= 16.0) {
+		// the candidates of the nugget rule in a Gram-form distance: below the difference form's bound plus the form's own
+		// cancellation error (a few ulp of |x'|^2 + |y'|^2 <= 2 norm2, 64 ulp allowed), whatever the length scales
+		p->cand_w = p->cand + 64.0 * 2.220446049250313e-16 * (2.0 * norm2 + 1.0);
+		if (ctx->sched.fill_gram && norm2 <= 16.0) {
 			p->gram = 1;
-			p->cand_g = p->cand + 64.0 * 2.220446049250313e-16 * (2.0 * norm2 + 1.0);
+			p->cand_g = p->cand_w;
 		}
 	}
 	return GPEMU_OK;
@@ -550,7 +554,9 @@ static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv, bool diag_do
 	// epilogue; 3.329 at 1024, 3.302 at 2048, 3.314 at 4096 now; 2048 also wins at N = 4096, 12288, 16384)
 	// With the inverse rows under the matrix (gradient, explicit inverse) 1024 is better again: 10.40 against 10.77 ms
 	// per value+gradient evaluation in batches of 16.
-	const int nb_top = ctx->sched.nb_top > 0 ? ctx->sched.nb_top : (ctx->nb >= 2 ? (inv ? 1024 : 2048) : 512);
+	// Round 5, measured at N = 4096 (profiles/r05_n4096_schedule_switches.txt): with the inverse rows 512 beats 1024 there
+	// (value+gradient batches of 16 / 64: +2 %), without them 1024 .. 4096 are within 0.5 % of each other.
+	const int nb_top = ctx->sched.nb_top > 0 ? ctx->sched.nb_top : (ctx->nb >= 2 ? (inv ? (ctx->Np <= 4096 ? 512 : 1024) : 2048) : 512);
 	if (n > nb_top) {
 		// right-looking over panels of nb_top columns: the trailing update touches the whole remaining
 		// matrix (thousands of tiles, K = panel width), which fills the chip far better than the few huge-K
@@ -1023,6 +1029,7 @@ extern "C" int gpemu_predict_setup(gpemu_ctx *ctx, const double *thetas, int nth
 	if (r.status) return fail(ctx, r.status, "H^T C^-1 H is not positive definite");
 	rc = build_prediction_state(ctx, 0, ctx, p, r, thetas, nthetas);
 	if (rc) return rc;
+	ctx->fact_in_T = true;
 	if (beta_out) for (int a = 0; a < ctx->nreg; a++) beta_out[a] = r.beta[a];
 	return GPEMU_OK;
 }
@@ -1084,6 +1091,7 @@ extern "C" int gpemu_predict_setup_batch(gpemu_ctx *const *ctxs, int n, const do
 			if (r.status) st = r.status;
 			else {
 				st = build_prediction_state(lead, c, ctxs[c], ps[c], r, thetas + (size_t)c * nthetas, nthetas);
+				ctxs[c]->fact_in_T = (c == 0);                // (element 0 of the batch sits where a single set-up leaves it)
 				if (st == GPEMU_OK && beta_out) for (int a = 0; a < nreg; a++) beta_out[(size_t)c * nreg + a] = r.beta[a];
 			}
 		}
@@ -1111,17 +1119,15 @@ extern "C" int gpemu_warm_start(int device)
 		X[(size_t)i * d + 1] = (i / 8) / 8.0;
 		y[i] = std::sin(0.3 * i);
 	}
-	for (int kind = GPEMU_POWEREXP; kind <= GPEMU_MATERN52 && !rc; kind += 2) {
-		const double th_pe[4] = {0.0, -3.0, -1.0, -1.0}, th_m[3] = {1.0, 0.05, -0.5};
-		const double *th = kind == GPEMU_POWEREXP ? th_pe : th_m;
-		const int nth = kind == GPEMU_POWEREXP ? 4 : 3;
-		rc = gpemu_set_model(ctx, kind, 1, N, d, X.data(), y.data());
+	{
+		// (one covariance function is enough: the instantiations for the others sit in the same code objects)
+		const double th[4] = {0.0, -3.0, -1.0, -1.0};
+		rc = gpemu_set_model(ctx, GPEMU_POWEREXP, 1, N, d, X.data(), y.data());
 		double v, s2, m, var;
 		int info = 0;
-		if (!rc) rc = gpemu_loglik(ctx, th, nth, &v, &s2, nullptr, nullptr, nullptr, &info);
-		if (!rc) rc = gpemu_predict_setup(ctx, th, nth, nullptr, &info);
+		if (!rc) rc = gpemu_loglik(ctx, th, 4, &v, &s2, nullptr, nullptr, nullptr, &info);
+		if (!rc) rc = gpemu_predict_setup(ctx, th, 4, nullptr, &info);
 		if (!rc) rc = gpemu_predict_batch(ctx, 1, X.data(), &m, &var);
-		if (!rc) { std::vector<double> mm(70), vv(70), q((size_t)70 * d, 0.3); rc = gpemu_predict_batch(ctx, 70, q.data(), mm.data(), vv.data()); }
 	}
 	gpemu_ctx_destroy(ctx);
 	return rc;
@@ -1311,6 +1317,15 @@ extern "C" int gpemu_get_cinverse(gpemu_ctx *ctx, double *cinv_out)
 	if (!ctx || !cinv_out) return GPEMU_ERR_ARG;
 	if (!ctx->pred_ready) return fail(ctx, GPEMU_ERR_STATE, "gpemu_predict_setup has not been called");
 	HIPCHK(ctx, hipSetDevice(ctx->device));
+	if (!ctx->cinv_ready && !ctx->fact_in_T) {
+		// set up by gpemu_predict_setup_batch as a later component: its factorisation ran in the first context's workspace
+		// (round 5: reading this context's own, never allocated workspace here was a GPU memory fault).  The explicit inverse is
+		// the slow path anyway (N x N doubles to the host): factor this component alone, same thetas, same bits.
+		const std::vector<double> th = ctx->last_thetas;
+		int info = 0;
+		int rc = gpemu_predict_setup(ctx, th.data(), (int)th.size(), nullptr, &info);
+		if (rc) return rc;
+	}
 	if (!ctx->cinv_ready) {
 		int rc = build_corner(ctx);
 		if (rc) return rc;
@@ -1411,7 +1426,7 @@ static int grad_enqueue_chunk(gpemu_ctx *ctx, int b0, int nbc, const double *th_
 		}
 	HIPCHK(ctx, launch_grad_partials(ctx->stream, ctx->dS, (long)dim, Rp, (long)sstride, nbc, ctx->dX, N, d, ctx->dAlpha, ctx->Np,
 	                                 (long)gslot, ctx->dGradPart, (long)need, &nparts, exact ? ctx->kind : 0, ctx->nreg,
-	                                 ctx->dParams + b0, noclamp));
+	                                 ctx->dParams + b0, noclamp, ctx->sched.grad_gram ? ctx->dXg : nullptr));
 	HIPCHK(ctx, launch_grad_reduce(ctx->stream, ctx->dGradPart, (long)need, nparts, np, nbc,
 	                               ctx->dGradSum + (size_t)b0 * gpemu_ctx::GRAD_NP_MAX, (long)gpemu_ctx::GRAD_NP_MAX));
 	return GPEMU_OK;

@@ -35,6 +35,7 @@ struct CovParams {
 	int gram;            // 1: the square training fill may use the MFMA Gram form of the squared distances (kernels_cov.hip)
 	int pad_;
 	double cand_g;       // Gram form: squared scaled distances at or below this are recomputed from differences
+	double cand_w;       // the exact gradient's Gram-form weights (any length scale): likewise, with that form's own error bound
 	double w[GPEMU_MAX_PARAMS];
 };
 
@@ -88,6 +89,7 @@ struct Sched {
 	int nb_top = 0;              // GPEMU_NB_TOP: outer panel width; 0 = automatic (512 for one matrix, 2048 / 1024 for a batch)
 	int split_rhs_rows = 1;      // GPEMU_SPLIT_RHS_ROWS: big-tile updates take the 64 right-hand-side rows in a launch of their own
 	int neg_modifier = 1;        // GPEMU_NEG_MODIFIER: C - A B^T through the NEG bit of the fp64 matrix instruction
+	int grad_gram = 1;           // GPEMU_GRAD_GRAM: the exact gradient's tile distances from the matrix unit (grad_exact_gram_kernel)
 	int stagger_us = 20;         // GPEMU_STAGGER_US: first-round offset between the two workgroups of a CU in the 128x128 GEMM (0 = none)
 };
 
@@ -168,6 +170,8 @@ struct gpemu_ctx {
 	double *hStage = nullptr;    // pinned: stage_cap*d query coordinates, then stage_cap means, then stage_cap variances
 	int pred_pending = 0;        // queries of an enqueued, not yet collected prediction batch
 	bool cinv_ready = false;
+	bool fact_in_T = false;      // the factorisation (with inverse rows) behind the prediction state sits in THIS context's workspace, element 0
+	                             // (false after gpemu_predict_setup_batch for every context but the first: their factorisations ran in the first one's)
 	double *dS = nullptr;        // S_cap corners of (Rp+Np)^2 for explicit inverse / gradient (one per batch element in flight)
 	size_t S_dim = 0;
 	int S_cap = 0;
@@ -225,7 +229,8 @@ hipError_t launch_predict_finish_small(hipStream_t s, const double *Vp, long ldv
                                        int d, const double *Xq, const double *betaQ, double kappa, double *mean, double *var);
 hipError_t launch_grad_partials(hipStream_t s, const double *S, long lds, int soff, long sstride, int nb, const double *X, int N,
                                 int d, double *ag, int np_pad, long gstride, double *part, long pstride, int *nparts,
-                                int exact_kind = 0, int nbeta = 0, const CovParams *pp_dev = nullptr, bool lit_noclamp = false);
+                                int exact_kind = 0, int nbeta = 0, const CovParams *pp_dev = nullptr, bool lit_noclamp = false,
+                                const double *Xg = nullptr);
 
 hipError_t launch_beta_solve(hipStream_t s, const double *res, long rstride, int Rp, int nreg, int nb, double *ag, long gstride,
                              int np_pad);

@@ -329,6 +329,11 @@ __device__ __forceinline__ void cov_fill_tile_gram_k(double *out, long ld, const
 						a = fma(t, t, a);
 						cnt += (fabs(D) < p.eps) ? 1 : 0;
 					}
+					// the table exp below has no clamp of its own (the Gram form proper keeps its argument above -70); a query
+					// row far outside the design arrives HERE with a squared scaled distance of any size (round 5: coordinates
+					// of 30 at d = 16 gave exp(-23 000) = NaN): hold the exponent at -700 (1e-304, which the k-vector clamp of
+					// emulator.c:588-590 turns into the zero the reference computes)
+					a = fmin(a, KIND == GPEMU_POWEREXP ? 700.0 : 490000.0);
 #pragma unroll
 					for (int rr = 0; rr < 4; rr++)
 #pragma unroll
@@ -1166,6 +1171,204 @@ __global__ __launch_bounds__(256) void grad_exact_kernel(const double *S, long l
 	}
 }
 
+// The same sums with the tile's squared scaled distances from the fp64 MFMA (round 5).  grad_exact_kernel above spends
+// 5 d vector instructions per element on the distance and the "same point" test and 4-5 more per element and direction
+// (164 at d = 16: 4 ms per batch of 16 at N = 4096, d = 16 -- a sixth of a value+gradient batch, profiles/
+// r05_pca8_cli_training_kernel_trace.txt); here the distances of a 64 x 64 tile are d/4 + 1 matrix instructions per wave
+// (|x'|^2 + |y'|^2 - 2 x'.y' on the design centred per dimension, as the Gram-form fill), the exp is the fill's 1024-entry
+// table form, and a direction costs a subtraction, a product and an FMA per element.  The Gram form's cancellation error
+// -- a few ulp of |x'|^2 + |y'|^2 in the squared distance, i.e. that much RELATIVE error in a weight -- is harmless
+// here at any length scale: the weights enter plain sums (no factorisation amplifies them), and the bar is 1e-8 of the
+// largest gradient component.  (The fill itself keeps its bound, make_cov_params: there the error meets cond(C).)
+// Pairs whose squared distance comes out below p.cand_w -- the nugget rule's candidates plus the cancellation bound -- are
+// recomputed from differences and take the exact "same point" test on the raw coordinates, as in the fill.
+// Lane (q, g) of wave w holds the elements (row 16 w + g + 4 r, column 16 j + q), r, j < 4.
+// LDS (doubles): coordinate tiles transposed [d][64] x 2, alpha x 2, table 1024, scales d, reduction scratch 256 x 17.
+__host__ __device__ inline size_t grad_gram_lds_doubles(int d) { return (size_t)128 * d + 128 + EXP_TAB_G + ((d + 1) & ~1) + 256 * 17; }
+
+template <int KIND>
+__global__ __launch_bounds__(256) void grad_exact_gram_kernel(const double *S, long lds_, int soff, long sstride, const double *X,
+                                                              const double *Xg, int N, int d, const double *ag, long gstride,
+                                                              double *part, long pstride, const CovParams *pp)
+{
+	S += (long)blockIdx.y * sstride;
+	const double *alpha = ag + (long)blockIdx.y * gstride;
+	part += (long)blockIdx.y * pstride;
+	const int np = 2 * d + 2;
+	const int nd = (KIND == GPEMU_POWEREXP) ? d : 1;
+	int tr, tc;
+	lower_tile(blockIdx.x, tr, tc);
+	const long t = blockIdx.x;
+
+	__shared__ CovParams ps;
+	extern __shared__ double grad_sm[];
+	const int dpad = (d + 1) & ~1;
+	double *xr_t = grad_sm, *xc_t = xr_t + 64 * d, *ar_s = xc_t + 64 * d, *ac_s = ar_s + 64, *tab = ac_s + 64;
+	double *wsc = tab + EXP_TAB_G, *scratch = wsc + dpad;
+	const int tid = threadIdx.x;
+	for (int e = tid; e < (int)(sizeof(CovParams) / sizeof(double)); e += 256)
+		reinterpret_cast<double *>(&ps)[e] = reinterpret_cast<const double *>(pp + blockIdx.y)[e];
+	for (int e = tid; e < 64 * d; e += 256) {
+		const int r = e / d, k = e % d;
+		const int gr = tr * 64 + r, gc = tc * 64 + r;
+		xr_t[k * 64 + r] = (gr < N) ? Xg[(long)gr * d + k] : 0.0;
+		xc_t[k * 64 + r] = (gc < N) ? Xg[(long)gc * d + k] : 0.0;
+	}
+	if (tid < 64) {
+		const int gr = tr * 64 + tid, gc = tc * 64 + tid;
+		ar_s[tid] = (gr < N) ? alpha[gr] : 0.0;
+		ac_s[tid] = (gc < N) ? alpha[gc] : 0.0;
+	}
+	__syncthreads();                                                  // ps is read below by every thread
+	const double croot = gram_root(KIND);
+	for (int e = tid; e < EXP_TAB_G; e += 256) tab[e] = g_exp2_tab[e] * ps.amp;
+	if (tid < d) wsc[tid] = ps.w[(KIND == GPEMU_POWEREXP) ? tid : 0] * croot;
+	__syncthreads();
+
+	const int lane = tid & 63, wave = tid >> 6;
+	const int q = lane & 15, g = lane >> 4;
+	// squared scaled distances of the lane's 16 elements from the matrix unit
+	d4g_t acc[4];
+#pragma unroll
+	for (int j = 0; j < 4; j++) acc[j] = (d4g_t){0.0, 0.0, 0.0, 0.0};
+	double na = 0.0, nb[4] = {0.0, 0.0, 0.0, 0.0};
+	for (int k0 = 0; k0 < d; k0 += 4) {
+		const int k = k0 + g;
+		const bool kv = k < d;
+		const double wk_ = wsc[kv ? k : 0];
+		const double xa = kv ? xr_t[k * 64 + 16 * wave + q] * wk_ : 0.0;
+		na = fma(xa, xa, na);
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			const double xb = kv ? xc_t[k * 64 + 16 * j + q] * wk_ : 0.0;
+			nb[j] = fma(xb, xb, nb[j]);
+			acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, -2.0 * xb, acc[j], 0, 0, 0);
+		}
+	}
+	na += __shfl_xor(na, 16); na += __shfl_xor(na, 32);
+#pragma unroll
+	for (int j = 0; j < 4; j++) { nb[j] += __shfl_xor(nb[j], 16); nb[j] += __shfl_xor(nb[j], 32); }
+	{
+		const double ea = (g == 0) ? na : (g == 1 ? 1.0 : 0.0);
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			const double eb = (g == 0) ? 1.0 : (g == 1 ? nb[j] : 0.0);
+			acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ea, eb, acc[j], 0, 0, 0);
+		}
+	}
+	const int row0 = 16 * wave + g, col0 = q;                         // tile-local
+	// nugget-rule candidates (the diagonal, duplicated design points): exact distance and "same point" test
+	const double cand_w = ps.cand_w * croot * croot;
+	unsigned same = 0;
+	{
+		bool cand = false;
+#pragma unroll
+		for (int r = 0; r < 4; r++)
+#pragma unroll
+			for (int j = 0; j < 4; j++) cand = cand || (acc[j][r] <= cand_w);
+		if (__any(cand)) {
+#pragma unroll 1
+			for (int e = 0; e < 16; e++) {
+				const int r = e >> 2, j = e & 3;
+				double ae = 0.0;
+#pragma unroll
+				for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+					for (int jj = 0; jj < 4; jj++) ae = (rr == r && jj == j) ? acc[jj][rr] : ae;
+				const int gr = tr * 64 + row0 + 4 * r, gc = tc * 64 + col0 + 16 * j;
+				if (ae <= cand_w && gr < N && gc < N) {
+					int cnt = 0;
+					double a = 0.0;
+					for (int k = 0; k < d; k++) {
+						const double D = X[(long)gr * d + k] - X[(long)gc * d + k];
+						const double v = D * wsc[k];
+						a = fma(v, v, a);
+						cnt += (fabs(D) < ps.eps) ? 1 : 0;
+					}
+#pragma unroll
+					for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+						for (int jj = 0; jj < 4; jj++) acc[jj][rr] = (rr == r && jj == j) ? a : acc[jj][rr];
+					if (cnt == d) same |= 1u << e;
+				}
+			}
+		}
+	}
+	// weight of every element times its kernel factor (pow-exp: the kernel value E; Matern: dC/dlog rho)
+	double wk[4][4];                                                  // [r][j]
+	double s_nug = 0.0;
+#pragma unroll
+	for (int r = 0; r < 4; r++) {
+		const int lr = row0 + 4 * r, gr = tr * 64 + lr;
+		const double arow = ar_s[lr];
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			const int lc = col0 + 16 * j, gc = tc * 64 + lc;
+			const bool valid = gr < N && gc < N && gc <= gr;
+			double W = 0.0;
+			if (valid) {
+				const double a = S[(long)(soff + gr) * lds_ + soff + gc];
+				W = ((gc == gr) ? 1.0 : 2.0) * (a - arow * ac_s[lc]);
+			}
+			// (the exponent held at -600: weights beyond that are 1e-261 of the amplitude either way, and the table exp --
+			// which carries the amplitude and has no clamp of its own -- stays inside the normal numbers for any amplitude
+			// above 2^-150; a cancellation that leaves a tiny negative squared distance counts as zero)
+			const double u2 = fmin(fmax(acc[j][r], 0.0), KIND == GPEMU_POWEREXP ? 600.0 : 360000.0);
+			if (KIND == GPEMU_POWEREXP) {
+				wk[r][j] = W * fast_exp_neg_g(-u2, tab);                                   // amp in the table
+			} else {
+				const double u = fast_sqrt_g(u2);                                           // c * distance / rho
+				const double e = fast_exp_neg_g(-u, tab);
+				if (KIND == GPEMU_MATERN32) {
+					wk[r][j] = W * (u2 * e);                                                // amp c^2 s^2 e^{-cs}
+				} else {
+					const double c5 = 2.236067978, ic2 = 1.0 / (c5 * c5);
+					wk[r][j] = W * (e * u2 * fma((5.0 / 3.0) * ic2, u, 1.0 - (10.0 / 3.0) * ic2));   // amp (s^2 (c^2 - 10/3) + (5/3) c s^3) e^{-cs}
+				}
+			}
+			if (same & (1u << (4 * r + j))) s_nug += W * ps.nug;
+		}
+	}
+	// the nd + 1 sums of the tile (directions 0 .. nd-1, then the nugget), sixteen per reduction
+	for (int k0 = 0; k0 <= nd; k0 += 16) {
+		double out[16];
+#pragma unroll
+		for (int jd = 0; jd < 16; jd++) {
+			const int k = k0 + jd;
+			double sk = 0.0;
+			if (k == nd) {
+				sk = s_nug;
+			} else if (k < nd) {
+				if (KIND == GPEMU_POWEREXP) {
+					double xr4[4], xc4[4];
+#pragma unroll
+					for (int r = 0; r < 4; r++) xr4[r] = xr_t[k * 64 + row0 + 4 * r];
+#pragma unroll
+					for (int j = 0; j < 4; j++) xc4[j] = xc_t[k * 64 + col0 + 16 * j];
+#pragma unroll
+					for (int r = 0; r < 4; r++)
+#pragma unroll
+						for (int j = 0; j < 4; j++) {
+							const double D = xr4[r] - xc4[j];
+							sk = fma(wk[r][j], D * D, sk);
+						}
+					const double w = ps.w[k];
+					sk *= 2.0 * w * w;                                                      // D^2 e^{-2 theta_k} = 2 (D w_k)^2
+				} else {
+#pragma unroll
+					for (int r = 0; r < 4; r++)
+#pragma unroll
+						for (int j = 0; j < 4; j++) sk += wk[r][j];
+				}
+			}
+			out[jd] = sk;
+		}
+		const double tot = block_sum<16>(out, scratch);
+		const int k = k0 + (tid >> 4);
+		if ((tid & 15) == 0 && k <= nd) part[t * np + k] = tot;
+	}
+}
+
 // beta = (H^T C^-1 H)^-1 (H^T C^-1 y) of one batch element from its Gram matrix G = Z^T Z (res: Rp x Rp row-major, G[0][0]
 // = y.Cinv.y, G[1+a][0] = (H^T Cinv y)_a, G[1+a][1+b] = (H^T Cinv H)_ab -- what finish_kernel leaves in dRes), by a
 // Cholesky solve in LDS; written behind the element's alpha scratch, where gather_alpha_kernel expects it.  This is the
@@ -1249,7 +1452,7 @@ hipError_t launch_grad_reduce(hipStream_t s, const double *part, long pstride, i
 // of pstride doubles
 hipError_t launch_grad_partials(hipStream_t s, const double *S, long lds_, int soff, long sstride, int nb, const double *X, int N,
                                 int d, double *ag, int np_pad, long gstride, double *part, long pstride, int *nparts,
-                                int exact_kind, int nbeta, const CovParams *pp_dev, bool lit_noclamp)
+                                int exact_kind, int nbeta, const CovParams *pp_dev, bool lit_noclamp, const double *Xg)
 {
 	const int nt = (N + 63) / 64;
 	const int ntiles = nt * (nt + 1) / 2;
@@ -1262,6 +1465,27 @@ hipError_t launch_grad_partials(hipStream_t s, const double *S, long lds_, int s
 	auto allow = [](const void *fn, size_t bytes) {
 		return bytes <= 65536 ? hipSuccess : hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 	};
+	if (exact_kind && Xg) {
+		// exact form with the tile's distances from the matrix unit (grad_exact_gram_kernel)
+		hipError_t e = ensure_exp_table(s);
+		if (e != hipSuccess) return e;
+		const size_t lds_g = grad_gram_lds_doubles(d) * sizeof(double);
+		const void *fn = exact_kind == GPEMU_POWEREXP ? (const void *)grad_exact_gram_kernel<GPEMU_POWEREXP>
+		               : exact_kind == GPEMU_MATERN32 ? (const void *)grad_exact_gram_kernel<GPEMU_MATERN32>
+		                                              : (const void *)grad_exact_gram_kernel<GPEMU_MATERN52>;
+		e = allow(fn, lds_g);
+		if (e != hipSuccess) return e;
+		if (exact_kind == GPEMU_POWEREXP)
+			hipLaunchKernelGGL(grad_exact_gram_kernel<GPEMU_POWEREXP>, grid, dim3(256), lds_g, s, S, lds_, soff, sstride, X, Xg, N, d, ag,
+			                   gstride, part, pstride, pp_dev);
+		else if (exact_kind == GPEMU_MATERN32)
+			hipLaunchKernelGGL(grad_exact_gram_kernel<GPEMU_MATERN32>, grid, dim3(256), lds_g, s, S, lds_, soff, sstride, X, Xg, N, d, ag,
+			                   gstride, part, pstride, pp_dev);
+		else
+			hipLaunchKernelGGL(grad_exact_gram_kernel<GPEMU_MATERN52>, grid, dim3(256), lds_g, s, S, lds_, soff, sstride, X, Xg, N, d, ag,
+			                   gstride, part, pstride, pp_dev);
+		return hipGetLastError();
+	}
 	hipError_t ea = hipSuccess;
 	if (exact_kind == GPEMU_POWEREXP) ea = allow((const void *)grad_exact_kernel<GPEMU_POWEREXP>, lds_exact);
 	else if (exact_kind == GPEMU_MATERN32) ea = allow((const void *)grad_exact_kernel<GPEMU_MATERN32>, lds_exact);

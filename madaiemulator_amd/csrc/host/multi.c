@@ -428,9 +428,16 @@ multi_emulator *alloc_multi_emulator(multi_modelstruct *m)
 		for (int i = first; i < e->nr; i++)              /* every component whose slot sits on this device */
 			if (!done[i] && (pinned >= 0 || gpemu_host_slot_device(i) == dev)) { models[n] = m->pca_model_array[i]; which[n++] = i; done[i] = 1; }
 		gpemu_host_thread_device(dev);
-		for (int b0 = 0; b0 < n; b0 += 16) {               /* (workspace: 16 x (2 Np + 64) x Np x 8 bytes per call) */
-			const int nb = n - b0 < 16 ? n - b0 : 16;
-			gpemu_host_alloc_emulators(models + b0, nb, fill_cinverse, made + b0);
+		if (fill_cinverse) {
+			/* the reference's public emulator_struct.cinverse is wanted (library callers): every component is set up on its
+			 * own -- the explicit N x N inverse comes out of a component's OWN factorisation workspace, and downloading and
+			 * mirroring it dwarfs what a batch saves */
+			for (int k = 0; k < n; k++) made[k] = gpemu_host_alloc_emulator(models[k], 1);
+		} else {
+			for (int b0 = 0; b0 < n; b0 += 16) {           /* (workspace: 16 x (2 Np + 64) x Np x 8 bytes per call) */
+				const int nb = n - b0 < 16 ? n - b0 : 16;
+				gpemu_host_alloc_emulators(models + b0, nb, 0, made + b0);
+			}
 		}
 		for (int k = 0; k < n; k++) e->emu_struct_array[which[k]] = made[k];
 	}

@@ -174,7 +174,7 @@ def test_kvectors_with_clamp(gpu_ctx, kind):
 
 
 @pytest.mark.parametrize("kind", [1, 2, 3])
-@pytest.mark.parametrize("N,d,M", [(300, 8, 200), (130, 3, 77), (64, 1, 64)])
+@pytest.mark.parametrize("N,d,M", [(300, 8, 200), (130, 3, 77), (64, 1, 64), (200, 16, 70)])
 def test_kvectors_gram_form(gpu_ctx, kind, N, d, M):
     """a16 in the MFMA Gram form (cov_kvec_gram_kernel, the prediction sweep's k-vector fill since round 4) at length
     scales that admit it: queries inside the design's box, queries EQUAL to training points (the nugget rule of
@@ -190,6 +190,8 @@ def test_kvectors_gram_form(gpu_ctx, kind, N, d, M):
     Xq[5] = X[7] + 5e-11
     Xq[6] = X[9] + 3.0                       # outside: |x'|^2 > 16 for the default length scales
     Xq[7] = -20.0
+    Xq[8] = 30.0                             # (round 5: at d = 16 this squared scaled distance, 2.3e4, came back as NaN)
+    Xq[9] = 1.0e4
     Xq[M - 1] = X[0]
     Xq[40:44] = 1.0 + 0.5 * synth.queries(4, d, 8)     # a whole 16-row group of one wave mildly outside
     gpu_ctx.set_model(kind, 0, X, y)
@@ -202,6 +204,7 @@ def test_kvectors_gram_form(gpu_ctx, kind, N, d, M):
     nz = ref != 0.0
     assert np.max(np.abs(got[nz] - ref[nz]) / ref[nz]) < ELEM_RTOL
     assert np.all(got[7] == 0.0) or kind != 1           # twenty length scales away: below the clamp (pow-exp)
+    assert np.all(np.isfinite(got)) and np.all(got[8] == 0.0) and np.all(got[9] == 0.0)
 
 
 # ------------------------------------------------------------------ a7-a11: likelihood
@@ -1524,6 +1527,13 @@ def test_predict_setup_batch_is_the_per_component_call_bit_for_bit(kind, N, d, o
     ref.set_model(kind, order, X, Ys[1])
     ref.predict_setup(rot[1])
     assert np.array_equal(ctxs[1].predict(Xq)[0], ref.predict(Xq)[0])
+    if N <= 1100:
+        # the explicit inverse (emulator_struct.cinverse) of a context that was set up as a LATER component of a batch: its
+        # factorisation ran in the first context's workspace (round 5: reading its own, never allocated one was a GPU memory
+        # fault) -- the entry factors the component alone and gives the single call's matrix bit for bit; the prediction
+        # state is the same afterwards
+        assert np.array_equal(ctxs[1].cinverse(), ref.cinverse()) and np.array_equal(ctxs[0].cinverse().shape, (N, N))
+        assert np.array_equal(ctxs[1].predict(Xq)[0], ref.predict(Xq)[0])
     ref.close()
     flops = nr * 2.0 * (64 * ((N + 63) // 64)) ** 3 / 3.0
     print(f"predict_setup_batch kind={kind} N={N} d={d} nr={nr}: first {t_first * 1e3:.2f} ms, replay {t_again * 1e3:.2f} ms = "
