@@ -900,6 +900,34 @@ def test_n8192_c3_oracle_fixture_and_a_50000_query_call(gpu_ctx):
     assert np.max(np.abs(m3 - f["mean"][6:9])) < RTOL * max(1.0, np.abs(f["mean"]).max()) and np.max(np.abs(v3 - f["var"][6:9])) < RTOL * kappa
 
 
+@pytest.mark.parametrize("kind,d", [(1, 5), (1, 16), (3, 4), (2, 3)])
+def test_exact_gradient_tile_distances_from_the_matrix_unit_or_from_differences(monkeypatch, kind, d):
+    """grad_exact_gram_kernel (round 5: the tile's squared scaled distances from the fp64 MFMA on the centred design, at ANY
+    length scale -- the weights enter plain sums) against grad_exact_kernel (coordinate differences, GPEMU_GRAD_GRAM=0): the
+    same gradient to rounding, with length scales far below the Gram-form fill's bound (|x'|^2 of several hundred), a pair of
+    design points 3e-9 apart (a candidate of the nugget rule that fails the exact "same point" test in both; pairs that pass
+    it off the diagonal make the matrix singular by the reference's own rule) and a ragged N."""
+    N = 1000
+    X, y = synth.design(N, d, 404 + d)
+    X[17] = X[3] + 3e-9                  # a near-coincident pair: a nugget-rule candidate that fails the exact test
+    a, b = _ctx_with_env(monkeypatch, {"GPEMU_GRAD_GRAM": "1"}), _ctx_with_env(monkeypatch, {"GPEMU_GRAD_GRAM": "0"})
+    modes = abi.MODE_EXACT_GRAD | (abi.MODE_MATERN_LOG if kind != 1 else 0)
+    for c in (a, b):
+        c.set_model(kind, 1, X, y)
+        c.set_mode(modes)
+    nth = abi.nthetas_for(kind, d)
+    for scale in (0.6, 0.08, 0.02):
+        th = np.zeros(nth)
+        th[1] = -3.0
+        th[2:] = np.log(scale) + 0.1 * np.arange(nth - 2)
+        ths = np.array([th, th + 0.05])
+        ga, gb = a.loglik_grad_batch(ths), b.loglik_grad_batch(ths)
+        assert np.all(ga["status"] == 0) and np.array_equal(ga["value"], gb["value"])
+        big = np.max(np.abs(gb["grad"]), axis=1, keepdims=True)
+        assert np.all(np.isfinite(ga["grad"])) and np.max(np.abs(ga["grad"] - gb["grad"]) / big) < 1e-11, (scale, ga["grad"], gb["grad"])
+    a.close(); b.close()
+
+
 def test_exact_gradient_against_mpmath_golden_v3():
     """the corrected gradient forms (GPEMU_MODE_EXACT_GRAD, + GPEMU_MODE_MATERN_LOG for the Matern kernels) against an
     independent vector: the derivative of the 50-digit mpmath value, taken numerically there

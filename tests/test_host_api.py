@@ -1,6 +1,7 @@
 """The C host layer (csrc/host, libEmuMI.so) that mirrors the reference's libEmu interface and the
 interactive_emulator CLI, driven the way the reference's callers drive them; results checked against the oracle."""
 import os
+import re
 import subprocess
 import sys
 
@@ -658,13 +659,23 @@ def test_multi_output_training_over_device_slots_writes_the_same_snapshot(driver
     (alloc_multi_emulator: component c on slot c mod S) are the serial ones too."""
     cli = build.CLI_BIN
     snaps = {}
-    for name, devs in (("serial", "0"), ("two_slots", "0,0"), ("three_slots", "0,0,0")):
+    # ("serial": one slot, one component at a time, the reference's loop; "side_by_side": one slot, the slot's components
+    # trained by a pool of component threads at the same time -- round 5, the default; two components at a time; slots)
+    for name, devs, cps in (("serial", "0", "1"), ("side_by_side", "0", "0"), ("two_at_a_time", "0", "2"), ("two_slots", "0,0", "0"),
+                            ("three_slots", "0,0,0", "1")):
         snap = tmp_path / f"snap_{name}"
-        env = dict(os.environ, GPEMU_SEED="2024", GPEMU_RESTARTS="2", GPEMU_DEVICES=devs)
-        out = run([cli, "estimate_thetas", MULTI, str(snap), "--regression_order=1"], env=env)
+        env = dict(os.environ, GPEMU_SEED="2024", GPEMU_RESTARTS="2", GPEMU_DEVICES=devs, GPEMU_COMPONENTS_PER_SLOT=cps, GPEMU_SEARCH_STATS="1")
+        out = subprocess.run([cli, "estimate_thetas", MULTI, str(snap), "--regression_order=1"], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
         snaps[name] = snap.read_bytes()
         assert len(snaps[name]) > 1000
-    assert snaps["serial"] == snaps["two_slots"] == snaps["three_slots"]
+        # every search reports its OWN evaluations (they were process-wide counters before round 5): the same figures
+        # whatever ran beside it
+        stats = sorted(re.findall(r"# search stats: runs (\d+) threads \d+ groups \d+ slots \d+ value_grad_evals (\d+) value_evals (\d+) cached (\d+)", out.stderr))
+        assert len(stats) >= 2
+        snaps[name + "_stats"] = stats
+    assert snaps["serial"] == snaps["side_by_side"] == snaps["two_at_a_time"] == snaps["two_slots"] == snaps["three_slots"]
+    assert snaps["serial_stats"] == snaps["side_by_side_stats"] == snaps["two_slots_stats"]
     X, _ = synth.read_input_model_file(MULTI)
     qf = tmp_path / "q.dat"
     np.savetxt(qf, X[:7] + 0.01, fmt="%.17g")
