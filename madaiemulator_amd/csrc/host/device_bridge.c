@@ -817,7 +817,11 @@ static pthread_mutex_t g_warm_mu = PTHREAD_MUTEX_INITIALIZER;
 
 static void *warm_main(void *arg)
 {
-	(void)gpemu_warm_start((int)(long)arg);      /* (a failure here shows up again, with its message, at the first real call) */
+	/* (the device is looked up HERE: counting the devices is already a call into the HIP runtime and starts it -- on the
+	 * caller's thread that would be the very wait this thread exists to take off it.  A failure shows up again, with its
+	 * message, at the first real call.) */
+	(void)arg;
+	(void)gpemu_warm_start(gpemu_host_device());
 	return NULL;
 }
 
@@ -826,7 +830,7 @@ void gpemu_host_warm_start(void)
 	const char *e = getenv("GPEMU_WARM_START");
 	if (e && atoi(e) == 0) return;
 	pthread_mutex_lock(&g_warm_mu);
-	if (g_warm_state == 0 && pthread_create(&g_warm_thread, NULL, warm_main, (void *)(long)gpemu_host_device()) == 0) g_warm_state = 1;
+	if (g_warm_state == 0 && pthread_create(&g_warm_thread, NULL, warm_main, NULL) == 0) g_warm_state = 1;
 	pthread_mutex_unlock(&g_warm_mu);
 }
 

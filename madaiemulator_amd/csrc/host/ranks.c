@@ -125,6 +125,21 @@ static void drop_failed_marker(int status)
 	if (fd >= 0) close(fd);
 }
 
+/* a process that has ended but has not been reaped by its parent (a launcher that waits for its ranks one after the other)
+ * still answers kill(pid, 0): /proc says what it is */
+static int pid_is_zombie(long pid)
+{
+	char path[64], buf[512];
+	snprintf(path, sizeof path, "/proc/%ld/stat", pid);
+	FILE *f = fopen(path, "r");
+	if (!f) return 0;
+	const size_t n = fread(buf, 1, sizeof buf - 1, f);
+	fclose(f);
+	buf[n] = 0;
+	const char *p = strrchr(buf, ')');          /* "pid (comm) S ...": the state letter follows the LAST ')' */
+	return p && p[1] == ' ' && (p[2] == 'Z' || p[2] == 'X');
+}
+
 /* is any other rank of this run known to be gone?  (its marker, or -- same node -- its process) */
 static int a_peer_is_gone(int world, int me, int *which, const char **how)
 {
@@ -133,7 +148,7 @@ static int a_peer_is_gone(int world, int me, int *which, const char **how)
 		if (r == me) continue;
 		snprintf(path, sizeof path, "%s/failed_%s_%d", g_dir, g_run, r);
 		if (access(path, F_OK) == 0) { *which = r; *how = "ended with an error"; return 1; }
-		if (g_pid_check && g_peer_pid[r] > 0 && kill((pid_t)g_peer_pid[r], 0) != 0 && errno == ESRCH) {
+		if (g_pid_check && g_peer_pid[r] > 0 && ((kill((pid_t)g_peer_pid[r], 0) != 0 && errno == ESRCH) || pid_is_zombie(g_peer_pid[r]))) {
 			/* a rank that has finished its part leaves `left_<run>_<r>` before it goes: that exit is not a failure */
 			snprintf(path, sizeof path, "%s/left_%s_%d", g_dir, g_run, r);
 			if (access(path, F_OK) == 0) continue;

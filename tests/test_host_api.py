@@ -817,15 +817,17 @@ def test_ranks_do_not_wait_for_a_rank_that_is_gone(tmp_path, how):
     import time
     t0 = time.time()
     procs = _start_ranks(3, tmp_path, per_rank_env={1: {"TEST_AFTER_JOIN": how}})
-    so1, se1 = procs[1].communicate(timeout=60)                   # (reaped: a zombie's pid still answers kill(pid, 0))
-    assert procs[1].returncode == (1 if how == "fatal" else -9), se1
-    if how == "fatal":
-        assert "rank 1: boom" in se1
+    # (the survivors first: the killed rank stays an unreaped zombie of this test process meanwhile, as under a launcher that
+    # waits for its ranks one after the other -- its pid still answers kill(pid, 0), /proc tells)
     for r in (0, 2):
         so, se = procs[r].communicate(timeout=60)
         assert procs[r].returncode == 1, (r, so, se[-2000:])
         # (rank 1's end, or the end it caused in the other survivor: whichever marker the watchdog met first)
         assert f"rank {r}: rank " in se and "of this run" in se and "not waiting for it" in se, se
+    so1, se1 = procs[1].communicate(timeout=60)
+    assert procs[1].returncode == (1 if how == "fatal" else -9), se1
+    if how == "fatal":
+        assert "rank 1: boom" in se1
     assert time.time() - t0 < 30
 
 
@@ -888,6 +890,33 @@ def test_one_process_per_gpu_ranks_write_the_serial_snapshot(tmp_path):
         _run_ranks([cli, "estimate_thetas", str(f), "@SNAP@", "--regression_order=0"], world, rdv, base,
                    lambda r: tmp_path / f"one_w{world}_r{r}")
         assert (tmp_path / f"one_w{world}_r0").read_bytes() == serial.read_bytes()
+
+
+@pytest.mark.gpu
+def test_two_rccl_ranks_on_one_device_end_promptly_with_status_1(tmp_path):
+    """the RCCL transport of ranks.c as far as a one-GPU box can take it: two CLI ranks (GPEMU_GATHER unset) meet in the
+    start-up handshake, rank 0's ncclUniqueId travels in its `go` file, both call ncclCommInitRank -- which RCCL refuses for
+    two ranks on ONE device.  What must hold: no rank hangs in the rendezvous or in the communicator; both end within seconds
+    with status 1 and a message that names the call (fatal.c; a rank whose peer failed first is ended by the watchdog).
+    Between two physical GPUs the same path has never run."""
+    import time
+    procs = []
+    t0 = time.time()
+    for r in range(2):
+        env = dict(os.environ, GPEMU_RANK=str(r), GPEMU_WORLD_SIZE="2", GPEMU_RENDEZVOUS_DIR=str(tmp_path), GPEMU_DEVICES="0",
+                   GPEMU_SEED="3", GPEMU_RESTARTS="2")
+        env.pop("GPEMU_GATHER", None)
+        procs.append(subprocess.Popen([build.CLI_BIN, "estimate_thetas", MULTI, str(tmp_path / f"snap{r}"), "--regression_order=1"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    errs = []
+    for p in procs:
+        so, se = p.communicate(timeout=180)
+        assert p.returncode == 1, (p.returncode, se[-1500:])
+        errs.append(se)
+    assert time.time() - t0 < 120
+    assert any("ncclCommInitRank" in e for e in errs), errs
+    for r, e in enumerate(errs):
+        assert "ncclCommInitRank" in e or "not waiting for it" in e, (r, e[-1500:])
 
 
 @pytest.mark.gpu
