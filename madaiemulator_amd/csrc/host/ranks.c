@@ -74,14 +74,16 @@ int gpemu_host_rank(void)
 #define NONCE_LEN 48
 
 static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
-static int g_joined = 0;                    /* the handshake of this process has succeeded */
+static int g_joined = 0;                    /* the handshake of this process has succeeded (atomic: read by the watchdog, the exit hook) */
 static char g_dir[3072];
 static char g_run[NONCE_LEN];               /* rank 0's nonce: the name of this run */
 static long g_peer_pid[MAX_WORLD];
 static void *g_comm = NULL;                 /* RCCL communicator (transport rccl) */
 static int g_use_files = 0;
 static unsigned g_gather_seq = 0;
-static volatile int g_finished = 0;
+static int g_finished = 0;                  /* this rank's part in the run is over (atomic: set by the main thread, read by the watchdog) */
+#define LOAD(x) __atomic_load_n(&(x), __ATOMIC_ACQUIRE)
+#define STORE(x, v) __atomic_store_n(&(x), (v), __ATOMIC_RELEASE)
 static int g_pid_check = 1;                 /* GPEMU_RANK_PID_CHECK=0: the ranks do not share a pid namespace (containers) */
 
 static void sleep_ms(int ms) { struct timespec t = {ms / 1000, (long)(ms % 1000) * 1000000L}; nanosleep(&t, NULL); }
@@ -118,7 +120,7 @@ static long read_file(const char *path, void *data, size_t cap)
 static void drop_failed_marker(int status)
 {
 	(void)status;
-	if (!g_joined || g_finished) return;
+	if (!LOAD(g_joined) || LOAD(g_finished)) return;
 	char path[4200];
 	snprintf(path, sizeof path, "%s/failed_%s_%d", g_dir, g_run, gpemu_host_rank());
 	const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
@@ -165,10 +167,10 @@ static void *watchdog_main(void *arg)
 {
 	(void)arg;
 	const int world = gpemu_host_world_size(), me = gpemu_host_rank();
-	while (!g_finished) {
+	while (!LOAD(g_finished)) {
 		int which = -1;
 		const char *how = "";
-		if (a_peer_is_gone(world, me, &which, &how) && !g_finished)
+		if (a_peer_is_gone(world, me, &which, &how) && !LOAD(g_finished))
 			gpemu_host_fatal("rank %d: rank %d of this run %s -- not waiting for it (GPEMU_RENDEZVOUS_DIR %s, run %s)\n", me, which, how, g_dir, g_run);
 		sleep_ms(200);
 	}
@@ -179,7 +181,7 @@ static void *watchdog_main(void *arg)
 static void join_run(void)
 {
 	pthread_mutex_lock(&g_mu);
-	if (g_joined) { pthread_mutex_unlock(&g_mu); return; }
+	if (LOAD(g_joined)) { pthread_mutex_unlock(&g_mu); return; }
 	const int world = gpemu_host_world_size(), rank = gpemu_host_rank();
 	if (world > MAX_WORLD) gpemu_host_fatal("GPEMU_WORLD_SIZE %d: at most %d ranks (one per GPU of a node)\n", world, MAX_WORLD);
 	const char *dir = getenv("GPEMU_RENDEZVOUS_DIR");
@@ -242,8 +244,8 @@ static void join_run(void)
 		}
 	}
 	for (int r = 0; r < world; r++) g_peer_pid[r] = nonce_pid(go + (size_t)r * NONCE_LEN);
-	g_joined = 1;
 	g_pid_check = env_int("GPEMU_RANK_PID_CHECK", 1) != 0;
+	STORE(g_joined, 1);
 	gpemu_host_on_exit(drop_failed_marker);
 	atexit(gpemu_host_ranks_finish);             /* a caller that never says it has finished: a regular exit says it for it */
 	pthread_t wd;
@@ -311,11 +313,11 @@ void gpemu_host_allgather(const double *send, int count, double *recv)
  * that its exit is a regular one, rank 0 waits for the others to have said so and removes the run's files */
 void gpemu_host_ranks_finish(void)
 {
-	if (gpemu_host_world_size() <= 1 || !g_joined || g_finished) return;
+	if (gpemu_host_world_size() <= 1 || !LOAD(g_joined) || LOAD(g_finished)) return;
 	const int world = gpemu_host_world_size(), rank = gpemu_host_rank();
 	char path[4200];
 	if (g_comm) { gpemu_rccl_comm_destroy(g_comm); g_comm = NULL; }
-	if (rank != 0) g_finished = 1;                   /* (before the marker: rank 0 may be gone a moment after it appears) */
+	if (rank != 0) STORE(g_finished, 1);             /* (before the marker: rank 0 may be gone a moment after it appears) */
 	snprintf(path, sizeof path, "%s/left_%s_%d", g_dir, g_run, rank);
 	(void)write_file(path, "", 0);
 	if (rank == 0) {
@@ -323,7 +325,7 @@ void gpemu_host_ranks_finish(void)
 			snprintf(path, sizeof path, "%s/left_%s_%d", g_dir, g_run, r);
 			while (access(path, F_OK) != 0) sleep_ms(2);         /* (the watchdog still runs: a rank that dies here ends the wait) */
 		}
-		g_finished = 1;
+		STORE(g_finished, 1);
 		for (int r = 0; r < world; r++) {
 			snprintf(path, sizeof path, "%s/left_%s_%d", g_dir, g_run, r); unlink(path);
 			snprintf(path, sizeof path, "%s/ack_%s_%d", g_dir, g_run, r); unlink(path);
@@ -333,5 +335,5 @@ void gpemu_host_ranks_finish(void)
 		snprintf(path, sizeof path, "%s/run_id", g_dir);
 		if (read_file(path, cur, NONCE_LEN) == NONCE_LEN && !strncmp(cur, g_run, NONCE_LEN)) unlink(path);   /* (not a newer run's) */
 	}
-	g_finished = 1;
+	STORE(g_finished, 1);
 }
