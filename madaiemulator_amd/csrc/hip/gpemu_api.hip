@@ -161,6 +161,9 @@ static Sched read_environment()
 	sc.grad_gram = geti("GPEMU_GRAD_GRAM", 1) != 0;
 	sc.stagger_us = std::max(0, std::min(1000, geti("GPEMU_STAGGER_US", 20)));
 	sc.factor_ahead = geti("GPEMU_FACTOR_AHEAD", 1) != 0;
+	sc.diag_inv_ahead = geti("GPEMU_DIAG_INV_AHEAD", 1) != 0;
+	v = geti("GPEMU_LEAF_STAGED", -1);
+	sc.leaf_staged = v == 0 || v == 1 ? v : -1;
 	v = geti("GPEMU_NB_TOP", 0);
 	sc.nb_top = v >= LEAF ? (v / LEAF) * LEAF : 0;
 	sc.split_rhs_rows = geti("GPEMU_SPLIT_RHS_ROWS", 1) != 0;
@@ -546,7 +549,7 @@ static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv, bool diag_do
 		unsigned long long *trf = trace_slot(ctx, "leaf_factor c0=%d", c0);
 		unsigned long long *trs = trace_slot(ctx, "leaf_solve c0=%d m=%d", c0, row_end - (c0 + LEAF));
 		return launch_leaf(ctx->stream, ctx->dT, ld, c0, row_end - (c0 + LEAF), ctx->dInfo, trf, trs, ctx->nb,
-		                   (long)ctx->T_stride, diag_done);
+		                   (long)ctx->T_stride, diag_done, ctx->sched.leaf_staged, ctx->sched.diag_inv_ahead != 0);
 	}
 	// automatic outer panel width: a batch has enough tiles per launch to afford the longer panel chain of a wider
 	// panel and gains from the larger K of its trailing updates and the fewer read-modify-write passes over the

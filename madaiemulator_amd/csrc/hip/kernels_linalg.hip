@@ -64,6 +64,7 @@ constexpr int LP = LEAF + 2;
 template <int P, int LD> __device__ __forceinline__ void panel_factor(double *A, int lane, int &bad, int bad_off);
 template <int P, int LD> __device__ __forceinline__ void panel_update(double *A, int wave, int lane);
 __device__ __forceinline__ void tri_inverse16(double *M, int o, double *tile, int lane);
+__device__ __forceinline__ void diag_inverse_ahead(double *A, int blk, int lane, double *Dg, long ldg);
 
 // FA = 1 (factor-ahead, 64x64 tiles of a triangular trailing update): the workgroup of tile (0,0) -- the diagonal block
 // the NEXT leaf factorisation starts from -- does not store its updated tile: it keeps it in LDS, factors it there
@@ -392,16 +393,22 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_nt_kernel(GemmArgs 
 		__syncthreads();
 		panel_update<0, LP>(A, wave, lane);
 		__syncthreads();
+		// (diag_inverse_ahead: the inverse of a finished 16x16 diagonal block goes to the block's upper part in HBM, where
+		// the leaf solve finds it -- computed by a wave that would idle beside wave 0's next panel)
 		if (wave == 0) panel_factor<1, LP>(A, lane, bad, 0);
+		else if (wave == 1) diag_inverse_ahead(A, 0, lane, g.C, g.ldc);
 		__syncthreads();
 		panel_update<1, LP>(A, wave, lane);
 		__syncthreads();
 		if (wave == 0) panel_factor<2, LP>(A, lane, bad, 0);
+		else if (wave == 2) diag_inverse_ahead(A, 1, lane, g.C, g.ldc);
 		__syncthreads();
 		panel_update<2, LP>(A, wave, lane);
 		__syncthreads();
 		if (wave == 0) panel_factor<3, LP>(A, lane, bad, 0);
+		else if (wave == 3) diag_inverse_ahead(A, 2, lane, g.C, g.ldc);
 		__syncthreads();
+		if (wave == 1) diag_inverse_ahead(A, 3, lane, g.C, g.ldc);
 		if (tid == 0 && bad) atomicMin(g.fa_info + blockIdx.y, g.fa_c0 + bad);
 #pragma unroll
 		for (int u = 0; u < 16; u++) {
@@ -880,15 +887,19 @@ __global__ __launch_bounds__(256) void leaf_factor_kernel(double *T, long ld, in
 	__syncthreads();
 	if (trace && tr0.wall) atomicAdd(trace + 7, (unsigned long long)clock64() - tr0.clk);          // first update done
 	if (wave == 0) panel_factor<1, LP>(A, lane, bad, 0);
+	else if (wave == 1) diag_inverse_ahead(A, 0, lane, D, ld);
 	__syncthreads();
 	panel_update<1, LP>(A, wave, lane);
 	__syncthreads();
 	if (wave == 0) panel_factor<2, LP>(A, lane, bad, 0);
+	else if (wave == 2) diag_inverse_ahead(A, 1, lane, D, ld);
 	__syncthreads();
 	panel_update<2, LP>(A, wave, lane);
 	__syncthreads();
 	if (wave == 0) panel_factor<3, LP>(A, lane, bad, 0);
+	else if (wave == 3) diag_inverse_ahead(A, 2, lane, D, ld);
 	__syncthreads();
+	if (wave == 1) diag_inverse_ahead(A, 3, lane, D, ld);
 	if (tid == 0 && bad) atomicMin(info, c0 + bad);
 #pragma unroll
 	for (int u = 0; u < 16; u++) {
@@ -979,10 +990,38 @@ __device__ __forceinline__ void tri_inverse16(double *M, int o, double *tile, in
 	tri_inverse16_to<LP, LP>(M, o, tile, lane, M + o * LP + o, LP);
 }
 
+// Round 5: the four diagonal inverses of a factored 64x64 block are computed ONCE, by the workgroup that factors it (a
+// wave that would otherwise idle beside wave 0's next 16-column panel; only the last block's inverse is behind the last
+// panel), and parked in the strictly upper 16x16 blocks (0,1) (1,2) (2,3) (0,3) of the diagonal block in HBM -- nothing
+// reads the upper part of a factored diagonal block.  The leaf solve stages the whole 64x64 block anyway and finds them
+// there: in a lock-step batch every one of its workgroups used to repeat the inversion (two barriers and five dependent
+// matrix products before the first solve step: 17 % of the kernel, scratch/mb/leaf_variants.hip).  Same arithmetic on the
+// same inputs: same bits.  The LDS scratch is the same upper block of A, which the factorisation never touches.
+__device__ __forceinline__ int diag_inverse_block(int blk) { return blk == 3 ? 3 : (blk + 1) + 4 * blk; }   // (row, col) = (v >> 2, v & 3): (0,1) (1,2) (2,3) (0,3)
+__device__ __forceinline__ void diag_inverse_ahead(double *A, int blk, int lane, double *Dg, long ldg)
+{
+	const int v = diag_inverse_block(blk), sr = v >> 2, sc = v & 3;
+	tri_inverse16_to<LP, LP>(A, 16 * blk, A + 16 * sr * LP + 16 * sc, lane, Dg + (long)(16 * sr) * ldg + 16 * sc, (int)ldg);
+}
+
+// STAGED = false: lane (q, g) reads and writes its 16 elements of panel row q one double at a time (16 wave-instructions of
+//   16 rows x 32 bytes each way) -- the shortest path for ONE matrix, where the kernel is latency-bound (5.5 us).
+// STAGED = true (round 5): the wave's 16 x 64 tile crosses HBM in whole 512-byte row pieces (16 bytes per lane, two rows
+//   per wave-instruction) and changes into the matrix unit's D/B layout through a wave-private LDS strip, LEAF_SROWS rows at
+//   a time.  In a lock-step batch the kernel is bound by the read-modify-write of the block column, and the access SHAPE
+//   sets the rate: scratch/mb/ld_stride.hip measures 3.5 TB/s for the 32-byte pieces against 5.2 TB/s for whole row pieces
+//   at N = 4096, B = 64 (3.0 against 3.9 at N = 8192, B = 16); the kernel itself ran at 3.6 TB/s.  Same arithmetic, same
+//   bits.  LDS: 33 KB for L + 4 x 4.25 KB strips = 50 KB, three workgroups per CU.
+constexpr int LEAF_SROWS = 8;                 // rows of the tile in the strip at a time
+constexpr int LEAF_SPITCH = 512 + 32;         // bytes between strip rows: 8 rows x 4 lane groups x 8 bytes hit 64 different banks
+// DBG (scratch/mb/leaf_variants.hip only; the product instantiates 0): bit 0 skips the diagonal inverses, bit 1 the chain
+// PRE = true: the diagonal inverses come with the staged block (diag_inverse_ahead); false: every workgroup computes them (A/B switch)
+template <bool STAGED, bool PRE = true, int DBG = 0>
 __global__ __launch_bounds__(256) void leaf_solve_kernel(double *T, long ld, int c0, int m_below, unsigned long long *trace, long bstride)
 {
 	T += (long)blockIdx.y * bstride;
 	__shared__ double M[LEAF * LP];        // L; diagonal 16x16 blocks replaced by their inverses
+	__shared__ __attribute__((aligned(16))) char strip_all[STAGED ? 4 * LEAF_SROWS * LEAF_SPITCH : 16];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int g = lane >> 4, q = lane & 15;
 	const TraceT0 tr0 = trace_begin(trace);
@@ -994,10 +1033,23 @@ __global__ __launch_bounds__(256) void leaf_solve_kernel(double *T, long ld, int
 	if (!valid) prow = m_below - 1;
 	double *bp = T + (long)(c0 + LEAF + prow) * ld + c0;
 	d4_t R[4];
+	// STAGED: lane l moves doubles 2 (l & 31), + 1 of tile rows 2 u + (l >> 5), u = 0 .. 7
+	d2_t in[8];
+	char *strip = strip_all + (STAGED ? wave * LEAF_SROWS * LEAF_SPITCH : 0);
+	const int crow = lane >> 5, ccol = 2 * (lane & 31);
+	if (STAGED) {
 #pragma unroll
-	for (int j = 0; j < 4; j++)
+		for (int u = 0; u < 8; u++) {
+			int r = prow0 + 2 * u + crow;
+			if (r > m_below - 1) r = m_below - 1;
+			in[u] = *reinterpret_cast<const d2_t *>(T + (long)(c0 + LEAF + r) * ld + c0 + ccol);
+		}
+	} else {
 #pragma unroll
-		for (int r = 0; r < 4; r++) R[j][r] = bp[16 * j + g + 4 * r];
+		for (int j = 0; j < 4; j++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) R[j][r] = bp[16 * j + g + 4 * r];
+	}
 	{
 		const double *D = T + (long)c0 * ld + c0;
 		double v[16];
@@ -1006,11 +1058,30 @@ __global__ __launch_bounds__(256) void leaf_solve_kernel(double *T, long ld, int
 #pragma unroll
 		for (int u = 0; u < 16; u++) M[(wave + 4 * u) * LP + lane] = v[u];
 	}
-	__syncthreads();
-	{
+	if (!PRE) {
+		__syncthreads();
 		// wave w inverts diagonal block w; scratch = an upper block of M: (0,1) (1,2) (2,3) (0,3)
 		const int sr = (wave == 3) ? 0 : wave, sc = (wave == 3) ? 3 : wave + 1;
-		tri_inverse16(M, 16 * wave, M + 16 * sr * LP + 16 * sc, lane);
+		if (!(DBG & 1)) tri_inverse16(M, 16 * wave, M + 16 * sr * LP + 16 * sc, lane);
+	}
+	if (STAGED) {
+		// rows 0 .. 7 of the tile through the strip into the lanes with q < 8, then rows 8 .. 15 into the others (the strip
+		// is this wave's alone and a wave's LDS operations execute in order: no barrier)
+#pragma unroll
+		for (int h = 0; h < 16 / LEAF_SROWS; h++) {
+#pragma unroll
+			for (int u = 0; u < LEAF_SROWS / 2; u++)
+				*reinterpret_cast<d2_t *>(strip + (2 * u + crow) * LEAF_SPITCH + 8 * ccol) = in[h * (LEAF_SROWS / 2) + u];
+			asm volatile("" ::: "memory");            // (the strip is written as 16-byte pieces and read as doubles)
+			if ((q / LEAF_SROWS) == h) {
+				const char *sp = strip + (q % LEAF_SROWS) * LEAF_SPITCH + 8 * g;
+#pragma unroll
+				for (int j = 0; j < 4; j++)
+#pragma unroll
+					for (int r = 0; r < 4; r++) R[j][r] = *reinterpret_cast<const double *>(sp + 8 * (16 * j + 4 * r));
+			}
+			asm volatile("" ::: "memory");
+		}
 	}
 	__syncthreads();
 	if (prow0 >= m_below) return;
@@ -1018,23 +1089,48 @@ __global__ __launch_bounds__(256) void leaf_solve_kernel(double *T, long ld, int
 #pragma unroll
 	for (int j = 0; j < 4; j++) {
 		d4_t acc = R[j];
+		d4_t xj = {0.0, 0.0, 0.0, 0.0};
+		if (DBG & 2) xj = acc * M[q * LP + g];
+		else {
 #pragma unroll
-		for (int i = 0; i < j; i++)
+			for (int i = 0; i < j; i++)
+#pragma unroll
+				for (int r = 0; r < 4; r++) {
+					const double a = -M[(16 * j + q) * LP + 16 * i + g + 4 * r];
+					acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[i][r], acc, 0, 0, 0);
+				}
 #pragma unroll
 			for (int r = 0; r < 4; r++) {
-				const double a = -M[(16 * j + q) * LP + 16 * i + g + 4 * r];
-				acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[i][r], acc, 0, 0, 0);
+				constexpr int dv = PRE ? 1 : 0;           // PRE: block j's inverse sits in the upper block diag_inverse_block(j)
+				const int ir = dv ? (j == 3 ? 0 : j) : j, ic = dv ? (j == 3 ? 3 : j + 1) : j;
+				const double a = M[(16 * ir + q) * LP + 16 * ic + g + 4 * r];
+				xj = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[r], xj, 0, 0, 0);
 			}
-		d4_t xj = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-		for (int r = 0; r < 4; r++) {
-			const double a = M[(16 * j + q) * LP + 16 * j + g + 4 * r];
-			xj = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[r], xj, 0, 0, 0);
 		}
 		X[j] = xj;
-		if (valid) {
+		if (!STAGED && valid) {
 #pragma unroll
 			for (int r = 0; r < 4; r++) bp[16 * j + g + 4 * r] = xj[r];
+		}
+	}
+	if (STAGED) {
+#pragma unroll
+		for (int h = 0; h < 16 / LEAF_SROWS; h++) {
+			if ((q / LEAF_SROWS) == h) {
+				char *sp = strip + (q % LEAF_SROWS) * LEAF_SPITCH + 8 * g;
+#pragma unroll
+				for (int j = 0; j < 4; j++)
+#pragma unroll
+					for (int r = 0; r < 4; r++) *reinterpret_cast<double *>(sp + 8 * (16 * j + 4 * r)) = X[j][r];
+			}
+			asm volatile("" ::: "memory");
+#pragma unroll
+			for (int u = 0; u < LEAF_SROWS / 2; u++) {
+				const d2_t v = *reinterpret_cast<const d2_t *>(strip + (2 * u + crow) * LEAF_SPITCH + 8 * ccol);
+				const int r = prow0 + h * LEAF_SROWS + 2 * u + crow;
+				if (r < m_below) *reinterpret_cast<d2_t *>(T + (long)(c0 + LEAF + r) * ld + c0 + ccol) = v;
+			}
+			asm volatile("" ::: "memory");
 		}
 	}
 	trace_end(trace, tr0);
@@ -1042,14 +1138,21 @@ __global__ __launch_bounds__(256) void leaf_solve_kernel(double *T, long ld, int
 
 
 hipError_t launch_leaf(hipStream_t s, double *T, long ld, int c0, int m_below, int *info, unsigned long long *trf,
-                       unsigned long long *trs, int nbatch, long bstride, bool skip_factor)
+                       unsigned long long *trs, int nbatch, long bstride, bool skip_factor, int staged, bool pre)
 {
 	if (nbatch < 1) nbatch = 1;
 	if (!skip_factor)                    // (skipped: the diagonal block was factored by the update before, factor-ahead)
 		hipLaunchKernelGGL(leaf_factor_kernel, dim3(1, nbatch), dim3(256), 0, s, T, ld, c0, info, trf, bstride);
-	if (m_below > 0)
-		hipLaunchKernelGGL(leaf_solve_kernel, dim3((m_below + 63) / 64, nbatch), dim3(256), 0, s, T, ld, c0, m_below,
-		                   trs, bstride);
+	if (m_below > 0) {
+		const dim3 grid((m_below + 63) / 64, nbatch);
+		// staged rows pay once the launch is bound by the block column's traffic (a lock-step batch: more workgroups than
+		// the chip holds at once); one matrix is latency-bound and keeps the direct form (staged < 0: automatic)
+		const bool st = staged < 0 ? (long)grid.x * grid.y >= 1024 : staged != 0;
+		if (st && pre) hipLaunchKernelGGL((leaf_solve_kernel<true, true>), grid, dim3(256), 0, s, T, ld, c0, m_below, trs, bstride);
+		else if (st) hipLaunchKernelGGL((leaf_solve_kernel<true, false>), grid, dim3(256), 0, s, T, ld, c0, m_below, trs, bstride);
+		else if (pre) hipLaunchKernelGGL((leaf_solve_kernel<false, true>), grid, dim3(256), 0, s, T, ld, c0, m_below, trs, bstride);
+		else hipLaunchKernelGGL((leaf_solve_kernel<false, false>), grid, dim3(256), 0, s, T, ld, c0, m_below, trs, bstride);
+	}
 	return hipGetLastError();
 }
 

@@ -1317,7 +1317,10 @@ def _schedule_run(monkeypatch, env):
                                  {"GPEMU_KVEC_GRAM": "0"}, {"GPEMU_IDLE_WAVES": "0"}, {"GPEMU_IDLE_WAVES": "0", "GPEMU_GEMM_BIG_TILES": "1"},
                                  {"GPEMU_GEMV_POINT": "0"}, {"GPEMU_STAGGER_US": "0", "GPEMU_GEMM_BIG_TILES": "1"},
                                  {"GPEMU_STAGGER_US": "200", "GPEMU_GEMM_BIG_TILES": "1"}, {"GPEMU_NEG_MODIFIER": "0"},
-                                 {"GPEMU_NEG_MODIFIER": "0", "GPEMU_GEMM_BIG_TILES": "1"}])
+                                 {"GPEMU_NEG_MODIFIER": "0", "GPEMU_GEMM_BIG_TILES": "1"},
+                                 {"GPEMU_LEAF_STAGED": "1"}, {"GPEMU_LEAF_STAGED": "0"}, {"GPEMU_DIAG_INV_AHEAD": "0"},
+                                 {"GPEMU_DIAG_INV_AHEAD": "0", "GPEMU_LEAF_STAGED": "1"},
+                                 {"GPEMU_LEAF_STAGED": "1", "GPEMU_FACTOR_AHEAD": "0"}])
 def test_schedule_switches_keep_parity(monkeypatch, env):
     """the measurement switches of INTEGRATION.md (factor-ahead, panel widths, tile shapes, tile order, no graph, the form
     of the prediction sweep's k-vector fill) change the
