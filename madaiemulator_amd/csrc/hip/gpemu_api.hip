@@ -162,6 +162,7 @@ static Sched read_environment()
 	sc.stagger_us = std::max(0, std::min(1000, geti("GPEMU_STAGGER_US", 20)));
 	sc.factor_ahead = geti("GPEMU_FACTOR_AHEAD", 1) != 0;
 	sc.diag_inv_ahead = geti("GPEMU_DIAG_INV_AHEAD", 1) != 0;
+	sc.leaf_pair = geti("GPEMU_LEAF_PAIR", 1) != 0;
 	v = geti("GPEMU_LEAF_STAGED", -1);
 	sc.leaf_staged = v == 0 || v == 1 ? v : -1;
 	v = geti("GPEMU_NB_TOP", 0);
@@ -539,7 +540,9 @@ static hipError_t trailing_update(gpemu_ctx *ctx, int c0, int k, int ncols, int 
 }
 
 // diag_done: the 64x64 diagonal block at (c0,c0) is already factored (by the factor-ahead tile of the update before)
-static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv, bool diag_done = false)
+// defer_c0 >= 0: the leaf solve of this block also solves, in place, the 64 rows under the diagonal block at defer_c0 (the
+// pair's first block, which leaf_pair_kernel leaves untouched there)
+static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv, bool diag_done = false, int defer_c0 = -1)
 {
 	const long ld = ctx->Np;
 	const int base_end = ctx->Np + ctx->Rp;
@@ -549,7 +552,24 @@ static hipError_t potrf_rec(gpemu_ctx *ctx, int c0, int n, int inv, bool diag_do
 		unsigned long long *trf = trace_slot(ctx, "leaf_factor c0=%d", c0);
 		unsigned long long *trs = trace_slot(ctx, "leaf_solve c0=%d m=%d", c0, row_end - (c0 + LEAF));
 		return launch_leaf(ctx->stream, ctx->dT, ld, c0, row_end - (c0 + LEAF), ctx->dInfo, trf, trs, ctx->nb,
-		                   (long)ctx->T_stride, diag_done, ctx->sched.leaf_staged, ctx->sched.diag_inv_ahead != 0);
+		                   (long)ctx->T_stride, diag_done, ctx->sched.leaf_staged, ctx->sched.diag_inv_ahead != 0, defer_c0);
+	}
+	if (n == 2 * LEAF && ctx->sched.leaf_pair && ctx->sched.diag_inv_ahead) {
+		// a 128-column pair: [factor the first diagonal block,] leaf_pair_kernel (solve of the first block + K=64 update with
+		// its factor-ahead tile), then the second block's leaf solve with the deferred 64 rows of the first
+		const int row_end = base_end + (inv ? c0 + LEAF : 0);
+		const int m_below = row_end - (c0 + LEAF);
+		ProfScope ps(ctx, GPEMU_PROF_LEAF, 0.0, 0.0);
+		if (!diag_done) {
+			unsigned long long *trf = trace_slot(ctx, "leaf_factor c0=%d", c0);
+			hipError_t e = launch_leaf(ctx->stream, ctx->dT, ld, c0, 0, ctx->dInfo, trf, nullptr, ctx->nb, (long)ctx->T_stride, false);
+			if (e != hipSuccess) return e;
+		}
+		unsigned long long *trp = trace_slot(ctx, "leaf_pair c0=%d m=%d", c0, m_below);
+		const bool fa = ctx->sched.factor_ahead != 0;
+		hipError_t e = launch_leaf_pair(ctx->stream, ctx->dT, ld, c0, m_below, ctx->dInfo, trp, ctx->nb, (long)ctx->T_stride, fa);
+		if (e != hipSuccess) return e;
+		return potrf_rec(ctx, c0 + LEAF, LEAF, inv, fa, c0);
 	}
 	// automatic outer panel width: a batch has enough tiles per launch to afford the longer panel chain of a wider
 	// panel and gains from the larger K of its trailing updates and the fewer read-modify-write passes over the

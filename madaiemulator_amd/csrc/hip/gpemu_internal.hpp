@@ -92,6 +92,7 @@ struct Sched {
 	int grad_gram = 1;           // GPEMU_GRAD_GRAM: the exact gradient's tile distances from the matrix unit (grad_exact_gram_kernel)
 	int leaf_staged = -1;        // GPEMU_LEAF_STAGED: the leaf solve moves whole 512-byte row pieces through an LDS strip (1), element-wise (0), automatic by launch size (-1)
 	int diag_inv_ahead = 1;      // GPEMU_DIAG_INV_AHEAD: the leaf solve takes the 16x16 diagonal inverses the factoring workgroup left in the block's upper part (0: every workgroup computes them)
+	int leaf_pair = 1;           // GPEMU_LEAF_PAIR: first block of a 128-column pair in one launch (leaf solve + K=64 update, leaf_pair_kernel); 0: two launches
 	int stagger_us = 20;         // GPEMU_STAGGER_US: first-round offset between the two workgroups of a CU in the 128x128 GEMM (0 = none)
 };
 
@@ -250,7 +251,9 @@ hipError_t launch_gemv_tri(hipStream_t s, const double *Kq, long ldk, const doub
 std::vector<int> build_tile_table(int tiles_m, int tiles_n, int tri, int S, int bm = 128, int bn = 128);
 hipError_t launch_leaf(hipStream_t s, double *T, long ld, int c0, int m_below, int *info,
                        unsigned long long *trace_factor = nullptr, unsigned long long *trace_solve = nullptr,
-                       int nbatch = 1, long bstride = 0, bool skip_factor = false, int staged = -1, bool pre = true);
+                       int nbatch = 1, long bstride = 0, bool skip_factor = false, int staged = -1, bool pre = true, int c0b = -1);
+hipError_t launch_leaf_pair(hipStream_t s, double *T, long ld, int c0, int m_below, int *info, unsigned long long *trace, int nbatch,
+                            long bstride, bool fa);
 bool gemm_factor_ahead_ok(const GemmArgs &a);
 bool gemm_uses_big_tiles(const GemmArgs &a);
 hipError_t launch_gram_partials(hipStream_t s, const double *Z, long ld, int Np, int nrhs, int Rp, double *part,

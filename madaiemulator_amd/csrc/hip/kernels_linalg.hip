@@ -1016,10 +1016,14 @@ constexpr int LEAF_SROWS = 8;                 // rows of the tile in the strip a
 constexpr int LEAF_SPITCH = 512 + 32;         // bytes between strip rows: 8 rows x 4 lane groups x 8 bytes hit 64 different banks
 // DBG (scratch/mb/leaf_variants.hip only; the product instantiates 0): bit 0 skips the diagonal inverses, bit 1 the chain
 // PRE = true: the diagonal inverses come with the staged block (diag_inverse_ahead); false: every workgroup computes them (A/B switch)
+// c0b >= 0: the LAST workgroup of the launch has another job -- the 64 rows under the diagonal block at c0b (the sub-diagonal
+// block of a pair that leaf_pair_kernel left unsolved in place, see there)
 template <bool STAGED, bool PRE = true, int DBG = 0>
-__global__ __launch_bounds__(256) void leaf_solve_kernel(double *T, long ld, int c0, int m_below, unsigned long long *trace, long bstride)
+__global__ __launch_bounds__(256) void leaf_solve_kernel(double *T, long ld, int c0, int m_below, unsigned long long *trace, long bstride, int c0b)
 {
 	T += (long)blockIdx.y * bstride;
+	int bx = blockIdx.x;
+	if (c0b >= 0 && bx == (int)gridDim.x - 1) { bx = 0; c0 = c0b; m_below = LEAF; }
 	__shared__ double M[LEAF * LP];        // L; diagonal 16x16 blocks replaced by their inverses
 	__shared__ __attribute__((aligned(16))) char strip_all[STAGED ? 4 * LEAF_SROWS * LEAF_SPITCH : 16];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1027,7 +1031,7 @@ __global__ __launch_bounds__(256) void leaf_solve_kernel(double *T, long ld, int
 	const TraceT0 tr0 = trace_begin(trace);
 	// this wave's 16 panel rows: all 16 values per lane requested up front (one memory latency, overlapped
 	// with staging L and inverting the diagonal blocks)
-	const int prow0 = (blockIdx.x * 4 + wave) * 16;
+	const int prow0 = (bx * 4 + wave) * 16;
 	int prow = prow0 + q;
 	const bool valid = prow < m_below;
 	if (!valid) prow = m_below - 1;
@@ -1137,21 +1141,249 @@ __global__ __launch_bounds__(256) void leaf_solve_kernel(double *T, long ld, int
 }
 
 
+// ---------------------------------------------------------------------------
+// leaf_pair_kernel (round 5): the FIRST block of a 128-column pair in one launch -- the leaf solve of columns [c0, c0+64)
+// and the K=64 update of columns [c0+64, c0+128) for the same rows (with its factor-ahead tile) -- so that the solved
+// block X1 goes from the solve to the update in registers / LDS instead of through HBM: 4 passes over 64-column pieces
+// of the block column (read B1, write X1, read and write C2) where the two launches made 5, and one launch less on the
+// chain of ONE matrix.  Workgroup b takes rows 64 b .. 64 b + 63 under the diagonal block (wave w: 16 of them).
+// The update needs L21 = X1 of the FIRST 64 rows as its B operand: every workgroup solves those rows again for itself
+// (wave w rows 16 w .. 16 w + 15; a second chain beside its own), which is only right while nobody has overwritten them --
+// so workgroup 0 does NOT store its X1 here; the next launch of the stream (the leaf solve of the pair's second block)
+// carries one extra workgroup that solves and stores those 64 rows in place (leaf_solve_kernel, c0b).  Nothing between
+// the two reads that block: every later update takes its operand rows from below the pair.
+// Bits: the solve is leaf_solve_kernel's chain; the update feeds the matrix unit what gemm_nt_kernel feeds it -- per
+// accumulator the chunks of 16 in order, inside a chunk k = 8 t + 2 g + h for (t, h) = (0,0) (0,1) (1,0) (1,1) in lane
+// group g, A negated by the instruction -- so the result equals the two launches' bit for bit
+// (test_schedule_switches_keep_parity, GPEMU_LEAF_PAIR=0).
+// LDS: 33 KB (L with the diagonal inverses; then the image of L21; then, in workgroup 0, the tile being factored) + four
+// 4.25 KB strips.
+// ---------------------------------------------------------------------------
+// coalesced pieces (lane: doubles ccol, ccol + 1 of tile rows 2 u + crow) -> the matrix unit's B/D layout (lane (q, g):
+// row q, doubles 16 j + g + 4 r) through the wave's strip, LEAF_SROWS rows at a time
+__device__ __forceinline__ void strip_rows_to_tile(char *strip, const d2_t (&in)[8], int lane, d4_t (&R)[4])
+{
+	const int g = lane >> 4, q = lane & 15, crow = lane >> 5, ccol = 2 * (lane & 31);
+#pragma unroll
+	for (int h = 0; h < 16 / LEAF_SROWS; h++) {
+#pragma unroll
+		for (int u = 0; u < LEAF_SROWS / 2; u++)
+			*reinterpret_cast<d2_t *>(strip + (2 * u + crow) * LEAF_SPITCH + 8 * ccol) = in[h * (LEAF_SROWS / 2) + u];
+		asm volatile("" ::: "memory");
+		if ((q / LEAF_SROWS) == h) {
+			const char *sp = strip + (q % LEAF_SROWS) * LEAF_SPITCH + 8 * g;
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+#pragma unroll
+				for (int r = 0; r < 4; r++) R[j][r] = *reinterpret_cast<const double *>(sp + 8 * (16 * j + 4 * r));
+		}
+		asm volatile("" ::: "memory");
+	}
+}
+// the leaf solve's chain for one 16-row tile: X_j^T = Linv_jj (B_j^T - sum_{i<j} L_ji X_i^T); M holds L with the inverses of
+// its diagonal 16x16 blocks in the upper blocks diag_inverse_block(j)
+__device__ __forceinline__ void leaf_chain(const d4_t (&R)[4], const double *M, int lane, d4_t (&X)[4])
+{
+	const int g = lane >> 4, q = lane & 15;
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		d4_t acc = R[j];
+#pragma unroll
+		for (int i = 0; i < j; i++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) {
+				const double a = -M[(16 * j + q) * LP + 16 * i + g + 4 * r];
+				acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[i][r], acc, 0, 0, 0);
+			}
+		d4_t xj = {0.0, 0.0, 0.0, 0.0};
+		const int ir = j == 3 ? 0 : j, ic = j == 3 ? 3 : j + 1;
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			const double a = M[(16 * ir + q) * LP + 16 * ic + g + 4 * r];
+			xj = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[r], xj, 0, 0, 0);
+		}
+		X[j] = xj;
+	}
+}
+
+__global__ __launch_bounds__(256, 3) void leaf_pair_kernel(double *T, long ld, int c0, int m_below, int *info, unsigned long long *trace,
+                                                        long bstride, int fa)
+{
+	T += (long)blockIdx.y * bstride;
+	__shared__ __attribute__((aligned(16))) double M[LEAF * LP];
+	__shared__ __attribute__((aligned(16))) char strip_all[4 * LEAF_SROWS * LEAF_SPITCH];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int g = lane >> 4, q = lane & 15, crow = lane >> 5, ccol = 2 * (lane & 31);
+	const int b = blockIdx.x;
+	const TraceT0 tr0 = trace_begin(trace);
+		double *rows = T + (long)(c0 + LEAF) * ld + c0;          // first row under the diagonal block, column c0
+	// (m_below is a multiple of 64 -- launch_leaf_pair refuses anything else -- so every row of every workgroup exists; the
+	// wave index through readfirstlane: row bases in scalar registers, ONE lane offset per access shape instead of a 64-bit
+	// address per row -- the kernel has to stay under 168 vector registers for three workgroups per CU)
+	const int uw = __builtin_amdgcn_readfirstlane(wave);
+	char *strip = strip_all + uw * LEAF_SROWS * LEAF_SPITCH;
+	const int prow0 = (b * 4 + uw) * 16;
+	double *wrow = rows + (long)prow0 * ld;                  // the wave's first row (scalar)
+	const unsigned voff = (unsigned)(crow * ld + ccol);      // lane offset of the coalesced shape: row crow of a row pair, doubles ccol, ccol + 1
+	// everything this workgroup reads from HBM before the update, requested up front: its wave's share of the first 64
+	// rows, its rows of block 1, L
+	d2_t in[8], in0[8];
+	if (b != 0) {
+		const double *w0 = rows + (long)(16 * uw) * ld;
+#pragma unroll
+		for (int u = 0; u < 8; u++) in0[u] = *reinterpret_cast<const d2_t *>(w0 + (long)(2 * u) * ld + voff);
+	}
+#pragma unroll
+	for (int u = 0; u < 8; u++) in[u] = *reinterpret_cast<const d2_t *>(wrow + (long)(2 * u) * ld + voff);
+	// the wave's rows of block 2: the update's accumulators start from them.  Requested up front as well: a workgroup's
+	// life under load is its memory latency, and what it has in flight while it computes is what keeps HBM busy
+	d4_t acc[4];
+	const unsigned coff = (unsigned)(g * ld + LEAF + q);    // lane offset of the accumulator shape: row g of a row quad, column 64 + q
+#pragma unroll
+	for (int r = 0; r < 4; r++)
+#pragma unroll
+		for (int j = 0; j < 4; j++) acc[j][r] = (wrow + (long)(4 * r) * ld + coff)[16 * j];
+	{
+		const double *D = T + (long)c0 * ld + c0;
+		double v[16];
+#pragma unroll
+		for (int u = 0; u < 16; u++) v[u] = D[(long)(uw + 4 * u) * ld + lane];
+#pragma unroll
+		for (int u = 0; u < 16; u++) M[(uw + 4 * u) * LP + lane] = v[u];
+	}
+	__syncthreads();
+	d4_t X[4], X0[4];
+	if (b != 0) {
+		d4_t R0[4];
+		strip_rows_to_tile(strip, in0, lane, R0);
+		leaf_chain(R0, M, lane, X0);
+	}
+	{
+		d4_t R[4];
+		strip_rows_to_tile(strip, in, lane, R);
+		leaf_chain(R, M, lane, X);
+	}
+	if (b == 0) {
+#pragma unroll
+		for (int j = 0; j < 4; j++) X0[j] = X[j];
+	}
+	// X1 of the wave's rows: through the strip to HBM in whole row pieces (not workgroup 0, see above), and from the strip
+	// into the update's A fragments: af[2 c + t] = doubles 16 c + 8 t + 2 g, + 1 of row q (chunk c of 16, half t)
+	d2_t af[8];
+#pragma unroll
+	for (int h = 0; h < 16 / LEAF_SROWS; h++) {
+		if ((q / LEAF_SROWS) == h) {
+			char *sp = strip + (q % LEAF_SROWS) * LEAF_SPITCH + 8 * g;
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+#pragma unroll
+				for (int r = 0; r < 4; r++) *reinterpret_cast<double *>(sp + 8 * (16 * j + 4 * r)) = X[j][r];
+		}
+		asm volatile("" ::: "memory");
+#pragma unroll
+		for (int u = 0; u < LEAF_SROWS / 2; u++) {
+			const d2_t v = *reinterpret_cast<const d2_t *>(strip + (2 * u + crow) * LEAF_SPITCH + 8 * ccol);
+			if (b != 0) *reinterpret_cast<d2_t *>(wrow + (long)(h * LEAF_SROWS + 2 * u) * ld + voff) = v;
+		}
+		if ((q / LEAF_SROWS) == h) {
+			const char *sp = strip + (q % LEAF_SROWS) * LEAF_SPITCH + 16 * g;
+#pragma unroll
+			for (int c = 0; c < 4; c++)
+#pragma unroll
+				for (int t = 0; t < 2; t++) af[2 * c + t] = *reinterpret_cast<const d2_t *>(sp + 8 * (16 * c + 8 * t));
+		}
+		asm volatile("" ::: "memory");
+	}
+	__syncthreads();                       // every wave is past its last read of L
+	// the image of L21 = X1 of the first 64 rows, row-major over M
+#pragma unroll
+	for (int j = 0; j < 4; j++)
+#pragma unroll
+		for (int r = 0; r < 4; r++) M[(16 * uw + q) * LP + 16 * j + g + 4 * r] = X0[j][r];
+	__syncthreads();
+	// C2 - X1 L21^T: B fragment of lane (q, g) for the 16 columns j: doubles 16 c + 8 t + 2 g, + 1 of row 16 j + q of L21
+#pragma unroll
+	for (int c = 0; c < 4; c++)
+#pragma unroll
+		for (int t = 0; t < 2; t++) {
+			d2_t bf[4];
+#pragma unroll
+			for (int j = 0; j < 4; j++) bf[j] = *reinterpret_cast<const d2_t *>(&M[(16 * j + q) * LP + 16 * c + 8 * t + 2 * g]);
+#pragma unroll
+			for (int h = 0; h < 2; h++)
+#pragma unroll
+				for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[2 * c + t][h], bf[j][h], acc[j], 0, 0, 1);
+		}
+	if (b == 0 && fa) {
+		// factor-ahead, as in gemm_nt_kernel: the updated diagonal block is factored here and leaves as L with its diagonal
+		// inverses; its 1-based failed pivot goes to the matrix's info word
+		__syncthreads();                   // the last read of the L21 image
+		double *A = M;
+#pragma unroll
+		for (int j = 0; j < 4; j++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) A[(16 * uw + g + 4 * r) * LP + 16 * j + q] = acc[j][r];
+		__syncthreads();
+		double *Dg = T + (long)(c0 + LEAF) * ld + c0 + LEAF;
+		int bad = 0;
+		if (wave == 0) panel_factor<0, LP>(A, lane, bad, 0);
+		__syncthreads();
+		panel_update<0, LP>(A, wave, lane);
+		__syncthreads();
+		if (wave == 0) panel_factor<1, LP>(A, lane, bad, 0);
+		else if (wave == 1) diag_inverse_ahead(A, 0, lane, Dg, ld);
+		__syncthreads();
+		panel_update<1, LP>(A, wave, lane);
+		__syncthreads();
+		if (wave == 0) panel_factor<2, LP>(A, lane, bad, 0);
+		else if (wave == 2) diag_inverse_ahead(A, 1, lane, Dg, ld);
+		__syncthreads();
+		panel_update<2, LP>(A, wave, lane);
+		__syncthreads();
+		if (wave == 0) panel_factor<3, LP>(A, lane, bad, 0);
+		else if (wave == 3) diag_inverse_ahead(A, 2, lane, Dg, ld);
+		__syncthreads();
+		if (wave == 1) diag_inverse_ahead(A, 3, lane, Dg, ld);
+		if (tid == 0 && bad) atomicMin(info + blockIdx.y, c0 + LEAF + bad);
+#pragma unroll
+		for (int u = 0; u < 16; u++) {
+			const int r = wave + 4 * u;
+			if (lane <= r) Dg[(long)r * ld + lane] = A[r * LP + lane];
+		}
+		trace_end(trace, tr0);
+		return;
+	}
+#pragma unroll
+	for (int r = 0; r < 4; r++)
+#pragma unroll
+		for (int j = 0; j < 4; j++) (wrow + (long)(4 * r) * ld + coff)[16 * j] = acc[j][r];
+	trace_end(trace, tr0);
+}
+
+hipError_t launch_leaf_pair(hipStream_t s, double *T, long ld, int c0, int m_below, int *info, unsigned long long *tr, int nbatch,
+                            long bstride, bool fa)
+{
+	if (nbatch < 1) nbatch = 1;
+	if (m_below < LEAF || m_below % LEAF) return hipErrorInvalidValue;
+	hipLaunchKernelGGL(leaf_pair_kernel, dim3(m_below / LEAF, nbatch), dim3(256), 0, s, T, ld, c0, m_below, info, tr, bstride, fa ? 1 : 0);
+	return hipGetLastError();
+}
+
 hipError_t launch_leaf(hipStream_t s, double *T, long ld, int c0, int m_below, int *info, unsigned long long *trf,
-                       unsigned long long *trs, int nbatch, long bstride, bool skip_factor, int staged, bool pre)
+                       unsigned long long *trs, int nbatch, long bstride, bool skip_factor, int staged, bool pre, int c0b)
 {
 	if (nbatch < 1) nbatch = 1;
 	if (!skip_factor)                    // (skipped: the diagonal block was factored by the update before, factor-ahead)
 		hipLaunchKernelGGL(leaf_factor_kernel, dim3(1, nbatch), dim3(256), 0, s, T, ld, c0, info, trf, bstride);
 	if (m_below > 0) {
-		const dim3 grid((m_below + 63) / 64, nbatch);
+		const dim3 grid((m_below + 63) / 64 + (c0b >= 0 ? 1 : 0), nbatch);
 		// staged rows pay once the launch is bound by the block column's traffic (a lock-step batch: more workgroups than
 		// the chip holds at once); one matrix is latency-bound and keeps the direct form (staged < 0: automatic)
 		const bool st = staged < 0 ? (long)grid.x * grid.y >= 1024 : staged != 0;
-		if (st && pre) hipLaunchKernelGGL((leaf_solve_kernel<true, true>), grid, dim3(256), 0, s, T, ld, c0, m_below, trs, bstride);
-		else if (st) hipLaunchKernelGGL((leaf_solve_kernel<true, false>), grid, dim3(256), 0, s, T, ld, c0, m_below, trs, bstride);
-		else if (pre) hipLaunchKernelGGL((leaf_solve_kernel<false, true>), grid, dim3(256), 0, s, T, ld, c0, m_below, trs, bstride);
-		else hipLaunchKernelGGL((leaf_solve_kernel<false, false>), grid, dim3(256), 0, s, T, ld, c0, m_below, trs, bstride);
+		if (st && pre) hipLaunchKernelGGL((leaf_solve_kernel<true, true>), grid, dim3(256), 0, s, T, ld, c0, m_below, trs, bstride, c0b);
+		else if (st) hipLaunchKernelGGL((leaf_solve_kernel<true, false>), grid, dim3(256), 0, s, T, ld, c0, m_below, trs, bstride, c0b);
+		else if (pre) hipLaunchKernelGGL((leaf_solve_kernel<false, true>), grid, dim3(256), 0, s, T, ld, c0, m_below, trs, bstride, c0b);
+		else hipLaunchKernelGGL((leaf_solve_kernel<false, false>), grid, dim3(256), 0, s, T, ld, c0, m_below, trs, bstride, c0b);
 	}
 	return hipGetLastError();
 }

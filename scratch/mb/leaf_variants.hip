@@ -19,7 +19,7 @@ template <bool ST, int DBG> static double run(hipStream_t s, double *T, int N, i
 		hipEventRecord(e0, s);
 		for (int c0 = 0; c0 + 128 < N; c0 += 256) {
 			const int m = N + 64 - c0 - 64;
-			hipLaunchKernelGGL((leaf_solve_kernel<ST, false, DBG>), dim3((m + 63) / 64, B), dim3(256), 0, s, T, (long)N, c0, m, (unsigned long long *)nullptr, bstride);
+			hipLaunchKernelGGL((leaf_solve_kernel<ST, false, DBG>), dim3((m + 63) / 64, B), dim3(256), 0, s, T, (long)N, c0, m, (unsigned long long *)nullptr, bstride, -1);
 			bytes += (long)m * 64 * 16 * B;
 		}
 		hipEventRecord(e1, s); hipEventSynchronize(e1);

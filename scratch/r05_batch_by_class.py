@@ -40,14 +40,14 @@ for ln in lines:
             fl = 2.0 * kk * B * (nn * (nn + 1) / 2.0 + (mm - nn) * nn)
     else:
         key = tag.strip().split()[0]; fl = 0.0
-    a = agg.setdefault(key, [0, 0.0, 0.0])
-    a[0] += 1; a[1] += (e - s) / 1e3; a[2] += fl
+    a = agg.setdefault(key, [0, 0.0, 0.0, 0, 0])
+    a[0] += 1; a[1] += (e - s) / 1e3; a[2] += fl; a[3] += q[2]; a[4] += q[3]
 tot = (last - first) / 1e3
 print("N=%d d=%d B=%d kind=%d order=%d inv=%d : traced window %.1f us (first workgroup start to last end of the potrf launches)" % (N, d, B, kind, order, inv, tot))
-print("%-34s %6s %10s %6s %12s %8s" % ("class", "n", "wall_us", "pct", "mfma_us", "frac"))
-for k, (n, w, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+print("%-34s %6s %10s %6s %12s %8s %8s" % ("class", "n", "wall_us", "pct", "mfma_us", "frac", "wg_us"))
+for k, (n, w, fl, lsum, lcnt) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     ideal = fl / 78.6e12 * 1e6
-    print("%-34s %6d %10.1f %6.1f %12.1f %8.2f" % (k, n, w, 100 * w / tot, ideal, ideal / w if w else 0))
+    print("%-34s %6d %10.1f %6.1f %12.1f %8.2f %8.2f" % (k, n, w, 100 * w / tot, ideal, ideal / w if w else 0, lsum / max(lcnt, 1) / 1e3))
 print("sum of launch walls %.1f us; N^3/3 x B at peak %.1f us -> potrf fraction %.3f" % (
     sum(v[1] for v in agg.values()), B * Np ** 3 / 3.0 / 78.6e12 * 1e6, B * Np ** 3 / 3.0 / 78.6e12 * 1e6 / tot))
 t0 = time.perf_counter()

@@ -1320,7 +1320,8 @@ def _schedule_run(monkeypatch, env):
                                  {"GPEMU_NEG_MODIFIER": "0", "GPEMU_GEMM_BIG_TILES": "1"},
                                  {"GPEMU_LEAF_STAGED": "1"}, {"GPEMU_LEAF_STAGED": "0"}, {"GPEMU_DIAG_INV_AHEAD": "0"},
                                  {"GPEMU_DIAG_INV_AHEAD": "0", "GPEMU_LEAF_STAGED": "1"},
-                                 {"GPEMU_LEAF_STAGED": "1", "GPEMU_FACTOR_AHEAD": "0"}])
+                                 {"GPEMU_LEAF_STAGED": "1", "GPEMU_FACTOR_AHEAD": "0"}, {"GPEMU_LEAF_PAIR": "0"},
+                                 {"GPEMU_LEAF_PAIR": "0", "GPEMU_LEAF_STAGED": "1"}])
 def test_schedule_switches_keep_parity(monkeypatch, env):
     """the measurement switches of INTEGRATION.md (factor-ahead, panel widths, tile shapes, tile order, no graph, the form
     of the prediction sweep's k-vector fill) change the
