@@ -40,14 +40,15 @@ for ln in lines:
             fl = 2.0 * kk * B * (nn * (nn + 1) / 2.0 + (mm - nn) * nn)
     else:
         key = tag.strip().split()[0]; fl = 0.0
-    a = agg.setdefault(key, [0, 0.0, 0.0, 0, 0])
-    a[0] += 1; a[1] += (e - s) / 1e3; a[2] += fl; a[3] += q[2]; a[4] += q[3]
+    a = agg.setdefault(key, [0, 0.0, 0.0, 0, 0, 0, 0, 0])
+    a[0] += 1; a[1] += (e - s) / 1e3; a[2] += fl; a[3] += q[2]; a[4] += q[3]; a[5] += q[4]; a[6] += q[5]; a[7] += q[7]
 tot = (last - first) / 1e3
 print("N=%d d=%d B=%d kind=%d order=%d inv=%d : traced window %.1f us (first workgroup start to last end of the potrf launches)" % (N, d, B, kind, order, inv, tot))
-print("%-34s %6s %10s %6s %12s %8s %8s" % ("class", "n", "wall_us", "pct", "mfma_us", "frac", "wg_us"))
-for k, (n, w, fl, lsum, lcnt) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+print("%-34s %6s %10s %6s %12s %8s %8s %9s %9s %9s" % ("class", "n", "wall_us", "pct", "mfma_us", "frac", "wg_us", "wg_clk", "prolog_clk", "land_clk"))
+for k, (n, w, fl, lsum, lcnt, csum, psum, wsum) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     ideal = fl / 78.6e12 * 1e6
-    print("%-34s %6d %10.1f %6.1f %12.1f %8.2f %8.2f" % (k, n, w, 100 * w / tot, ideal, ideal / w if w else 0, lsum / max(lcnt, 1) / 1e3))
+    print("%-34s %6d %10.1f %6.1f %12.1f %8.2f %8.2f %9.0f %9.0f %9.0f" % (k, n, w, 100 * w / tot, ideal, ideal / w if w else 0, lsum / max(lcnt, 1) / 1e3,
+                                                                        csum / max(lcnt, 1), psum / max(lcnt, 1), wsum / max(lcnt, 1)))
 print("sum of launch walls %.1f us; N^3/3 x B at peak %.1f us -> potrf fraction %.3f" % (
     sum(v[1] for v in agg.values()), B * Np ** 3 / 3.0 / 78.6e12 * 1e6, B * Np ** 3 / 3.0 / 78.6e12 * 1e6 / tot))
 t0 = time.perf_counter()
