@@ -11,7 +11,7 @@ import sys
 
 KEYS = [("gemm_nt_kernel<128, 128", "gemm_nt_kernel_128x128_8waves_dma"), ("gemm_nt_kernel<64, 64, 4, 2, 2, 1", "gemm_nt_kernel_64x64_factor_ahead"),
         ("gemm_nt_kernel<64, 64, 4, 2, 2, 0", "gemm_nt_kernel_64x64"), ("cov_stage_gram_kernel", "cov_stage_kernel"), ("cov_stage_batch_kernel", "cov_stage_kernel"),
-        ("leaf_solve_kernel", "leaf_solve_kernel"), ("leaf_factor_kernel", "leaf_factor_kernel")]
+        ("leaf_solve_kernel", "leaf_solve_kernel"), ("leaf_factor_kernel", "leaf_factor_kernel"), ("leaf_pair_kernel", "leaf_pair_kernel")]
 out = {"workload": sys.argv[2] if len(sys.argv) > 2 else "", "units": "rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB; converted to bytes here",
        "correction": "FETCH_SIZE x 2 on gfx950 (MI355X_MICROARCH.md; the 8-B/lane C-tile reads calibrate to the same half, "
                      "profiles/r01_pmc_fetch_calibration.txt); WRITE_SIZE exact; Infinity-Cache hits are counted: fabric traffic, "
