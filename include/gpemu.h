@@ -290,6 +290,10 @@ int gpemu_test_staged_matrix(gpemu_ctx *ctx, int nb, const double *thetas, int n
  * of sb x sb tiles: entry q * 8 + x is the q-th tile of XCD x, (tm << 16) | tn, or -1 (unused tail slot).  Host logic
  * only (no device).  Returns the table length, or -GPEMU_ERR_ARG; writes min(length, cap) entries to out. */
 int gpemu_test_tile_table(int tiles_m, int tiles_n, int tri, int sb, int *out, int cap);
+/* the table of the square product with row-start skipping (C^-1 = U U^T; tile (r, c <= r), tile row r contracting from
+ * k = max(k0, floor16(r * bm - kstart_off)) to k1): whole tile rows per XCD, rows dealt longest-work-first to the least
+ * loaded XCD, each XCD's rows by decreasing k-range.  Same entry format and return value as above. */
+int gpemu_test_row_table(int tiles_m, int bm, int kstart_off, int k0, int k1, int *out, int cap);
 
 #ifdef __cplusplus
 }

@@ -81,6 +81,7 @@ SYMBOLS = {
     "gpemu_test_potrf": (C.c_int, [C.c_void_p, C.c_int, _dp, _ip]),
     "gpemu_test_staged_matrix": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, C.c_int, _dp]),
     "gpemu_test_tile_table": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _ip, C.c_int]),
+    "gpemu_test_row_table": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip, C.c_int]),
 }
 
 _lib = None

@@ -99,6 +99,7 @@ static hipError_t gemm(gpemu_ctx *ctx, const GemmArgs &a_in)
 	a.table_sb = ctx->sched.gemm_table;
 	a.keep_idle_waves = ctx->sched.idle_waves ? 0 : 1;
 	a.stagger_ticks = ctx->sched.stagger_us * 100;
+	a.row_table = ctx->sched.corner_row_table;
 	a.no_neg_modifier = ctx->sched.neg_modifier ? 0 : 1;
 	a.trace = trace_slot(ctx, "gemm m=%d n=%d k=%d", a.m, a.n, a.k1 - a.k0);
 	// GPEMU_PROF_GEMM: every GEMM launch; GPEMU_PROF_GEMM_BIG: only the launches that run the 128x128 8-wave kernel
@@ -163,6 +164,7 @@ static Sched read_environment()
 	sc.factor_ahead = geti("GPEMU_FACTOR_AHEAD", 1) != 0;
 	sc.diag_inv_ahead = geti("GPEMU_DIAG_INV_AHEAD", 1) != 0;
 	sc.leaf_pair = geti("GPEMU_LEAF_PAIR", 1) != 0;
+	sc.corner_row_table = geti("GPEMU_CORNER_ROW_TABLE", 1) != 0;
 	v = geti("GPEMU_LEAF_STAGED", -1);
 	sc.leaf_staged = v == 0 || v == 1 ? v : -1;
 	v = geti("GPEMU_NB_TOP", 0);
@@ -1928,6 +1930,16 @@ extern "C" int gpemu_test_tile_table(int tiles_m, int tiles_n, int tri, int sb, 
 {
 	if (tiles_m < 1 || tiles_n < 1 || tiles_m > 32767 || tiles_n > 32767 || sb < 1) return -GPEMU_ERR_ARG;
 	const std::vector<int> t = gpemu::build_tile_table(tiles_m, tiles_n, tri, sb);
+	if (out)
+		for (int i = 0; i < (int)t.size() && i < cap; i++) out[i] = t[i];
+	return (int)t.size();
+}
+
+/* the row table of the square product with row-start skipping (gpemu::build_row_table): same hook, same conventions */
+extern "C" int gpemu_test_row_table(int tiles_m, int bm, int kstart_off, int k0, int k1, int *out, int cap)
+{
+	if (tiles_m < 1 || tiles_m > 32767 || bm < 16 || k1 <= k0) return -GPEMU_ERR_ARG;
+	const std::vector<int> t = gpemu::build_row_table(tiles_m, bm, kstart_off, k0, k1);
 	if (out)
 		for (int i = 0; i < (int)t.size() && i < cap; i++) out[i] = t[i];
 	return (int)t.size();

@@ -71,6 +71,7 @@ struct GemmArgs {
 	int force_cfg;       // test/bench hook: 2 = 64x64 tiles, 8 = 128x128 tiles, 0 = automatic
 	int keep_idle_waves; // 1: waves above the diagonal of a triangular update's diagonal tiles compute their (unread) output anyway (A/B switch)
 	int no_neg_modifier; // 1: alpha = -1 by negating the accumulators on the way in and out, as rounds 1-3 did (A/B switch)
+	int row_table;       // 1: the square product with row-start skipping (C^-1 = U U^T) gives whole tile rows to an XCD (build_row_table)
 	int stagger_ticks;   // > 0: of the launch's first round, the workgroup in the odd slot of its CU starts this many 10 ns ticks late (kernel comment)
 };
 
@@ -93,6 +94,7 @@ struct Sched {
 	int leaf_staged = -1;        // GPEMU_LEAF_STAGED: the leaf solve moves whole 512-byte row pieces through an LDS strip (1), element-wise (0), automatic by launch size (-1)
 	int diag_inv_ahead = 1;      // GPEMU_DIAG_INV_AHEAD: the leaf solve takes the 16x16 diagonal inverses the factoring workgroup left in the block's upper part (0: every workgroup computes them)
 	int leaf_pair = 1;           // GPEMU_LEAF_PAIR: first block of a 128-column pair in one launch (leaf solve + K=64 update, leaf_pair_kernel); 0: two launches
+	int corner_row_table = 1;    // GPEMU_CORNER_ROW_TABLE: C^-1 = U U^T with whole tile rows per XCD (0: row-major enumeration, round-robin over the XCDs)
 	int stagger_us = 20;         // GPEMU_STAGGER_US: first-round offset between the two workgroups of a CU in the 128x128 GEMM (0 = none)
 };
 
@@ -249,6 +251,7 @@ hipError_t launch_skinny_nt(hipStream_t s, const double *Kq, long ldk, const dou
 hipError_t launch_gemv_tri(hipStream_t s, const double *Kq, long ldk, const double *L, long ldl, double *Vp, long ldv,
                            long sstride, int mq, int ntot, int K, int ntri, int nslice, int klen);
 std::vector<int> build_tile_table(int tiles_m, int tiles_n, int tri, int S, int bm = 128, int bn = 128);
+std::vector<int> build_row_table(int tiles_m, int bm, int kstart_off, int k0, int k1);
 hipError_t launch_leaf(hipStream_t s, double *T, long ld, int c0, int m_below, int *info,
                        unsigned long long *trace_factor = nullptr, unsigned long long *trace_solve = nullptr,
                        int nbatch = 1, long bstride = 0, bool skip_factor = false, int staged = -1, bool pre = true, int c0b = -1);

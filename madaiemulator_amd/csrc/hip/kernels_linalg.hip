@@ -693,17 +693,61 @@ std::vector<int> build_tile_table(int tiles_m, int tiles_n, int tri, int S, int 
 	return table;
 }
 
-static TileTable gemm_tile_table(hipStream_t s, int tiles_m, int tiles_n, int tri, int bm, int bn, int sb)
+// The square product with row-start skipping (C^-1 = U U^T of the gradient path: tile (r, c <= r) contracts over k >= the
+// first column of tile row r, so the tiles of ONE tile row have one k-range and run in step, sharing their A panel chunk by
+// chunk; no two tiles of different rows are ever at the same k).  Dealt round-robin in row-major order, a row's tiles sit
+// on all eight XCDs and every tile streams both its panels through the fabric: 21.6 GB per launch of 16 matrices at
+// N = 4096 for 2.2 GB of operands, 3.5 TB/s at 0.75 of the matrix peak (profiles/r05_corner_product_tile_table_ab.txt).
+// This table gives whole tile rows to an XCD -- rows dealt to the XCDs longest-work-first onto the least loaded one, each
+// XCD's rows in order of decreasing k-range -- so that a row's A panel crosses the fabric once.  (Round 5's first attempt
+// gave each XCD a CONTIGUOUS eighth of the rows by work: the XCD with the short rows finished last.)
+// entry q * 8 + x = the q-th tile of XCD x, -1 beyond its share.
+std::vector<int> build_row_table(int tiles_m, int bm, int kstart_off, int k0, int k1)
+{
+	struct Row { int r; long work; };
+	std::vector<Row> rows;
+	for (int r = 0; r < tiles_m; r++) {
+		int ks = (r * bm - kstart_off) & ~(GEMM_BK - 1);
+		if (ks < k0) ks = k0;
+		const long K = std::max(0, k1 - ks);
+		rows.push_back(Row{r, (long)(r + 1) * (K + 6 * GEMM_BK)});          // (a tile's fixed cost counted as six k-steps)
+	}
+	std::sort(rows.begin(), rows.end(), [](const Row &a, const Row &b) { return a.work != b.work ? a.work > b.work : a.r < b.r; });
+	long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	std::vector<int> mine[8];
+	for (const Row &w : rows) {
+		int x = 0;
+		for (int y = 1; y < 8; y++)
+			if (load[y] < load[x]) x = y;
+		load[x] += w.work;
+		mine[x].push_back(w.r);
+	}
+	size_t maxlen = 0;
+	std::vector<int> seq[8];
+	for (int x = 0; x < 8; x++) {
+		std::sort(mine[x].begin(), mine[x].end());                             // decreasing k-range = increasing row
+		for (int r : mine[x])
+			for (int c = 0; c <= r; c++) seq[x].push_back((r << 16) | c);
+		maxlen = std::max(maxlen, seq[x].size());
+	}
+	std::vector<int> table(8 * maxlen, -1);
+	for (int x = 0; x < 8; x++)
+		for (size_t q = 0; q < seq[x].size(); q++) table[q * 8 + x] = seq[x][q];
+	return table;
+}
+
+// rowtab: the row table above (tiles_n = kstart_off, tri = 2 + k0, sb = k1 in the cache key)
+static TileTable gemm_tile_table(hipStream_t s, int tiles_m, int tiles_n, int tri, int bm, int bn, int sb, bool rowtab = false)
 {
 	int dev = 0;
 	(void)hipGetDevice(&dev);
-	const auto key = std::make_tuple(dev, tiles_m, tiles_n, tri, sb, bm, bn);
+	const auto key = std::make_tuple(dev, tiles_m, tiles_n, tri, sb, bm, rowtab ? -1 : bn);
 	std::lock_guard<std::mutex> lock(g_tile_mutex);
 	auto it = g_tile_tables.find(key);
 	if (it != g_tile_tables.end()) return it->second;
 	hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
 	if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return TileTable{nullptr, 0};
-	const std::vector<int> table = build_tile_table(tiles_m, tiles_n, tri, sb, bm, bn);
+	const std::vector<int> table = rowtab ? build_row_table(tiles_m, bm, tiles_n, tri - 2, sb) : build_tile_table(tiles_m, tiles_n, tri, sb, bm, bn);
 	TileTable tt{nullptr, (int)table.size()};
 	if (hipMalloc(&tt.dptr, table.size() * sizeof(int)) != hipSuccess ||
 	    hipMemcpyAsync(tt.dptr, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess ||
@@ -741,6 +785,10 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs &a_in)
 			const TileTable tt = gemm_tile_table(s, tiles_m, tiles_n, tri_ok ? 1 : 0, bm, bn, a.table_sb);
 			if (tt.dptr) { a.order_mode = 3; a.tile_table = tt.dptr; T = tt.len; }
 		}
+	}
+	if (a.row_table && a.kstart_mode && !a.kend_mode && tri_ok && a.m == a.n && bm == bn && tiles_m >= 16 && tiles_m < 32768 && a.ksplit <= 1) {
+		const TileTable tt = gemm_tile_table(s, tiles_m, a.kstart_off, 2 + a.k0, bm, bn, a.k1, true);
+		if (tt.dptr) { a.order_mode = 3; a.tile_table = tt.dptr; T = tt.len; }
 	}
 	// (the first-round offset pays from the second round on: a launch that fits two rounds of 512 resident workgroups or fewer
 	// would only start its odd slots late)

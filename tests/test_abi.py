@@ -96,3 +96,33 @@ def test_gemm_tile_table_is_a_balanced_permutation():
             blocks = {(tm // sb, tn // sb) for tm, tn in share}
             assert len(blocks) <= 4          # (triangular diagonal blocks hold half the tiles)
     assert L.gpemu_test_tile_table(0, 4, 0, 8, None, 0) < 0 and L.gpemu_test_tile_table(4, 40000, 0, 8, None, 0) < 0
+
+
+def test_row_table_gives_whole_tile_rows_to_an_xcd():
+    """the workgroup -> tile table of C^-1 = U U^T (host logic, no device): every lower tile exactly once, a tile row on
+    ONE XCD, an XCD's rows in order of decreasing k-range, the XCDs' shares of work within a few per cent"""
+    import numpy as np
+    L = abi.load()
+    for tiles_m, bm, off, k1 in [(33, 128, 64, 4096), (65, 128, 64, 8192), (17, 128, 64, 2048), (129, 128, 64, 16384), (40, 64, 64, 2496)]:
+        n = L.gpemu_test_row_table(tiles_m, bm, off, 0, k1, None, 0)
+        assert n > 0 and n % 8 == 0
+        buf = (ctypes.c_int * n)()
+        assert L.gpemu_test_row_table(tiles_m, bm, off, 0, k1, buf, n) == n
+        t = np.array(buf[:], dtype=np.int64).reshape(-1, 8)
+        got = [(int(e) >> 16, int(e) & 0xffff) for e in t.ravel() if e >= 0]
+        want = {(r, c) for r in range(tiles_m) for c in range(r + 1)}
+        assert len(got) == len(want) and set(got) == want
+        owner, work = {}, np.zeros(8)
+        for x in range(8):
+            col = [int(e) for e in t[:, x]]
+            cnt = sum(e >= 0 for e in col)
+            assert all(e >= 0 for e in col[:cnt]) and all(e < 0 for e in col[cnt:])
+            rows = [e >> 16 for e in col[:cnt]]
+            assert rows == sorted(rows)                              # decreasing k-range = increasing row, a row's tiles together
+            for r in set(rows):
+                assert owner.setdefault(r, x) == x
+                ks = max(0, ((r * bm - off) // 16) * 16)
+                work[x] += (r + 1) * (k1 - ks)
+        assert len(owner) == tiles_m
+        assert work.max() / work.mean() < (1.08 if tiles_m >= 33 else 1.15)
+    assert L.gpemu_test_row_table(0, 128, 64, 0, 4096, None, 0) < 0

@@ -1321,7 +1321,7 @@ def _schedule_run(monkeypatch, env):
                                  {"GPEMU_LEAF_STAGED": "1"}, {"GPEMU_LEAF_STAGED": "0"}, {"GPEMU_DIAG_INV_AHEAD": "0"},
                                  {"GPEMU_DIAG_INV_AHEAD": "0", "GPEMU_LEAF_STAGED": "1"},
                                  {"GPEMU_LEAF_STAGED": "1", "GPEMU_FACTOR_AHEAD": "0"}, {"GPEMU_LEAF_PAIR": "0"},
-                                 {"GPEMU_LEAF_PAIR": "0", "GPEMU_LEAF_STAGED": "1"}])
+                                 {"GPEMU_LEAF_PAIR": "0", "GPEMU_LEAF_STAGED": "1"}, {"GPEMU_CORNER_ROW_TABLE": "0"}])
 def test_schedule_switches_keep_parity(monkeypatch, env):
     """the measurement switches of INTEGRATION.md (factor-ahead, panel widths, tile shapes, tile order, no graph, the form
     of the prediction sweep's k-vector fill) change the
