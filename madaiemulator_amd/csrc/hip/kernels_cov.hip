@@ -915,38 +915,99 @@ __global__ void gather_alpha_kernel(const double *S, long lds_, int soff, long s
 	ag[(long)blockIdx.y * gstride + i] = a;
 }
 
-// Sum over the 256 threads of a workgroup of NV (<= 16) per-thread partials, in a fixed order: the partials go through
-// LDS (scratch: 256 x (NV + 1) doubles), the 16 threads of group g = tid >> 4 each add 16 of the 256 partials of value g
-// in thread order and a 4-step butterfly inside the group finishes.  Returns the total of value g in every thread of
-// group g (g < NV).  Two barriers per call, whatever NV: the tree reduction per value this replaces cost ten.
+// Sum over the 256 threads of a workgroup of NV (1 or 16) per-thread partials, in a fixed order.  Inside a wave the sixteen
+// values are summed by a butterfly that HALVES what a lane carries at every step: lanes l and l ^ 32 split the sixteen
+// between them (each adds the partner's half to its own), l ^ 16 the remaining eight, then four, then two -- after four
+// steps lane l holds the sum over sixteen lanes of value (l >> 2) & 15, two plain steps finish the wave: 17 exchanges of
+// a double per lane.  The four waves' totals meet in 64 doubles of LDS.  Returns the total of value `tid` in threads
+// tid < NV.  Two barriers per call.  (Rounds 3-5a exchanged all 256 x 16 partials through LDS: 35 KB per workgroup, which
+// with the coordinate tiles and the exp table left TWO workgroups per CU at d = 16 -- the gradient kernels ran at a
+// seventh of their instruction rate.)
 template <int NV>
 __device__ __forceinline__ double block_sum(const double (&acc)[NV], double *scratch)
 {
-	static_assert(NV >= 1 && NV <= 16, "one 16-thread group per value");
-	const int tid = threadIdx.x;
+	static_assert(NV == 1 || NV == 8 || NV == 16, "one value, eight or sixteen");
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	double v;
+	if (NV == 8) {
+		// (the same butterfly from eight values: three halving steps, lane l then holds value (l >> 3) & 7 summed over eight lanes)
+		double a4[4], a2[2];
+		{
+			const bool hi = (lane & 32) != 0;
 #pragma unroll
-	for (int v = 0; v < NV; v++) scratch[tid * (NV + 1) + v] = acc[v];
-	__syncthreads();
-	const int g = tid >> 4, s = tid & 15;
-	double sum = 0.0;
-	if (g < NV) {
+			for (int i = 0; i < 4; i++) {
+				const double mine = hi ? acc[(4 + i) % NV] : acc[i % NV], send = hi ? acc[i % NV] : acc[(4 + i) % NV];
+				a4[i] = mine + __shfl_xor(send, 32);
+			}
+		}
+		{
+			const bool hi = (lane & 16) != 0;
 #pragma unroll
-		for (int j = 0; j < 16; j++) sum += scratch[(s * 16 + j) * (NV + 1) + g];
+			for (int i = 0; i < 2; i++) {
+				const double mine = hi ? a4[2 + i] : a4[i], send = hi ? a4[i] : a4[2 + i];
+				a2[i] = mine + __shfl_xor(send, 16);
+			}
+		}
+		{
+			const bool hi = (lane & 8) != 0;
+			v = (hi ? a2[1] : a2[0]) + __shfl_xor(hi ? a2[0] : a2[1], 8);
+		}
+		v += __shfl_xor(v, 4);
+		v += __shfl_xor(v, 2);
+		v += __shfl_xor(v, 1);
+		if ((lane & 7) == 0) scratch[wave * 16 + (lane >> 3)] = v;
+	} else if (NV == 16) {
+		double a8[8], a4[4], a2[2];
+		{
+			const bool hi = (lane & 32) != 0;
+#pragma unroll
+			for (int i = 0; i < 8; i++) {
+				const double mine = hi ? acc[(8 + i) % NV] : acc[i % NV], send = hi ? acc[i % NV] : acc[(8 + i) % NV];
+				a8[i] = mine + __shfl_xor(send, 32);
+			}
+		}
+		{
+			const bool hi = (lane & 16) != 0;
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				const double mine = hi ? a8[4 + i] : a8[i], send = hi ? a8[i] : a8[4 + i];
+				a4[i] = mine + __shfl_xor(send, 16);
+			}
+		}
+		{
+			const bool hi = (lane & 8) != 0;
+#pragma unroll
+			for (int i = 0; i < 2; i++) {
+				const double mine = hi ? a4[2 + i] : a4[i], send = hi ? a4[i] : a4[2 + i];
+				a2[i] = mine + __shfl_xor(send, 8);
+			}
+		}
+		{
+			const bool hi = (lane & 4) != 0;
+			v = (hi ? a2[1] : a2[0]) + __shfl_xor(hi ? a2[0] : a2[1], 4);
+		}
+		v += __shfl_xor(v, 2);
+		v += __shfl_xor(v, 1);
+		if ((lane & 3) == 0) scratch[wave * 16 + (lane >> 2)] = v;
+	} else {
+		v = acc[0];
+		v += __shfl_xor(v, 32); v += __shfl_xor(v, 16); v += __shfl_xor(v, 8);
+		v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+		if (lane == 0) scratch[wave * 16] = v;
 	}
-	sum += __shfl_xor(sum, 8);
-	sum += __shfl_xor(sum, 4);
-	sum += __shfl_xor(sum, 2);
-	sum += __shfl_xor(sum, 1);
+	__syncthreads();
+	double sum = 0.0;
+	if (tid < NV) sum = ((scratch[tid] + scratch[16 + tid]) + scratch[32 + tid]) + scratch[48 + tid];
 	__syncthreads();
 	return sum;
 }
 
 // dynamic LDS of the two gradient kernels (doubles): two 64 x (d + 1) coordinate tiles, alpha of the tile's rows and
 // columns, the exp table, per-direction constants, the reduction scratch
-constexpr int GRAD_CHUNK = 8;                      // literal form: directions per reduction (2 sums each)
+constexpr int GRAD_CHUNK = 4;                      // literal form: directions per reduction (2 sums each: eight values, block_sum<8>)
 __host__ __device__ inline size_t grad_lds_doubles(int d, int tab_len)
 {
-	return (size_t)128 * (d + 1) + 128 + tab_len + 2 * (size_t)((d + 1) & ~1) + 256 * 17;
+	return (size_t)128 * (d + 1) + 128 + tab_len + 2 * (size_t)((d + 1) & ~1) + 64;
 }
 
 // exp(x), x <= 0, from the 1024-entry table 2^(j/1024) in LDS (the Gram-form fill's exp with amplitude 1), arguments
@@ -959,7 +1020,7 @@ __device__ __forceinline__ double fast_exp_neg_t(double x, const double *tab)
 // CLAMP = false: the host has checked that 1/2 e^{-2 theta_k} D^2 stays below 600 for every pair of design points and
 // every direction of the batch (the usual case), so the exp argument needs no lower bound
 template <bool CLAMP>
-__global__ __launch_bounds__(256) void grad_part_kernel(const double *S, long lds_, int soff, long sstride, const double *X,
+__global__ __launch_bounds__(256, 4) void grad_part_kernel(const double *S, long lds_, int soff, long sstride, const double *X,
                                                         int N, int d, const double *ag, int np_pad, long gstride, double *part,
                                                         long pstride)
 {
@@ -1003,7 +1064,14 @@ __global__ __launch_bounds__(256) void grad_part_kernel(const double *S, long ld
 
 	const int c = tid & 63, rsub = tid >> 6;
 	const int gc = tc * 64 + c;
-	double wa[16], wq[16];                 // weight x A_ab and weight x alpha_a alpha_b of the thread's 16 elements
+	// weight x A_ab of the thread's 16 elements; the weight x alpha_a alpha_b of the quadratic forms is NOT kept per element
+	// (32 more registers, and the kernel is paced by how many waves a SIMD holds: 252 registers = two waves, 128 = four):
+	// alpha_b is the thread's own column factor and leaves the sums, alpha_a comes from LDS (one address per wave: a
+	// broadcast) where it is used, and the weight is 2 for every element of a tile below the diagonal blocks (`interior`);
+	// the diagonal and edge tiles take it from two bit masks
+	const bool interior = tr > tc && tr * 64 + 63 < N && tc * 64 + 63 < N;
+	double wa[16];
+	unsigned m1 = 0, m2 = 0;               // elements of weight 1 (the diagonal) and 2
 	double tsum = 0.0;
 #pragma unroll
 	for (int u = 0; u < 16; u++) {
@@ -1013,9 +1081,11 @@ __global__ __launch_bounds__(256) void grad_part_kernel(const double *S, long ld
 		const double a = valid ? S[(long)(soff + gr) * lds_ + soff + gc] : 0.0;
 		const double w = valid ? ((gc == gr) ? 1.0 : 2.0) : 0.0;
 		wa[u] = w * a;
-		wq[u] = w * (ar_s[r] * ac_s[c]);
+		if (valid) { if (gc == gr) m1 |= 1u << u; else m2 |= 1u << u; }
 		if (gr == gc && gr < N) tsum += a;
 	}
+	const double acq = ac_s[c];
+	const double *arw = ar_s + rsub;       // alpha of the thread's rows: arw[4 u]
 	// trace of A; alpha^T alpha, rows of the diagonal tiles in index order
 	{
 		const double one[1] = {tsum};
@@ -1039,21 +1109,36 @@ __global__ __launch_bounds__(256) void grad_part_kernel(const double *S, long ld
 				const double nh = -hk[k];
 				const double xck = xc_t[k * 64 + c];
 				const double *xrk = xr_t + k * 64 + rsub;
+				if (interior) {
 #pragma unroll
-				for (int u = 0; u < 16; u++) {
-					const double D = xrk[4 * u] - xck;
-					const double uu = D * D;
-					const double x = nh * uu;
-					const double z = uu * (CLAMP ? fast_exp_neg_t(x, tab) : fast_exp_neg_g(x, tab));   // emulator.c:203 without its e^{-2 theta}
-					acc[2 * j] = fma(wa[u], z, acc[2 * j]);
-					acc[2 * j + 1] = fma(wq[u], z, acc[2 * j + 1]);
-					if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);         // four chains in flight
+					for (int u = 0; u < 16; u++) {
+						const double D = xrk[4 * u] - xck;
+						const double uu = D * D;
+						const double x = nh * uu;
+						const double z = uu * (CLAMP ? fast_exp_neg_t(x, tab) : fast_exp_neg_g(x, tab));   // emulator.c:203 without its e^{-2 theta}
+						acc[2 * j] = fma(wa[u], z, acc[2 * j]);
+						acc[2 * j + 1] = fma(arw[4 * u], z, acc[2 * j + 1]);
+						if (u & 1) __builtin_amdgcn_sched_barrier(0);            // two chains in flight (four waves per SIMD cover the rest)
+					}
+				} else {
+#pragma unroll
+					for (int u = 0; u < 16; u++) {
+						const double D = xrk[4 * u] - xck;
+						const double uu = D * D;
+						const double x = nh * uu;
+						const double z = uu * (CLAMP ? fast_exp_neg_t(x, tab) : fast_exp_neg_g(x, tab));
+						const double wsel = ((m2 >> u) & 1u) ? 2.0 : (((m1 >> u) & 1u) ? 1.0 : 0.0);
+						acc[2 * j] = fma(wa[u], z, acc[2 * j]);
+						acc[2 * j + 1] = fma(wsel * arw[4 * u], z, acc[2 * j + 1]);
+						if (u & 1) __builtin_amdgcn_sched_barrier(0);
+					}
 				}
+				acc[2 * j + 1] *= interior ? 2.0 * acq : acq;
 			}
 		}
 		const double tot = block_sum<2 * GRAD_CHUNK>(acc, scratch);
-		const int v = tid >> 4, k = k0 + (v >> 1);
-		if ((tid & 15) == 0 && k < d) part[(long)t * np + 2 * k + (v & 1)] = e2k[k] * tot;
+		const int v = tid, k = k0 + (v >> 1);
+		if (tid < 2 * GRAD_CHUNK && k < d) part[(long)t * np + 2 * k + (v & 1)] = e2k[k] * tot;
 	}
 }
 
@@ -1166,8 +1251,8 @@ __global__ __launch_bounds__(256) void grad_exact_kernel(const double *S, long l
 			acc[j] = sk;
 		}
 		const double tot = block_sum<16>(acc, scratch);
-		const int k = k0 + (tid >> 4);
-		if ((tid & 15) == 0 && k <= nd) part[t * np + k] = tot;
+		const int k = k0 + tid;
+		if (tid < 16 && k <= nd) part[t * np + k] = tot;
 	}
 }
 
@@ -1184,10 +1269,10 @@ __global__ __launch_bounds__(256) void grad_exact_kernel(const double *S, long l
 // recomputed from differences and take the exact "same point" test on the raw coordinates, as in the fill.
 // Lane (q, g) of wave w holds the elements (row 16 w + g + 4 r, column 16 j + q), r, j < 4.
 // LDS (doubles): coordinate tiles transposed [d][64] x 2, alpha x 2, table 1024, scales d, reduction scratch 256 x 17.
-__host__ __device__ inline size_t grad_gram_lds_doubles(int d) { return (size_t)128 * d + 128 + EXP_TAB_G + ((d + 1) & ~1) + 256 * 17; }
+__host__ __device__ inline size_t grad_gram_lds_doubles(int d) { return (size_t)128 * d + 128 + EXP_TAB_G + ((d + 1) & ~1) + 64; }
 
 template <int KIND>
-__global__ __launch_bounds__(256) void grad_exact_gram_kernel(const double *S, long lds_, int soff, long sstride, const double *X,
+__global__ __launch_bounds__(256, 4) void grad_exact_gram_kernel(const double *S, long lds_, int soff, long sstride, const double *X,
                                                               const double *Xg, int N, int d, const double *ag, long gstride,
                                                               double *part, long pstride, const CovParams *pp)
 {
@@ -1329,11 +1414,13 @@ __global__ __launch_bounds__(256) void grad_exact_gram_kernel(const double *S, l
 			if (same & (1u << (4 * r + j))) s_nug += W * ps.nug;
 		}
 	}
-	// the nd + 1 sums of the tile (directions 0 .. nd-1, then the nugget), sixteen per reduction
-	for (int k0 = 0; k0 <= nd; k0 += 16) {
-		double out[16];
+	// the nd + 1 sums of the tile (directions 0 .. nd-1, then the nugget), eight per reduction (sixteen kept 32 more
+	// registers alive: the kernel is paced by how many waves a SIMD holds -- 1 711 us per batch of 16 at N=4096, d=16 with
+	// two waves per SIMD, 968 us with four)
+	for (int k0 = 0; k0 <= nd; k0 += 8) {
+		double out[8];
 #pragma unroll
-		for (int jd = 0; jd < 16; jd++) {
+		for (int jd = 0; jd < 8; jd++) {
 			const int k = k0 + jd;
 			double sk = 0.0;
 			if (k == nd) {
@@ -1363,9 +1450,9 @@ __global__ __launch_bounds__(256) void grad_exact_gram_kernel(const double *S, l
 			}
 			out[jd] = sk;
 		}
-		const double tot = block_sum<16>(out, scratch);
-		const int k = k0 + (tid >> 4);
-		if ((tid & 15) == 0 && k <= nd) part[t * np + k] = tot;
+		const double tot = block_sum<8>(out, scratch);
+		const int k = k0 + tid;
+		if (tid < 8 && k <= nd) part[t * np + k] = tot;
 	}
 }
 
