@@ -451,9 +451,20 @@ __global__ __launch_bounds__(256) void cov_stage_batch_kernel(double *T, long ld
 // The same staging when EVERY matrix of the batch takes the Gram form (the usual case: make_cov_params): no difference-
 // form code and none of its 33 KB LDS tile in the kernel, so five workgroups fit a CU instead of three, and a workgroup
 // fills GRAM_TPW tiles with one set of tables.  Workgroups beyond the tiles copy the shared R rows as above.
+// waves per SIMD the staging kernel is compiled for (pow-exp, Matern): the fill's phases -- operands, distances on the matrix
+// unit, sixteen element chains, stores -- run one behind the other inside a wave, and what overlaps them is the other waves of
+// the SIMD.  Left to itself the compiler took 152 / 116 registers (three / four waves); bounded to four / five (120 / 91
+// registers, no spill) the fill went from 66.6 / 67.6 to 58.6 / 62.8 us per N=8192 matrix; five / six spill and lose
+// (77 / 72 us).  profiles/r05_fill_what_bounds_it.txt
+#ifndef GPEMU_FILL_WAVES_PE
+#define GPEMU_FILL_WAVES_PE 4
+#endif
+#ifndef GPEMU_FILL_WAVES_MT
+#define GPEMU_FILL_WAVES_MT 5
+#endif
 constexpr int GRAM_TPW = 4;
 template <int KIND>
-__global__ __launch_bounds__(256) void cov_stage_gram_kernel(double *T, long ld, long bstride, const double *X, int N, int Np,
+__global__ __launch_bounds__(256, KIND == GPEMU_POWEREXP ? GPEMU_FILL_WAVES_PE : GPEMU_FILL_WAVES_MT) void cov_stage_gram_kernel(double *T, long ld, long bstride, const double *X, int N, int Np,
                                                              int d, const CovParams *pp, int mode, const double *Rrows, int Rp,
                                                              const double *Xg, long rstride)
 {
@@ -560,7 +571,7 @@ hipError_t launch_cov_fill(hipStream_t s, double *out, long ld, const double *Xr
 // tile row (the same 64 queries against consecutive 64-point blocks of the design) with one set of tables; 9 KB of LDS,
 // d/4 + 1 matrix instructions per 256 elements instead of the difference form's 2 d subtract/FMA wave-instructions per element.
 template <int KIND>
-__global__ __launch_bounds__(256) void cov_kvec_gram_kernel(double *out, long ld, const double *Xq, int M, int Mp, const double *X,
+__global__ __launch_bounds__(256, 4) void cov_kvec_gram_kernel(double *out, long ld, const double *Xq, int M, int Mp, const double *X,
                                                             const double *Xg, const double *mid, int N, int Np, int d, CovParams p)
 {
 	__shared__ double tab[EXP_TAB_G];
@@ -1272,7 +1283,7 @@ __global__ __launch_bounds__(256) void grad_exact_kernel(const double *S, long l
 __host__ __device__ inline size_t grad_gram_lds_doubles(int d) { return (size_t)128 * d + 128 + EXP_TAB_G + ((d + 1) & ~1) + 64; }
 
 template <int KIND>
-__global__ __launch_bounds__(256, 4) void grad_exact_gram_kernel(const double *S, long lds_, int soff, long sstride, const double *X,
+__global__ __launch_bounds__(256, KIND == GPEMU_POWEREXP ? 4 : 1) void grad_exact_gram_kernel(const double *S, long lds_, int soff, long sstride, const double *X,
                                                               const double *Xg, int N, int d, const double *ag, long gstride,
                                                               double *part, long pstride, const CovParams *pp)
 {
