@@ -5,7 +5,7 @@
 #                                     GEMM launches of a batch by K, fill time, value+gradient kernel stats (exact, N=4096 d=16)
 set -e
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r05q
+O=$R/gpurun_out/r05r
 mkdir -p $O
 cd $R
 if [ "$1" = "A" ]; then
