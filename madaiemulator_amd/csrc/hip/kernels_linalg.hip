@@ -1064,6 +1064,28 @@ constexpr int LEAF_SROWS = 8;                 // rows of the tile in the strip a
 constexpr int LEAF_SPITCH = 512 + 32;         // bytes between strip rows: 8 rows x 4 lane groups x 8 bytes hit 64 different banks
 // DBG (scratch/mb/leaf_variants.hip only; the product instantiates 0): bit 0 skips the diagonal inverses, bit 1 the chain
 // PRE = true: the diagonal inverses come with the staged block (diag_inverse_ahead); false: every workgroup computes them (A/B switch)
+// coalesced pieces (lane: doubles ccol, ccol + 1 of tile rows 2 u + crow) -> the matrix unit's B/D layout (lane (q, g):
+// row q, doubles 16 j + g + 4 r) through the wave's strip, LEAF_SROWS rows at a time
+__device__ __forceinline__ void strip_rows_to_tile(char *strip, const d2_t (&in)[8], int lane, d4_t (&R)[4])
+{
+	// (the strip is written as 16-byte pieces and read as doubles: the empty asm statements keep the compiler from reordering them)
+	const int g = lane >> 4, q = lane & 15, crow = lane >> 5, ccol = 2 * (lane & 31);
+#pragma unroll
+	for (int h = 0; h < 16 / LEAF_SROWS; h++) {
+#pragma unroll
+		for (int u = 0; u < LEAF_SROWS / 2; u++)
+			*reinterpret_cast<d2_t *>(strip + (2 * u + crow) * LEAF_SPITCH + 8 * ccol) = in[h * (LEAF_SROWS / 2) + u];
+		asm volatile("" ::: "memory");
+		if ((q / LEAF_SROWS) == h) {
+			const char *sp = strip + (q % LEAF_SROWS) * LEAF_SPITCH + 8 * g;
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+#pragma unroll
+				for (int r = 0; r < 4; r++) R[j][r] = *reinterpret_cast<const double *>(sp + 8 * (16 * j + 4 * r));
+		}
+		asm volatile("" ::: "memory");
+	}
+}
 // c0b >= 0: the LAST workgroup of the launch has another job -- the 64 rows under the diagonal block at c0b (the sub-diagonal
 // block of a pair that leaf_pair_kernel left unsolved in place, see there)
 template <bool STAGED, bool PRE = true, int DBG = 0>
@@ -1116,25 +1138,9 @@ __global__ __launch_bounds__(256) void leaf_solve_kernel(double *T, long ld, int
 		const int sr = (wave == 3) ? 0 : wave, sc = (wave == 3) ? 3 : wave + 1;
 		if (!(DBG & 1)) tri_inverse16(M, 16 * wave, M + 16 * sr * LP + 16 * sc, lane);
 	}
-	if (STAGED) {
-		// rows 0 .. 7 of the tile through the strip into the lanes with q < 8, then rows 8 .. 15 into the others (the strip
-		// is this wave's alone and a wave's LDS operations execute in order: no barrier)
-#pragma unroll
-		for (int h = 0; h < 16 / LEAF_SROWS; h++) {
-#pragma unroll
-			for (int u = 0; u < LEAF_SROWS / 2; u++)
-				*reinterpret_cast<d2_t *>(strip + (2 * u + crow) * LEAF_SPITCH + 8 * ccol) = in[h * (LEAF_SROWS / 2) + u];
-			asm volatile("" ::: "memory");            // (the strip is written as 16-byte pieces and read as doubles)
-			if ((q / LEAF_SROWS) == h) {
-				const char *sp = strip + (q % LEAF_SROWS) * LEAF_SPITCH + 8 * g;
-#pragma unroll
-				for (int j = 0; j < 4; j++)
-#pragma unroll
-					for (int r = 0; r < 4; r++) R[j][r] = *reinterpret_cast<const double *>(sp + 8 * (16 * j + 4 * r));
-			}
-			asm volatile("" ::: "memory");
-		}
-	}
+	// rows 0 .. 7 of the tile through the strip into the lanes with q < 8, then rows 8 .. 15 into the others (the strip is
+	// this wave's alone and a wave's LDS operations execute in order: no barrier)
+	if (STAGED) strip_rows_to_tile(strip, in, lane, R);
 	__syncthreads();
 	if (prow0 >= m_below) return;
 	d4_t X[4];
@@ -1207,27 +1213,6 @@ __global__ __launch_bounds__(256) void leaf_solve_kernel(double *T, long ld, int
 // LDS: 33 KB (L with the diagonal inverses; then the image of L21; then, in workgroup 0, the tile being factored) + four
 // 4.25 KB strips.
 // ---------------------------------------------------------------------------
-// coalesced pieces (lane: doubles ccol, ccol + 1 of tile rows 2 u + crow) -> the matrix unit's B/D layout (lane (q, g):
-// row q, doubles 16 j + g + 4 r) through the wave's strip, LEAF_SROWS rows at a time
-__device__ __forceinline__ void strip_rows_to_tile(char *strip, const d2_t (&in)[8], int lane, d4_t (&R)[4])
-{
-	const int g = lane >> 4, q = lane & 15, crow = lane >> 5, ccol = 2 * (lane & 31);
-#pragma unroll
-	for (int h = 0; h < 16 / LEAF_SROWS; h++) {
-#pragma unroll
-		for (int u = 0; u < LEAF_SROWS / 2; u++)
-			*reinterpret_cast<d2_t *>(strip + (2 * u + crow) * LEAF_SPITCH + 8 * ccol) = in[h * (LEAF_SROWS / 2) + u];
-		asm volatile("" ::: "memory");
-		if ((q / LEAF_SROWS) == h) {
-			const char *sp = strip + (q % LEAF_SROWS) * LEAF_SPITCH + 8 * g;
-#pragma unroll
-			for (int j = 0; j < 4; j++)
-#pragma unroll
-				for (int r = 0; r < 4; r++) R[j][r] = *reinterpret_cast<const double *>(sp + 8 * (16 * j + 4 * r));
-		}
-		asm volatile("" ::: "memory");
-	}
-}
 // the leaf solve's chain for one 16-row tile: X_j^T = Linv_jj (B_j^T - sum_{i<j} L_ji X_i^T); M holds L with the inverses of
 // its diagonal 16x16 blocks in the upper blocks diag_inverse_block(j)
 __device__ __forceinline__ void leaf_chain(const d4_t (&R)[4], const double *M, int lane, d4_t (&X)[4])
