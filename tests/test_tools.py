@@ -42,3 +42,20 @@ def test_rocpd_summary_groups_kernels(tmp_path):
     assert "gemm_nt_kernel (all tile shapes)" in full.stdout and "      3 " in full.stdout
     only = subprocess.run([sys.executable, tool, str(db), "--grid-y", "16"], capture_output=True, text=True, timeout=60)
     assert only.returncode == 0 and "      2 " in only.stdout.split("gemm_nt_kernel (all tile shapes)")[1]
+
+
+def test_every_environment_variable_the_library_reads_is_documented():
+    """INTEGRATION.md lists the switches: a GPEMU_* name read with getenv anywhere in csrc/ must appear there"""
+    import glob, os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    names = set()
+    for f in glob.glob(os.path.join(root, "madaiemulator_amd", "csrc", "*", "*")):
+        if not f.endswith((".c", ".cpp", ".hip", ".h", ".hpp")):
+            continue
+        for line in open(f, errors="replace"):
+            if "getenv" in line or "geti(" in line or "env_int(" in line:
+                names.update(re.findall(r'"(GPEMU_[A-Z0-9_]+)"', line))
+    assert len(names) > 30
+    missing = sorted(n for n in names if n not in doc)
+    assert not missing, missing
