@@ -1379,6 +1379,32 @@ def test_tile_order_does_not_change_the_bits(monkeypatch):
     assert vals[0] == vals[1] == vals[2]
 
 
+def test_round5_chain_kernels_do_not_change_the_bits_at_a_baseline_size(monkeypatch):
+    """the round-5 kernels of the panel chain at the size where they are chosen automatically (N = 4096, lock-step batches of
+    32: the staged leaf solve, the diagonal inverses left by the factoring workgroup, leaf_pair_kernel, the row table of
+    C^-1 = U U^T): every one switched off gives the same value, sigma^2, beta and gradient to the last bit, and a batch element
+    equals the single evaluation"""
+    N, d, B = 4096, 8, 32
+    X, y = synth.design(N, d, 11)
+    ths = np.array([synth.perturbed_thetas(1, d, 4, i) for i in range(B)])
+    got = []
+    for env in ({}, {"GPEMU_LEAF_STAGED": "0"}, {"GPEMU_DIAG_INV_AHEAD": "0"}, {"GPEMU_LEAF_PAIR": "0"},
+                {"GPEMU_LEAF_STAGED": "0", "GPEMU_DIAG_INV_AHEAD": "0", "GPEMU_LEAF_PAIR": "0", "GPEMU_CORNER_ROW_TABLE": "0"}):
+        c = _ctx_with_env(monkeypatch, env)
+        c.set_model(1, 0, X, y)
+        rb = c.loglik_batch(ths)
+        r1 = c.loglik(ths[5])
+        assert r1["value"] == rb["value"][5] and r1["sigma2"] == rb["sigma2"][5]
+        rg = c.loglik_grad_batch(ths[:8])
+        assert np.array_equal(rg["value"], rb["value"][:8])
+        got.append((rb["value"].copy(), rb["sigma2"].copy(), rb["beta"].copy(), rg["grad"].copy()))
+        c.close()
+    for g in got[1:]:
+        for a, b in zip(got[0], g):
+            assert np.array_equal(a, b)
+    assert np.all(np.isfinite(got[0][0])) and np.all(np.isfinite(got[0][3]))
+
+
 def test_host_threads_with_their_own_contexts():
     """the boundary's threading contract (re-entrant across threads with distinct params): three host
     threads drive their own contexts at the same time (ctypes releases the GIL); every result equals, bit for
